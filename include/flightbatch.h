@@ -1,0 +1,188 @@
+/*
+ * flightbatch.h — C ABI of libflightbatch: MI355X-native batched 6-DOF flight-dynamics integrator.
+ *
+ * Drop-in boundary for ONE hot path of e271828e/Flight.jl: the per-step ODE evaluation and fixed-step
+ * RK4 integration of `Model(SimpleWorld(Cessna172Sv0()))`, executed for N independent aircraft at once.
+ * Every entry point cites the reference interface it stands behind (paths relative to the reference
+ * repository root; FC = lib/FlightCore/src, FP = lib/FlightPhysics/src, FA = lib/FlightApps/src).
+ * The reference has no FFI for this path (it is pure Julia); the binding a maintainer would add is a
+ * `ccall` shim — see INTEGRATION.md, following the in-tree precedent FC/joysticks.jl:45-53.
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 = ok, negative = error (message via fb_last_error()).
+ *  - handles are opaque, owned by the library; one handle = one HIP device + one stream.
+ *  - host arrays are caller-owned, contiguous, column-major [N x Nfield] with the aircraft index
+ *    fastest (structure-of-arrays): element (i, k) lives at ptr[k*N + i].
+ *  - calls on one handle are not thread-safe (mirrors the reference's io_lock, FC/sim.jl:545);
+ *    different handles may be driven from different threads.
+ *  - there is NO CPU fallback: fb_create fails when no HIP device is available.
+ */
+#ifndef FLIGHTBATCH_H
+#define FLIGHTBATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fb_handle_s* fb_handle;
+
+/* ---- model / kinematics / dtype ids -------------------------------------------------------- */
+enum { FB_MODEL_C172S0 = 0, FB_MODEL_C172X2 = 1, FB_MODEL_ROBOT2D = 2 }; /* FA/c172/c172s/c172s0.jl:14-18 */
+enum { FB_KIN_WA = 0, FB_KIN_ECEF = 1, FB_KIN_NED = 2 };                 /* FP/kinematics.jl:148,250,329   */
+enum { FB_F64 = 0, FB_F32 = 1 };
+
+/* ---- continuous state x[FB_NX] of Cessna172Sv0 + WA kinematics (SURVEY.md §8 state layout) ---- */
+enum {
+    FB_X_ALPHA_FILT = 0, FB_X_BETA_FILT = 1, /* FA/c172/c172.jl:296 */
+    FB_X_LDG_FRC = 2,                        /* left[2], right[2], nose[2]; FP/landinggear.jl:380-382 */
+    FB_X_FUEL = 8,                           /* FA/c172/c172.jl:601 */
+    FB_X_ENG_OMEGA = 9, FB_X_ENG_IDLE = 10, FB_X_ENG_FRC = 11, /* FP/piston.jl:290-291 */
+    FB_X_Q_WB = 12, FB_X_Q_EW = 16, FB_X_H_E = 20,             /* FP/kinematics.jl:152-153 */
+    FB_X_OMEGA_EB_B = 21, FB_X_V_EB_B = 24,                    /* FP/dynamics.jl:436 */
+    FB_NX = 27
+};
+/* ---- discrete state s[FB_NS] (int32) ---- */
+enum {
+    FB_S_STALL = 0,     /* FA/c172/c172.jl:272-274 */
+    FB_S_ENG_STATE = 1, /* FP/piston.jl:198-202 : 0 off, 1 starting, 2 running */
+    FB_NS = 2
+};
+/* ---- real inputs u[FB_NU] ---- */
+enum {
+    FB_U_THROTTLE = 0, FB_U_MIXTURE = 1,                                  /* FP/piston.jl:259-267 */
+    FB_U_AILERON = 2, FB_U_ELEVATOR = 3, FB_U_RUDDER = 4,                 /* FA/c172/c172s/c172s.jl:62-72 */
+    FB_U_AILERON_OFFSET = 5, FB_U_ELEVATOR_OFFSET = 6, FB_U_RUDDER_OFFSET = 7,
+    FB_U_FLAPS = 8, FB_U_BRAKE_LEFT = 9, FB_U_BRAKE_RIGHT = 10,
+    FB_U_M_PILOT = 11, FB_U_M_COPILOT = 12, FB_U_M_LPASS = 13, FB_U_M_RPASS = 14, FB_U_M_BAGGAGE = 15, /* c172.jl:521-527 */
+    FB_NU = 16
+};
+/* ---- integer inputs ui[1]: bit field ---- */
+enum {
+    FB_UI_ENG_START = 1, FB_UI_ENG_STOP = 2, /* FP/piston.jl:260-261 */
+    FB_UI_MIXTURE_AUTO = 4,                  /* FP/piston.jl:263 */
+    FB_UI_STEERING_ENGAGED = 8,              /* FP/landinggear.jl:52-55 */
+    FB_UI_DEFAULT = 4 | 8,
+    FB_NUI = 1
+};
+/* ---- per-aircraft status word (exceptions of the reference become sticky bits) ---- */
+enum {
+    FB_ST_OK = 0,
+    FB_ST_ALT_RANGE = 1,      /* ArgumentError, FP/geodesy.jl:218-221 */
+    FB_ST_ISA_RANGE = 2,      /* ArgumentError, FP/atmosphere.jl:133  */
+    FB_ST_GROUND_CRASH = 4,   /* GroundCrash,   FP/landinggear.jl:331-347 */
+    FB_ST_NAN = 8,
+    FB_ST_CONTACT_ASSERT = 16 /* @assert, FP/landinggear.jl:321 */
+};
+/* ---- output record y[FB_NY] (what cb_save logs of `mdl.y`, FC/sim.jl:345-347) ---- */
+enum {
+    FB_Y_KIN = 0,    /* KinData, 40 doubles, FP/kinematics.jl:46-63:
+                        e_nb(psi,theta,phi) q_nb[4] q_eb[4] q_en[4] lat lon n_e[3] h_e h_o r_eb_e[3]
+                        w_wb_b[3] w_eb_b[3] v_eb_b[3] v_eb_n[3] v_gnd chi_gnd gamma_gnd */
+    FB_Y_AIR = 40,   /* AirData, 22 doubles, FP/atmosphere.jl:198-215:
+                        v_ew_n[3] v_ew_b[3] v_wb_b[3] T p rho a mu M Tt pt dp q TAS EAS CAS */
+    FB_Y_AERO = 62,  /* 16: alpha beta alpha_filt_dot beta_filt_dot C_D C_Y C_L C_l C_m C_n F[3] tau[3]; c172.jl:276-294 */
+    FB_Y_LDG = 78,   /* 3 x 11 (left,right,nose): dh wow xi xi_dot F_dmp_zs wr_b.F[3] wr_b.tau[3]; landinggear.jl:210-222,384-395 */
+    FB_Y_PWP = 111,  /* 22: engine MAP f mdot omega tau_shaft P_shaft SFC idle_out frc_out (piston.jl:269-287);
+                            propeller J Mt wr_b.F[3] wr_b.tau[3] hr_b[3] P eta_p (propellers.jl:378-390) */
+    FB_Y_FUEL = 133, /* 1: m_total; c172.jl:594-598 */
+    FB_Y_DYN = 134,  /* 40: mp_b.m mp_b.r_OG[3] mp_b.J[9 row-major] wr_b.F[3] wr_b.tau[3] wdot_eb_b[3] vdot_eb_b[3]
+                            a_eb_b[3] a_ib_b[3] f_c_c[3] alpha_ib_b[3] g_c_c[3]; dynamics.jl:416-434 */
+    FB_NY = 174
+};
+/* ---- trim (FA/c172/c172.jl:796-818) ---- */
+enum {
+    FB_TP_N_E = 0, /* n_e[3] */ FB_TP_H_E = 3, FB_TP_PSI_NB = 4, FB_TP_EAS = 5, FB_TP_GAMMA_WB_N = 6,
+    FB_TP_PSI_WB_DOT = 7, FB_TP_THETA_WB_DOT = 8, FB_TP_BETA_A = 9, FB_TP_FUEL_LOAD = 10, FB_TP_MIXTURE = 11,
+    FB_TP_FLAPS = 12, FB_TP_PAYLOAD = 13, /* 5 masses */
+    FB_NTP = 18
+};
+enum {
+    FB_TS_ALPHA_A = 0, FB_TS_PHI_NB = 1, FB_TS_N_ENG = 2, FB_TS_THROTTLE = 3, FB_TS_AILERON = 4,
+    FB_TS_ELEVATOR = 5, FB_TS_RUDDER = 6,
+    FB_NTS = 7
+};
+/* ---- lookup tables uploaded by the host. All doubles unless noted. ---- */
+enum {
+    FB_TABLE_EGM96 = 0,     /* float32 [721 x 1441], column-major [lat, lon]; FP/geodesy.jl:186-198 */
+    FB_TABLE_PROPELLER = 1, /* [21 x 21 x 6]: (J, Mt, {C_Fx,C_Mx,C_Fz_a,C_Mz_a,C_P,eta_p}); FP/propellers.jl:235-276 */
+    FB_TABLE_PISTON = 2,    /* packed blob, layout in csrc/tables.h; FP/piston.jl:70-195 */
+    FB_TABLE_AERO = 3       /* packed blob, layout in csrc/tables.h; FA/c172/c172.jl:51-199 */
+};
+
+/* World-level parameters shared by the whole batch (one SimpleWorld each in the reference, identical here) */
+typedef struct fb_params {
+    double dt;           /* integration step, FC/sim.jl:188 (default 0.02) */
+    int32_t periodic_n;  /* Δt/dt ratio for f_periodic!, FC/sim.jl:189 (unused by C172Sv0: no periodic dynamics) */
+    int32_t surface;     /* 0 DryTarmac, 1 WetTarmac, 2 IcyTarmac; FP/terrain.jl:13,38 */
+    double T_sl, p_sl;   /* TunableSeaLevel, FP/atmosphere.jl:75-78 */
+    double wind_ned[3];  /* TunableWind, FP/atmosphere.jl:165 */
+    double h_terrain;    /* HorizontalTerrain elevation (orthometric), FP/terrain.jl:34-36 */
+} fb_params;
+
+/* --------------------------------------------------------------------------------------------- */
+/* Model(SimpleWorld(...)) + Simulation(mdl; ...) : FC/modeling.jl:103-153, FC/sim.jl:183-255.
+ * device_id >= 0 selects the HIP device; there is no CPU backend (device_id < 0 is an error). */
+int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out);
+int32_t fb_destroy(fb_handle h);
+int64_t fb_size(fb_handle h);
+
+/* Run on an externally created HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
+int32_t fb_set_stream(fb_handle h, void* hip_stream);
+/* Use caller-owned DEVICE memory for x [N x FB_NX doubles] and s [N x FB_NS int32] (e.g. a torch
+ * tensor's data_ptr), so collectives can run on the state without a host round trip. NULL restores
+ * the handle's own buffers. */
+int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev);
+
+/* Lookup tables: what the reference builds at construction time (Appendix B of SURVEY.md). */
+int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t* dims, int32_t ndims);
+int32_t fb_set_params(fb_handle h, const fb_params* p);
+int32_t fb_get_params(fb_handle h, fb_params* p);
+
+/* mdl.x / mdl.s / mdl.u access : FC/modeling.jl:89-101 ; property forwarding FC/sim.jl:261-275 */
+int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s);
+int32_t fb_get_state(fb_handle h, double* x, int32_t* s);
+int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui);
+int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui);
+
+/* f_init!(world, C172.TrimParameters): FP/world.jl:49-57 -> FA/c172/c172.jl:883-942.
+ * trim_params [N x FB_NTP]; trim_state [N x FB_NTS] in: initial guess (c172.jl:796-804), out: solution.
+ * success[i] = 1 when cost <= 1e-16 (the reference's STOPVAL_REACHED criterion, c172.jl:926,934).
+ * On return x, s, u hold the trimmed initial condition (assign!, FA/c172/c172s/c172s.jl:227-263). */
+int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost);
+
+/* f_ode!(world) : FP/world.jl:26-32. Uses current x, u, s; writes xdot [N x FB_NX] (may be NULL)
+ * and refreshes the output record y. */
+int32_t fb_f_ode(fb_handle h, double* xdot);
+/* f_step!(world) : FP/world.jl:34-39. Acts on y of the last fb_f_ode, like the reference. */
+int32_t fb_f_step(fb_handle h);
+/* f_periodic!(Unconditional(), world) : FP/world.jl:41-47 (no-op for C172Sv0: @no_periodic everywhere). */
+int32_t fb_f_periodic(fb_handle h);
+/* mdl.y of the last fb_f_ode / fb_step : y [N x FB_NY] */
+int32_t fb_get_outputs(fb_handle h, double* y);
+
+/* nsteps x step!(sim) : FC/sim.jl:386 — RK4 (OrdinaryDiffEq, fixed dt) + callbacks in the order
+ * cb_step, cb_periodic, cb_user(no-op), FC/sim.jl:204-218. Asynchronous on the handle's stream. */
+int32_t fb_step(fb_handle h, int64_t nsteps);
+/* steps fused per kernel launch (state stays in registers between them). Default 1. */
+int32_t fb_set_steps_per_launch(fb_handle h, int32_t k);
+int32_t fb_sync(fb_handle h);
+/* sim.t : FC/sim.jl:261-275 */
+double fb_time(fb_handle h);
+
+/* SimulationTermination / ArgumentError mapping: per-aircraft sticky status bits (FB_ST_*). */
+int32_t fb_status(fb_handle h, int32_t* status);
+
+/* HIP-event timing on the handle's stream around the fb_step launches issued between begin and end;
+ * reports total elapsed ms and the number of stepping-kernel launches. */
+int32_t fb_timing_begin(fb_handle h);
+int32_t fb_timing_end(fb_handle h, float* ms, int64_t* n_launches);
+
+const char* fb_last_error(void);
+const char* fb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLIGHTBATCH_H */

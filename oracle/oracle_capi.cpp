@@ -1,0 +1,486 @@
+// TEST INFRASTRUCTURE — CPU oracle, not product code.
+// extern "C" surface of the CPU oracle, loaded with ctypes by tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg ONLY. Array conventions are those of include/flightbatch.h
+// (structure-of-arrays, aircraft index fastest) so that results compare element-for-element with the
+// HIP library's.
+//
+// PARITY STATUS: the reference (Julia) cannot run here and ships no golden vectors for trajectories.
+// This restatement is pinned by the reference's own known-answer / tolerance tests (tests/test_oracle_*.py
+// cite each one); the 1e-6 trajectory figure against a real Julia run remains "parity unpinned".
+#include "fo_c172.hpp"
+#include "../include/flightbatch.h"
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace fo;
+
+static std::vector<float> g_geoid;
+static std::unique_ptr<C172Model> g_model;
+
+static Env env_from(const double* e) {
+    Env v;
+    v.T_sl = e[0]; v.p_sl = e[1]; v.wind = {e[2], e[3], e[4]}; v.h_trn = e[5]; v.surface = (int)e[6];
+    return v;
+}
+static C172Inputs inputs_from(const double* u, const int32_t* ui, int64_t n, int64_t i) {
+    C172Inputs c;
+    auto U = [&](int k) { return u[k * n + i]; };
+    c.throttle = U(FB_U_THROTTLE); c.mixture = U(FB_U_MIXTURE);
+    c.aileron = U(FB_U_AILERON); c.elevator = U(FB_U_ELEVATOR); c.rudder = U(FB_U_RUDDER);
+    c.aileron_offset = U(FB_U_AILERON_OFFSET); c.elevator_offset = U(FB_U_ELEVATOR_OFFSET); c.rudder_offset = U(FB_U_RUDDER_OFFSET);
+    c.flaps = U(FB_U_FLAPS); c.brake_left = U(FB_U_BRAKE_LEFT); c.brake_right = U(FB_U_BRAKE_RIGHT);
+    c.m_pilot = U(FB_U_M_PILOT); c.m_copilot = U(FB_U_M_COPILOT); c.m_lpass = U(FB_U_M_LPASS);
+    c.m_rpass = U(FB_U_M_RPASS); c.m_baggage = U(FB_U_M_BAGGAGE);
+    const int32_t b = ui[i];
+    c.eng_start = b & FB_UI_ENG_START; c.eng_stop = b & FB_UI_ENG_STOP;
+    c.mixture_ctl = (b & FB_UI_MIXTURE_AUTO) ? MIX_AUTO : MIX_MANUAL;
+    c.steering_engaged = b & FB_UI_STEERING_ENGAGED;
+    return c;
+}
+static void inputs_to(const C172Inputs& c, double* u, int32_t* ui, int64_t n, int64_t i) {
+    auto U = [&](int k) -> double& { return u[k * n + i]; };
+    U(FB_U_THROTTLE) = c.throttle; U(FB_U_MIXTURE) = c.mixture;
+    U(FB_U_AILERON) = c.aileron; U(FB_U_ELEVATOR) = c.elevator; U(FB_U_RUDDER) = c.rudder;
+    U(FB_U_AILERON_OFFSET) = c.aileron_offset; U(FB_U_ELEVATOR_OFFSET) = c.elevator_offset; U(FB_U_RUDDER_OFFSET) = c.rudder_offset;
+    U(FB_U_FLAPS) = c.flaps; U(FB_U_BRAKE_LEFT) = c.brake_left; U(FB_U_BRAKE_RIGHT) = c.brake_right;
+    U(FB_U_M_PILOT) = c.m_pilot; U(FB_U_M_COPILOT) = c.m_copilot; U(FB_U_M_LPASS) = c.m_lpass;
+    U(FB_U_M_RPASS) = c.m_rpass; U(FB_U_M_BAGGAGE) = c.m_baggage;
+    ui[i] = (c.eng_start ? FB_UI_ENG_START : 0) | (c.eng_stop ? FB_UI_ENG_STOP : 0) |
+            (c.mixture_ctl == MIX_AUTO ? FB_UI_MIXTURE_AUTO : 0) | (c.steering_engaged ? FB_UI_STEERING_ENGAGED : 0);
+}
+static void put3(double* y, int64_t n, int64_t i, int k, V3 v) { y[(k)*n + i] = v.x; y[(k + 1) * n + i] = v.y; y[(k + 2) * n + i] = v.z; }
+static void put4(double* y, int64_t n, int64_t i, int k, Quat q) { y[k * n + i] = q.w; y[(k + 1) * n + i] = q.x; y[(k + 2) * n + i] = q.y; y[(k + 3) * n + i] = q.z; }
+static void pack_y(const C172Y& Y, double* y, int64_t n, int64_t i) {
+    auto P = [&](int k) -> double& { return y[(int64_t)k * n + i]; };
+    int k = FB_Y_KIN;
+    const KinData& K = Y.kin;
+    P(k) = K.e_nb.psi; P(k + 1) = K.e_nb.theta; P(k + 2) = K.e_nb.phi; k += 3;
+    put4(y, n, i, k, K.q_nb); k += 4; put4(y, n, i, k, K.q_eb); k += 4; put4(y, n, i, k, K.q_en); k += 4;
+    P(k) = K.ll.phi; P(k + 1) = K.ll.lam; k += 2;
+    put3(y, n, i, k, K.n_e); k += 3;
+    P(k) = K.h_e; P(k + 1) = K.h_o; k += 2;
+    put3(y, n, i, k, K.r_eb_e); k += 3; put3(y, n, i, k, K.w_wb_b); k += 3; put3(y, n, i, k, K.w_eb_b); k += 3;
+    put3(y, n, i, k, K.v_eb_b); k += 3; put3(y, n, i, k, K.v_eb_n); k += 3;
+    P(k) = K.v_gnd; P(k + 1) = K.chi_gnd; P(k + 2) = K.gamma_gnd; k += 3;
+    const AirData& A = Y.air;
+    k = FB_Y_AIR;
+    put3(y, n, i, k, A.v_ew_n); k += 3; put3(y, n, i, k, A.v_ew_b); k += 3; put3(y, n, i, k, A.v_wb_b); k += 3;
+    const double av[13] = {A.T, A.p, A.rho, A.a, A.mu, A.M, A.Tt, A.pt, A.dp, A.q, A.TAS, A.EAS, A.CAS};
+    for (int j = 0; j < 13; j++) P(k + j) = av[j];
+    k = FB_Y_AERO;
+    const AeroY& E = Y.aero;
+    const double ev[10] = {E.alpha, E.beta, E.alpha_filt_dot, E.beta_filt_dot, E.coeffs.C_D, E.coeffs.C_Y, E.coeffs.C_L,
+                           E.coeffs.C_l, E.coeffs.C_m, E.coeffs.C_n};
+    for (int j = 0; j < 10; j++) P(k + j) = ev[j];
+    put3(y, n, i, k + 10, E.wr_b.F); put3(y, n, i, k + 13, E.wr_b.tau);
+    for (int g = 0; g < 3; g++) {
+        k = FB_Y_LDG + 11 * g;
+        const GearUnitY& G = Y.ldg[g];
+        P(k) = G.strut.dh; P(k + 1) = G.strut.wow ? 1.0 : 0.0; P(k + 2) = G.strut.xi; P(k + 3) = G.strut.xi_dot; P(k + 4) = G.strut.F_dmp_zs;
+        put3(y, n, i, k + 5, G.contact.wr_b.F); put3(y, n, i, k + 8, G.contact.wr_b.tau);
+    }
+    k = FB_Y_PWP;
+    const EngineY& N = Y.pwp.engine;
+    const double nv[9] = {N.MAP, N.f, N.mdot, N.omega, N.tau_shaft, N.P_shaft, N.SFC, N.idle.output, N.frc.output};
+    for (int j = 0; j < 9; j++) P(k + j) = nv[j];
+    k += 9;
+    const PropY& R = Y.pwp.propeller;
+    P(k) = R.J; P(k + 1) = R.Mt; put3(y, n, i, k + 2, R.wr_b.F); put3(y, n, i, k + 5, R.wr_b.tau); put3(y, n, i, k + 8, R.hr_b);
+    P(k + 11) = R.P; P(k + 12) = R.eta_p;
+    P(FB_Y_FUEL) = Y.fuel_m_total;
+    k = FB_Y_DYN;
+    const DynamicsData& D = Y.dyn;
+    P(k) = D.mp_S_b.m; put3(y, n, i, k + 1, D.mp_S_b.r_OG);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) P(k + 4 + 3 * r + c) = D.mp_S_b.J.m[r][c];
+    put3(y, n, i, k + 13, D.wr_S_b.F); put3(y, n, i, k + 16, D.wr_S_b.tau);
+    put3(y, n, i, k + 19, D.wd_eb_b); put3(y, n, i, k + 22, D.vd_eb_b); put3(y, n, i, k + 25, D.a_eb_b);
+    put3(y, n, i, k + 28, D.a_ib_b); put3(y, n, i, k + 31, D.f_c_c); put3(y, n, i, k + 34, D.alpha_ib_b); put3(y, n, i, k + 37, D.g_c_c);
+}
+
+extern "C" {
+
+// Load EGM96 grid and build every table of Cessna172Sv0. Must be called once.
+int32_t fo_init(const char* egm96_path) {
+    FILE* f = std::fopen(egm96_path, "rb");
+    if (!f) return -1;
+    g_geoid.resize((size_t)Geoid::NPHI * Geoid::NLAM);
+    const size_t got = std::fread(g_geoid.data(), sizeof(float), g_geoid.size(), f);
+    std::fclose(f);
+    if (got != g_geoid.size()) return -2;
+    geoid_table().data = g_geoid.data();
+    g_model.reset(new C172Model());
+    try { g_model->build(); } catch (const std::exception& e) { std::fprintf(stderr, "fo_init: %s\n", e.what()); return -3; }
+    return 0;
+}
+int32_t fo_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+// f_ode!(world) for n aircraft. env[7] = T_sl, p_sl, wind N,E,D, h_terrain, surface.
+int32_t fo_c172_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* env,
+                      double* xdot, double* y, int32_t* status) {
+    const Env e = env_from(env);
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NX], xd[NX];
+        for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        C172Y Y;
+        const int32_t st = c172_f_ode(*g_model, e, inputs_from(u, ui, n, i), d, xi, xd, Y);
+        if (xdot) for (int k = 0; k < NX; k++) xdot[k * n + i] = xd[k];
+        if (y) pack_y(Y, y, n, i);
+        if (status) status[i] |= st;
+    }
+    return 0;
+}
+// f_step!(world): acts on the y of an f_ode! at the current x (recomputed here, pure function).
+int32_t fo_c172_f_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, int32_t* status) {
+    const Env e = env_from(env);
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NX], xd[NX];
+        for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        const C172Inputs in = inputs_from(u, ui, n, i);
+        C172Y Y;
+        int32_t st = c172_f_ode(*g_model, e, in, d, xi, xd, Y);
+        st |= c172_f_step(*g_model, in, d, xi, Y);
+        for (int k = 0; k < NX; k++) x[k * n + i] = xi[k];
+        s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
+        if (status) status[i] |= st;
+    }
+    return 0;
+}
+// nsteps x step!(sim). threads <= 0: all OpenMP threads. reference_like != 0: 6 RHS evaluations per
+// step as OrdinaryDiffEq does with a u-modifying callback; 0: skip the redundant 6th.
+// traj (optional): [n x NX x n_saved] states saved every save_every steps (incl. step 0 when save_every>0).
+int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
+                     int64_t nsteps, int32_t* status, int32_t threads, int32_t reference_like, double* traj, int64_t save_every) {
+    const Env e = env_from(env);
+#ifdef _OPENMP
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NX];
+        for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        const C172Inputs in = inputs_from(u, ui, n, i);
+        C172Y Y;
+        int32_t st = 0;
+        int64_t slot = 0;
+        if (traj && save_every > 0) { for (int k = 0; k < NX; k++) traj[(slot * NX + k) * n + i] = xi[k]; slot++; }
+        for (int64_t t = 0; t < nsteps; t++) {
+            st |= c172_step(*g_model, e, in, d, xi, dt, Y, nullptr, reference_like != 0);
+            if (traj && save_every > 0 && ((t + 1) % save_every == 0)) {
+                for (int k = 0; k < NX; k++) traj[(slot * NX + k) * n + i] = xi[k];
+                slot++;
+            }
+        }
+        for (int k = 0; k < NX; k++) x[k * n + i] = xi[k];
+        s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
+        if (status) status[i] |= st;
+    }
+    return 0;
+}
+// f_init!(world, TrimParameters) for n aircraft. tp [n x FB_NTP], ts [n x FB_NTS] in/out.
+int32_t fo_c172_trim(int64_t n, const double* tp, double* ts, const double* env, double* x, double* u, int32_t* ui, int32_t* s,
+                     int32_t* success, double* cost, int32_t threads) {
+    const Env e = env_from(env);
+#ifdef _OPENMP
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        auto TP = [&](int k) { return tp[k * n + i]; };
+        TrimParams p;
+        p.n_e = {TP(FB_TP_N_E), TP(FB_TP_N_E + 1), TP(FB_TP_N_E + 2)};
+        p.h_e = TP(FB_TP_H_E); p.psi_nb = TP(FB_TP_PSI_NB); p.EAS = TP(FB_TP_EAS); p.gamma_wb_n = TP(FB_TP_GAMMA_WB_N);
+        p.psi_wb_dot = TP(FB_TP_PSI_WB_DOT); p.theta_wb_dot = TP(FB_TP_THETA_WB_DOT); p.beta_a = TP(FB_TP_BETA_A);
+        p.fuel_load = TP(FB_TP_FUEL_LOAD); p.mixture = TP(FB_TP_MIXTURE); p.flaps = TP(FB_TP_FLAPS);
+        for (int k = 0; k < 5; k++) p.payload[k] = TP(FB_TP_PAYLOAD + k);
+        TrimState t{ts[0 * n + i], ts[1 * n + i], ts[2 * n + i], ts[3 * n + i], ts[4 * n + i], ts[5 * n + i], ts[6 * n + i]};
+        double c = 0;
+        const bool ok = trim_solve(*g_model, p, e, t, &c);
+        const double tv[7] = {t.alpha_a, t.phi_nb, t.n_eng, t.throttle, t.aileron, t.elevator, t.rudder};
+        for (int k = 0; k < 7; k++) ts[k * n + i] = tv[k];
+        double xi[NX];
+        C172Inputs in; C172Disc d;
+        trim_assign(*g_model, p, t, e, xi, in, d);
+        if (x) for (int k = 0; k < NX; k++) x[k * n + i] = xi[k];
+        if (u && ui) inputs_to(in, u, ui, n, i);
+        if (s) { s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state; }
+        if (success) success[i] = ok;
+        if (cost) cost[i] = c;
+    }
+    return 0;
+}
+double fo_c172_trim_cost(const double* tp18, const double* ts7, const double* env) {
+    TrimParams p;
+    p.n_e = {tp18[0], tp18[1], tp18[2]};
+    p.h_e = tp18[FB_TP_H_E]; p.psi_nb = tp18[FB_TP_PSI_NB]; p.EAS = tp18[FB_TP_EAS]; p.gamma_wb_n = tp18[FB_TP_GAMMA_WB_N];
+    p.psi_wb_dot = tp18[FB_TP_PSI_WB_DOT]; p.theta_wb_dot = tp18[FB_TP_THETA_WB_DOT]; p.beta_a = tp18[FB_TP_BETA_A];
+    p.fuel_load = tp18[FB_TP_FUEL_LOAD]; p.mixture = tp18[FB_TP_MIXTURE]; p.flaps = tp18[FB_TP_FLAPS];
+    for (int k = 0; k < 5; k++) p.payload[k] = tp18[FB_TP_PAYLOAD + k];
+    TrimState t{ts7[0], ts7[1], ts7[2], ts7[3], ts7[4], ts7[5], ts7[6]};
+    return trim_cost(*g_model, p, t, env_from(env));
+}
+
+// ---- table export (to cross-check the product host's own table builders) ----
+int32_t fo_get_prop_table(double* out /*21*21*6*/) {
+    for (int c = 0; c < 6; c++) std::memcpy(out + c * 441, g_model->prop_lookup.data[c].data(), 441 * sizeof(double));
+    return 0;
+}
+// kind: 0 δ_wot(2x9) 1 μ_wot(2x9) 2 π_std(13x3) 3 π_wot(5x3) 4 π_ratio(11) 5 sfc_ratio(11) 6 sfc_pow(5x8)
+int32_t fo_get_piston_table(int32_t kind, double* out) {
+    const PistonLookup& L = g_model->eng_lookup;
+    const std::vector<double>* v = nullptr;
+    switch (kind) {
+        case 0: v = &L.delta_wot.v; break; case 1: v = &L.mu_wot.v; break; case 2: v = &L.pi_std.v; break;
+        case 3: v = &L.pi_wot.v; break; case 4: v = &L.pi_ratio.v; break; case 5: v = &L.sfc_ratio.v; break;
+        case 6: v = &L.sfc_pow.v; break; default: return -1;
+    }
+    std::memcpy(out, v->data(), v->size() * sizeof(double));
+    return (int32_t)v->size();
+}
+
+// ============================ known-answer test helpers ======================================
+// Small entry points that let tests/ restate the reference's own unit tests against this oracle.
+void fo_quat_mul(const double* a, const double* b, double* o) { Quat r = qmul({a[0], a[1], a[2], a[3]}, {b[0], b[1], b[2], b[3]}); o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z; }
+void fo_quat_rotate(const double* q, const double* v, double* o) { V3 r = rotate({q[0], q[1], q[2], q[3]}, {v[0], v[1], v[2]}); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void fo_quat_from_euler(double psi, double theta, double phi, double* o) { Quat r = quat_from_euler({psi, theta, phi}); o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z; }
+void fo_euler_from_quat(const double* q, double* o) { Euler e = euler_from_quat({q[0], q[1], q[2], q[3]}); o[0] = e.psi; o[1] = e.theta; o[2] = e.phi; }
+void fo_rmatrix_from_quat(const double* q, double* o9) { M3 M = rmatrix_from_quat({q[0], q[1], q[2], q[3]}); for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o9[3 * r + c] = M.m[r][c]; }
+void fo_quat_from_rmatrix(const double* m9, double* o) { M3 M; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M.m[r][c] = m9[3 * r + c]; Quat q = quat_from_rmatrix(M); o[0] = q.w; o[1] = q.x; o[2] = q.y; o[3] = q.z; }
+void fo_euler_dot(const double* e, const double* w, double* o) { V3 r = euler_dot({e[0], e[1], e[2]}, {w[0], w[1], w[2]}); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void fo_ltf(const double* n_e, double psi_nw, double* o) { Quat r = ltf({n_e[0], n_e[1], n_e[2]}, psi_nw); o[0] = r.w; o[1] = r.x; o[2] = r.y; o[3] = r.z; }
+void fo_nvector_from_qew(const double* q, double* o) { V3 r = nvector_from_qew({q[0], q[1], q[2], q[3]}); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+double fo_psi_nw_from_qew(const double* q) { return psi_nw_from_qew({q[0], q[1], q[2], q[3]}); }
+void fo_nvector_from_latlon(double phi, double lam, double* o) { V3 r = nvector_from_latlon({phi, lam}); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void fo_latlon_from_nvector(const double* n, double* o) { LatLon l = latlon_from_nvector({n[0], n[1], n[2]}); o[0] = l.phi; o[1] = l.lam; }
+double fo_geoid_height(const double* n) { return geoid_height({n[0], n[1], n[2]}); }
+void fo_cartesian_from_geographic(const double* n, double h, double* o) { V3 r = cartesian_from_geographic({n[0], n[1], n[2]}, h); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void fo_geographic_from_cartesian(const double* r, double* o4) { GeoNE g = geographic_from_cartesian({r[0], r[1], r[2]}); o4[0] = g.n_e.x; o4[1] = g.n_e.y; o4[2] = g.n_e.z; o4[3] = g.h_e; }
+double fo_gravity(const double* n, double h) { return gravity({n[0], n[1], n[2]}, h); }
+void fo_G_n(const double* n, double h, double* o) { V3 r = G_n({n[0], n[1], n[2]}, h); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+double fo_h_geop_from_orth(double h) { return h_geop_from_orth(h); }
+double fo_h_orth_from_geop(double h) { return h_orth_from_geop(h); }
+void fo_isa(double h_geop, double T_sl, double p_sl, double* o2) { int32_t st = 0; ISAData d = isa_data(h_geop, {T_sl, p_sl}, st); o2[0] = d.T; o2[1] = d.p; }
+double fo_h2delta(double h) { return pst::h2delta(h); }
+
+// Kinematics-only simulation (reference test: lib/FlightPhysics/test/test_kinematics.jl:35-95).
+// mech: 0 WA, 1 ECEF, 2 NED. init = q_nb[4], n_e[3], h_e, w_wb_b[3], v_eb_n[3] (14). Inputs u stay constant.
+// out = q_nb[4], v_eb_n[3], h_e, n_e[3], v_eb_b[3], w_eb_b[3] (17)
+int32_t fo_kinematics_sim(int32_t mech, const double* init, double dt, int64_t nsteps, double* out) {
+    KinInit ic;
+    ic.q_nb = {init[0], init[1], init[2], init[3]}; ic.n_e = {init[4], init[5], init[6]}; ic.h_e = init[7];
+    ic.w_wb_b = {init[8], init[9], init[10]}; ic.v_eb_n = {init[11], init[12], init[13]};
+    double x[9], uv[6], k1[9], k2[9], k3[9], k4[9], xt[9];
+    int nx;
+    KinData y;
+    auto f = [&](const double* xx, double* xd) {
+        if (mech == 0) wa_f_ode(xx, uv, xd, y); else if (mech == 1) ecef_f_ode(xx, uv, xd, y); else ned_f_ode(xx, uv, xd, y);
+    };
+    if (mech == 0) { wa_init(ic, x, uv); nx = 9; } else if (mech == 1) { ecef_init(ic, x, uv); nx = 8; } else { ned_init(ic, x, uv); nx = 6; }
+    f(x, k1);
+    for (int64_t t = 0; t < nsteps; t++) {
+        f(x, k1);
+        for (int i = 0; i < nx; i++) xt[i] = x[i] + dt / 2 * k1[i];
+        f(xt, k2);
+        for (int i = 0; i < nx; i++) xt[i] = x[i] + dt / 2 * k2[i];
+        f(xt, k3);
+        for (int i = 0; i < nx; i++) xt[i] = x[i] + dt * k3[i];
+        f(xt, k4);
+        for (int i = 0; i < nx; i++) x[i] = x[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
+        f(x, k1);
+        if (mech == 0) wa_f_step(x); else if (mech == 1) ecef_f_step(x);
+    }
+    f(x, k1);
+    out[0] = y.q_nb.w; out[1] = y.q_nb.x; out[2] = y.q_nb.y; out[3] = y.q_nb.z;
+    out[4] = y.v_eb_n.x; out[5] = y.v_eb_n.y; out[6] = y.v_eb_n.z; out[7] = y.h_e;
+    out[8] = y.n_e.x; out[9] = y.n_e.y; out[10] = y.n_e.z;
+    out[11] = y.v_eb_b.x; out[12] = y.v_eb_b.y; out[13] = y.v_eb_b.z;
+    out[14] = y.w_eb_b.x; out[15] = y.w_eb_b.y; out[16] = y.w_eb_b.z;
+    return 0;
+}
+// KinData(KinInit): out = q_eb[4], r_eb_e[3], q_nb[4], h_o, w_eb_b[3], v_eb_b[3]  (18)
+void fo_kindata_from_init(const double* init, double* out) {
+    KinInit ic;
+    ic.q_nb = {init[0], init[1], init[2], init[3]}; ic.n_e = {init[4], init[5], init[6]}; ic.h_e = init[7];
+    ic.w_wb_b = {init[8], init[9], init[10]}; ic.v_eb_n = {init[11], init[12], init[13]};
+    KinData k = kindata_from_init(ic);
+    out[0] = k.q_eb.w; out[1] = k.q_eb.x; out[2] = k.q_eb.y; out[3] = k.q_eb.z;
+    out[4] = k.r_eb_e.x; out[5] = k.r_eb_e.y; out[6] = k.r_eb_e.z;
+    out[7] = k.q_nb.w; out[8] = k.q_nb.x; out[9] = k.q_nb.y; out[10] = k.q_nb.z; out[11] = k.h_o;
+    out[12] = k.w_eb_b.x; out[13] = k.w_eb_b.y; out[14] = k.w_eb_b.z; out[15] = k.v_eb_b.x; out[16] = k.v_eb_b.y; out[17] = k.v_eb_b.z;
+}
+// VehicleDynamics.f_ode! (reference test: test_dynamics.jl:37-63).
+// mp = m, r_OG[3], J[9 row-major]; wr = F[3], tau[3]; out = wdot[3], vdot[3], a_eb_b[3], a_ib_b[3]
+void fo_dynamics_f_ode(const double* x6, const double* mp13, const double* wr6, const double* ho3, const double* q_eb, const double* r_eb_e, double* out12) {
+    DynamicsU u;
+    u.mp_S_b.m = mp13[0]; u.mp_S_b.r_OG = {mp13[1], mp13[2], mp13[3]};
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) u.mp_S_b.J.m[r][c] = mp13[4 + 3 * r + c];
+    u.wr_S_b = {{wr6[0], wr6[1], wr6[2]}, {wr6[3], wr6[4], wr6[5]}};
+    u.ho_S_b = {ho3[0], ho3[1], ho3[2]};
+    u.q_eb = {q_eb[0], q_eb[1], q_eb[2], q_eb[3]}; u.r_eb_e = {r_eb_e[0], r_eb_e[1], r_eb_e[2]};
+    double xd[6];
+    DynamicsData y;
+    dynamics_f_ode(x6, u, xd, y);
+    for (int i = 0; i < 6; i++) out12[i] = xd[i];
+    out12[6] = y.a_eb_b.x; out12[7] = y.a_eb_b.y; out12[8] = y.a_eb_b.z; out12[9] = y.a_ib_b.x; out12[10] = y.a_ib_b.y; out12[11] = y.a_ib_b.z;
+}
+// translate(FrameTransform(r), MassProperties(RigidBodyDistribution(m, J))) -> mp13
+void fo_mp_translate(const double* r3, double m, const double* J9, double* mp13) {
+    MassProperties c;
+    c.m = m;
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) c.J.m[r][k] = J9[3 * r + k];
+    FrameTransform t;
+    t.r = {r3[0], r3[1], r3[2]};
+    MassProperties b = translate(t, c);
+    mp13[0] = b.m; mp13[1] = b.r_OG.x; mp13[2] = b.r_OG.y; mp13[3] = b.r_OG.z;
+    for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) mp13[4 + 3 * r + k] = b.J.m[r][k];
+}
+// PIVector{2} simulated with RK4 (reference test: test_control.jl:38-66).
+// params per channel: k_p k_i k_l beta_p lo hi ; returns x[2] and the PIOut fields of the last f_ode
+void fo_pi_sim(const double* params12, const double* input2, const int32_t* sat_ext2, double* x2, double dt, int64_t nsteps, double* out /*2 x (output, y_i, sat_out, int_halted)*/) {
+    PIParams p[2];
+    for (int c = 0; c < 2; c++) p[c] = {params12[6 * c], params12[6 * c + 1], params12[6 * c + 2], params12[6 * c + 3], params12[6 * c + 4], params12[6 * c + 5]};
+    PIOut y[2];
+    for (int c = 0; c < 2; c++) {
+        double x = x2[c];
+        auto f = [&](double xx) { return pi_f_ode(p[c], input2[c], sat_ext2[c], xx, y[c]); };
+        for (int64_t t = 0; t < nsteps; t++) {
+            const double k1 = f(x), k2 = f(x + dt / 2 * k1), k3 = f(x + dt / 2 * k2), k4 = f(x + dt * k3);
+            x = x + (dt / 6) * (2 * (k2 + k3) + (k1 + k4));
+        }
+        f(x);
+        x2[c] = x;
+        out[4 * c] = y[c].output; out[4 * c + 1] = y[c].y_i; out[4 * c + 2] = y[c].sat_out; out[4 * c + 3] = y[c].int_halted;
+    }
+}
+// Propellers.Coefficients(n_blades, Blade(), J, Mt, Δβ)
+void fo_prop_coefficients(int32_t n_blades, double J, double Mt, double dbeta, double* out6) {
+    PropCoeffs c = prop_coefficients(n_blades, Blade{}, J, Mt, dbeta);
+    out6[0] = c.C_Fx; out6[1] = c.C_Mx; out6[2] = c.C_Fz_a; out6[3] = c.C_Mz_a; out6[4] = c.C_P; out6[5] = c.eta_p;
+}
+void fo_prop_lookup_eval(double J, double Mt, double* out6) {
+    PropCoeffs c = g_model->prop_lookup.eval(J, Mt);
+    out6[0] = c.C_Fx; out6[1] = c.C_Mx; out6[2] = c.C_Fz_a; out6[3] = c.C_Mz_a; out6[4] = c.C_P; out6[5] = c.eta_p;
+}
+// Propeller.f_ode! with KinData(KinInit(v_eb_n)) and standard AtmosphericData (test_propellers.jl:127-145)
+void fo_propeller_f_ode(int32_t sense, const double* t_bp_r, const double* v_eb_n, double omega, double* out /*wr_p F[3] tau[3]*/) {
+    KinInit ic;
+    ic.v_eb_n = {v_eb_n[0], v_eb_n[1], v_eb_n[2]};
+    KinData kin = kindata_from_init(ic);
+    AtmData atm{isa::T_std, isa::p_std, isa::rho_std, std::sqrt(isa::gamma * isa::R * isa::T_std), 0.0, V3{}};
+    AirData air = air_data(atm, kin);
+    PropParams p;
+    p.sense = sense; p.t_bp.r = {t_bp_r[0], t_bp_r[1], t_bp_r[2]};
+    PropY y;
+    propeller_f_ode(p, g_model->prop_lookup, kin, air, omega, y);
+    out[0] = y.wr_p.F.x; out[1] = y.wr_p.F.y; out[2] = y.wr_p.F.z; out[3] = y.wr_p.tau.x; out[4] = y.wr_p.tau.y; out[5] = y.wr_p.tau.z;
+}
+// Piston lookups for arbitrary (n_stall, n_max) (test_piston.jl:57-127). which: 0 δ_wot(n,μ) 1 π_std(n,μ)
+// 2 π_wot(n,δ) 3 π_ISA_pow(n,μ,δ) 4 μ_wot(n,δ)
+double fo_piston_lookup(double n_stall, double n_max, int32_t which, double a, double b, double c) {
+    static double cs = -1, cm = -1;
+    static PistonLookup L;
+    if (cs != n_stall || cm != n_max) { L.build(n_stall, n_max); cs = n_stall; cm = n_max; }
+    switch (which) {
+        case 0: return L.delta_wot(a, b); case 1: return L.pi_std(a, b); case 2: return L.pi_wot(a, b);
+        case 3: return compute_pi_ISA_pow(L, a, b, c); case 4: return L.mu_wot(a, b);
+    }
+    return NAN;
+}
+// Thruster test harness (test_piston.jl:20-45, 211-260): default PistonEngine + default Propeller (CW, d=2, J_xx=0.3,
+// t_bp = identity), KinData()/AirData() defaults. Advances nsteps RK4 steps of dt; in/out: x_eng[3], state.
+// ctl bits: 1 start, 2 stop. out: omega, Fx_b, tau_x_b
+void fo_thruster_sim(double* x_eng, int32_t* state, int32_t ctl, double throttle, int32_t fuel_available, double dt, int64_t nsteps, double* out3) {
+    static PistonLookup L;
+    static bool built = false;
+    EngineParams ep;
+    if (!built) { L.build(ep.w_stall / ep.w_rated, ep.w_max / ep.w_rated); built = true; }
+    PropParams pp;
+    KinData kin = kindata_from_init(KinInit{});
+    AtmData atm{isa::T_std, isa::p_std, isa::rho_std, std::sqrt(isa::gamma * isa::R * isa::T_std), 0.0, V3{}};
+    AirData air = air_data(atm, kin);
+    EngineU eu;
+    eu.start = ctl & 1; eu.stop = ctl & 2; eu.throttle = throttle;
+    ThrusterY y;
+    auto f = [&](const double* xx, double* xd) { thruster_f_ode(ep, L, pp, g_model->prop_lookup, 1.0, eu, *state, xx, air, kin, xd, y); };
+    double k1[3], k2[3], k3[3], k4[3], xt[3];
+    for (int64_t t = 0; t < nsteps; t++) {
+        f(x_eng, k1);
+        for (int i = 0; i < 3; i++) xt[i] = x_eng[i] + dt / 2 * k1[i];
+        f(xt, k2);
+        for (int i = 0; i < 3; i++) xt[i] = x_eng[i] + dt / 2 * k2[i];
+        f(xt, k3);
+        for (int i = 0; i < 3; i++) xt[i] = x_eng[i] + dt * k3[i];
+        f(xt, k4);
+        for (int i = 0; i < 3; i++) x_eng[i] = x_eng[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
+        f(x_eng, k1);
+        *state = engine_f_step(ep, eu, *state, x_eng[0], fuel_available != 0);
+    }
+    f(x_eng, k1);
+    out3[0] = y.engine.omega; out3[1] = y.propeller.wr_b.F.x; out3[2] = y.propeller.wr_b.tau.x;
+}
+double fo_engine_tau_shaft(double omega, int32_t state, double throttle) {
+    static PistonLookup L;
+    static bool built = false;
+    EngineParams ep;
+    if (!built) { L.build(ep.w_stall / ep.w_rated, ep.w_max / ep.w_rated); built = true; }
+    KinInit ic;
+    ic.v_eb_n = {50, 0, 0};
+    KinData kin = kindata_from_init(ic);
+    AtmData atm{isa::T_std, isa::p_std, isa::rho_std, std::sqrt(isa::gamma * isa::R * isa::T_std), 0.0, V3{}};
+    AirData air = air_data(atm, kin);
+    EngineU eu;
+    eu.throttle = throttle; eu.tau_load = -10; eu.J_load = 0.1;
+    double x[3] = {omega, 0, 0}, xd[3];
+    EngineY y;
+    engine_f_ode(ep, L, eu, state, x, air, xd, y);
+    return y.tau_shaft;
+}
+int32_t fo_engine_f_step(int32_t state, double omega, int32_t ctl, int32_t fuel_available) {
+    EngineParams ep;
+    EngineU eu;
+    eu.start = ctl & 1; eu.stop = ctl & 2;
+    return engine_f_step(ep, eu, state, omega, fuel_available != 0);
+}
+double fo_get_mu(int32_t skidding, int32_t surface, double v) { return get_mu(skidding ? friction_skidding(surface) : friction_rolling(surface), v); }
+// LandingGearUnit test (test_landing_gear.jl:93-214): DirectSteering(ψ_max = π/6), DirectBraking, Strut(l_0 = 1,
+// SimpleDamper(25000, 1000, 1000)), HorizontalTerrain() at NVector(). Aircraft at orthometric height h_o above terrain 0.
+// kin = q_nb[4], w_wb_b[3], v_eb_n[3] ; x_frc[2] ; out = wow, xi, xi_dot, F_dmp_zs, v_ec_xy[2], mu_max[2], mu_eff[2],
+// f_c[3], wr_b.F[3], xdot_frc[2], sat_out[2], mu_roll, dh   (23)
+void fo_ldg_unit_f_ode(double h_orth, const double* kin10, double steering_input, double brake_input, const double* x_frc, double* out) {
+    GearUnitParams gp;
+    gp.steering = DIRECT_STEERING; gp.psi_max = PI / 6; gp.braking = DIRECT_BRAKING;
+    gp.strut.l_0 = 1.0; gp.strut.damper = Damper{25000, 1000, 1000, 50000};
+    GearUnitU gu;
+    gu.steering_input = steering_input; gu.brake_input = brake_input;
+    KinInit ic;
+    ic.q_nb = {kin10[0], kin10[1], kin10[2], kin10[3]}; ic.w_wb_b = {kin10[4], kin10[5], kin10[6]}; ic.v_eb_n = {kin10[7], kin10[8], kin10[9]};
+    ic.h_e = h_ellip_from_orth(h_orth, ic.n_e);
+    KinData kin = kindata_from_init(ic);
+    Env env;
+    GearUnitY y;
+    double xd[2];
+    gear_unit_f_ode(gp, gu, env, kin, x_frc, xd, y);
+    const double o[23] = {y.strut.wow ? 1.0 : 0.0, y.strut.xi, y.strut.xi_dot, y.strut.F_dmp_zs, y.strut.v_ec_xy[0], y.strut.v_ec_xy[1],
+                          y.contact.mu_max[0], y.contact.mu_max[1], y.contact.mu_eff[0], y.contact.mu_eff[1],
+                          y.contact.f_c.x, y.contact.f_c.y, y.contact.f_c.z, y.contact.wr_b.F.x, y.contact.wr_b.F.y, y.contact.wr_b.F.z,
+                          xd[0], xd[1], (double)y.contact.frc[0].sat_out, (double)y.contact.frc[1].sat_out, y.contact.mu_roll, y.strut.dh, 0};
+    for (int i = 0; i < 23; i++) out[i] = o[i];
+}
+
+}  // extern "C"
