@@ -1,0 +1,724 @@
+// c172_device.hpp — device-side physics of one Cessna172Sv0 in SimpleWorld, one aircraft per lane.
+//
+// Written for gfx950 (MI355X): fp64 VALU work, one thread = one aircraft, all per-aircraft state in
+// registers, the small lookup tables (aero / piston / propeller, 25 KB) staged in LDS per workgroup,
+// the EGM96 geoid (4.2 MB float32) gathered from global memory (L2 / Infinity-Cache resident).
+//
+// What it computes is the reference's f_ode!(world) / f_step!(world); how it computes it is laid out
+// for the GPU (file:line = reference, relative to lib/):
+//   * identity frame rotations of the C172 (every t_b* is a pure translation, FlightApps/src/c172/
+//     c172.jl:32,455-471,514-518,628-629; c172s.jl:30) are elided — exact, x∘1 = x in floating point;
+//   * half-angle sin/cos pairs are produced by one sincos();
+//   * the local-level frame at the centre of mass is not built through lat/lon and three quaternion
+//     products (FlightPhysics/src/dynamics.jl:476-488): gravity points along -n_e(Oc) in ECEF, so
+//     g_c = q_eb'(-g n_e); same vector, two atan2 + two sincos + three products cheaper;
+//   * ECEF->geodetic (Fukushima) is evaluated once per point, not once per consumer
+//     (dynamics.jl:476,487 call it twice on the same Oc);
+//   * total mass properties are accumulated as Σm, Σm r, ΣJ with one division instead of the
+//     reference's chain of pairwise `+` (dynamics.jl:262-272), which divides at every addition.
+// These change results at rounding level only (tests hold GPU vs CPU oracle to 1e-9 relative on ẋ).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tables.h"
+#include "../../include/flightbatch.h"
+
+namespace fbd {
+
+#define FBD __device__ __forceinline__
+#ifndef FB_GROUND_ATTR
+#define FB_GROUND_ATTR __noinline__
+#endif
+
+constexpr double PI = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------------------------
+// small vector / quaternion algebra (FlightPhysics/src/quaternions.jl:109-115; attitude.jl:93-118)
+struct v3 { double x, y, z; };
+FBD v3 operator+(v3 a, v3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+FBD v3 operator-(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+FBD v3 operator-(v3 a) { return {-a.x, -a.y, -a.z}; }
+FBD v3 operator*(double s, v3 a) { return {s * a.x, s * a.y, s * a.z}; }
+FBD double dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+FBD v3 cross(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+FBD double norm(v3 a) { return sqrt(dot(a, a)); }
+
+struct quat { double w, x, y, z; };
+FBD quat qmul(quat a, quat b) {
+    return {a.w * b.w - (a.x * b.x + a.y * b.y + a.z * b.z),
+            a.w * b.x + b.w * a.x + (a.y * b.z - a.z * b.y),
+            a.w * b.y + b.w * a.y + (a.z * b.x - a.x * b.z),
+            a.w * b.z + b.w * a.z + (a.x * b.y - a.y * b.x)};
+}
+FBD quat qconj(quat q) { return {q.w, -q.x, -q.y, -q.z}; }
+// v' = v + 2 q_im x (q_re v + q_im x v)   (attitude.jl:98-103)
+FBD v3 qrot(quat q, v3 v) {
+    const v3 qi = {q.x, q.y, q.z};
+    const v3 t = q.w * v + cross(qi, v);
+    return v + cross(2.0 * qi, t);
+}
+FBD v3 qrot_inv(quat q, v3 v) { return qrot(qconj(q), v); }
+
+// ---------------------------------------------------------------------------------------------
+// WGS-84 (FlightPhysics/src/geodesy.jl:15-35)
+namespace wgs {
+constexpr double GM = 3.986005e+14;
+constexpr double a = 6378137.0;
+constexpr double f = 1 / 298.257223563;
+constexpr double w_ie = 7.292115e-05;
+constexpr double b = a * (1 - f);
+constexpr double e2 = 2 * f - f * f;
+constexpr double a2 = a * a;
+constexpr double m = w_ie * w_ie * a * a * b / GM;
+constexpr double g_a = 9.7803253359;
+constexpr double g_b = 9.8321849378;
+constexpr double k_g = b * g_b / (a * g_a) - 1;
+}  // namespace wgs
+constexpr double H_MIN = -1000.0;
+
+struct Tables {
+    const double* lds;   // [aero | piston | propeller] blob in LDS
+    const float* egm96;  // 721 x 1441 float32, column-major [lat, lon], global memory
+};
+
+// EGM96 geoid height at a location given by its n-vector (geodesy.jl:103-106, 186-211).
+// Bilinear on the uniform grid lat ∈ [-π/2, π/2] (721), lon ∈ [0, 2π] (1441), linear extrapolation.
+FBD double geoid_height(const Tables& T, v3 n, double& lat, double& lon) {
+    lat = atan2(n.z, sqrt(n.x * n.x + n.y * n.y));
+    lon = atan2(n.y, n.x);
+    double lam = fmod(lon + 2 * PI, 2 * PI);
+    lam = lam < 0 ? lam + 2 * PI : lam;
+    const double xi = (lat + PI / 2) / (PI / 720);
+    const double xj = lam / (2 * PI / 1440);
+    const int i = min(max((int)floor(xi), 0), 719);
+    const int j = min(max((int)floor(xj), 0), 1439);
+    const double wi = xi - i, wj = xj - j;
+    const float* p = T.egm96 + i + 721 * j;
+    const double a00 = p[0], a10 = p[1], a01 = p[721], a11 = p[722];
+    return (1 - wi) * ((1 - wj) * a00 + wj * a01) + wi * ((1 - wj) * a10 + wj * a11);
+}
+FBD double geoid_height(const Tables& T, v3 n) {
+    double la, lo;
+    return geoid_height(T, n, la, lo);
+}
+
+// ECEF -> (n-vector, ellipsoidal altitude): Fukushima, one Halley step (geodesy.jl:367-412)
+FBD void geodetic_from_ecef(v3 r, v3& n, double& h) {
+    using namespace wgs;
+    const double p2 = r.x * r.x + r.y * r.y;
+    const double p = sqrt(p2);
+    const double az = fabs(r.z);
+    constexpr double c = a * e2;
+    constexpr double ec2 = 1 - e2;
+    const double ec = sqrt(ec2);
+    const double zc = ec * az;
+    const double s0 = az;
+    const double c0 = ec * p;
+    const double a0 = sqrt(s0 * s0 + c0 * c0);
+    const double a03 = a0 * a0 * a0;
+    const double b0 = 1.5 * c * s0 * c0 * ((p * s0 - zc * c0) * a0 - c * s0 * c0);
+    const double s1 = (zc * a03 + c * (s0 * s0 * s0)) * a03 - b0 * s0;
+    const double c1 = (p * a03 - c * (c0 * c0 * c0)) * a03 - b0 * c0;
+    const double cc = ec * c1;
+    const double s12 = s1 * s1, cc2 = cc * cc;
+    h = (p * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / sqrt(s12 + cc2);
+    const double sgn = (r.z > 0) ? 1.0 : ((r.z < 0) ? -1.0 : 0.0);
+    double cos_phi, sin_phi;
+    if (s1 < cc) {
+        const double t = s1 / cc;
+        cos_phi = 1 / sqrt(1 + t * t);
+        sin_phi = t * cos_phi * sgn;
+    } else {
+        const double t = cc / s1;
+        const double as = 1 / sqrt(1 + t * t);
+        cos_phi = t * as;
+        sin_phi = as * sgn;
+    }
+    const double cl = p > 0 ? r.x / p : 1.0;
+    const double sl = p > 0 ? r.y / p : 0.0;
+    v3 u = {cos_phi * cl, cos_phi * sl, sin_phi};
+    const double inv = 1 / norm(u);  // NVector constructor normalises (geodesy.jl:47-51)
+    n = inv * u;
+}
+// Somigliana gravity with altitude correction (geodesy.jl:451-467)
+FBD double normal_gravity(double nz, double h) {
+    using namespace wgs;
+    const double s2 = nz * nz;
+    const double g0 = g_a * (1 + k_g * s2) / sqrt(1 - e2 * s2);
+    return g0 * (1 - 2 / a * (1 + f + m - 2 * f * s2) * h + 3 / a2 * (h * h));
+}
+
+// ---------------------------------------------------------------------------------------------
+// table lookups (Interpolations.jl semantics: Gridded(Linear) knot search = searchsortedlast clamped)
+struct loc { int i; double w; };
+template <int N>
+FBD loc grid_locate(const double* k, double x, bool flat_lo, bool flat_hi) {
+    x = (flat_lo && x < k[0]) ? k[0] : x;
+    x = (flat_hi && x > k[N - 1]) ? k[N - 1] : x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j <= N - 2; j++) i += (k[j] <= x) ? 1 : 0;  // knots ascending: count = index of last knot <= x
+    const double k0 = k[i], k1 = k[i + 1];
+    return {i, (x - k0) / (k1 - k0)};
+}
+FBD loc range_locate(double a, double b, int n, double x, bool flat) {
+    if (flat) x = fmin(fmax(x, a), b);
+    const double xi = (x - a) / ((b - a) / (n - 1));
+    const int i = min(max((int)floor(xi), 0), n - 2);
+    return {i, xi - i};
+}
+FBD double lerp1(const double* v, loc l) { return (1 - l.w) * v[l.i] + l.w * v[l.i + 1]; }
+FBD double lerp2(const double* v, int n1, loc l1, loc l2) {
+    const double* p = v + l1.i + n1 * l2.i;
+    return (1 - l1.w) * ((1 - l2.w) * p[0] + l2.w * p[n1]) + l1.w * ((1 - l2.w) * p[1] + l2.w * p[n1 + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Atmosphere (FlightPhysics/src/atmosphere.jl:22-34, 99-135)
+namespace isa {
+constexpr double R = 287.05287, gamma = 1.40, beta_s = 1.458e-6, S = 110.4;
+constexpr double T_std = 288.15, p_std = 101325.0, rho_std = p_std / (R * T_std), g_std = 9.80665;
+}  // namespace isa
+FBD void isa_data(double h, double T_sl, double p_sl, double& T, double& p, int32_t& st) {
+    constexpr double beta[7] = {-6.5e-3, 0, 1e-3, 2.8e-3, 0, -2.8e-3, -2e-3};
+    constexpr double hc[7] = {11000, 20000, 32000, 47000, 51000, 71000, 84852};
+    double hb = 0, Tb = T_sl, pb = p_sl;
+    bool done = false;
+    T = Tb; p = pb;
+#pragma unroll 1
+    for (int i = 0; i < 7 && !done; i++) {
+        const double hh = (h < hc[i]) ? h : hc[i];
+        done = h < hc[i];
+        const double Tn = Tb + beta[i] * (hh - hb);
+        double pn;
+        if (beta[i] != 0.0) pn = pb * pow(1 + beta[i] / Tb * (hh - hb), -isa::g_std / (beta[i] * isa::R));
+        else pn = pb * exp(-isa::g_std / (isa::R * Tb) * (hh - hb));
+        T = Tn; p = pn;
+        hb = hc[i]; Tb = Tn; pb = pn;
+    }
+    if (!done) st |= FB_ST_ISA_RANGE;
+}
+
+// ---------------------------------------------------------------------------------------------
+// continuous PI compensator with anti-windup (FlightPhysics/src/control.jl:52-81), one channel
+FBD double pi_ode(double k_p, double k_i, double k_l, double lo, double hi, double input, double x_i, double& output) {
+    const double out_free = k_p * input + x_i;
+    output = fmin(fmax(out_free, lo), hi);
+    const int sat = (out_free >= hi ? 1 : 0) - (out_free <= lo ? 1 : 0);
+    const bool halted = (input * sat) > 0;  // sat_ext is never driven on this path (stays 0)
+    return (halted ? 0.0 : k_i * input) - k_l * x_i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Model constants of Cessna172Sv0
+namespace c172 {
+constexpr double D2R = PI / 180;
+// aero (FlightApps/src/c172/c172.jl:247-258)
+constexpr double S = 16.165, b = 10.912, c = 1.494, V_min = 1.0, tau_filt = 0.02;
+constexpr double de_lo = -28 * D2R, de_hi = 23 * D2R, da_lo = -20 * D2R, da_hi = 20 * D2R;
+constexpr double dr_lo = -16 * D2R, dr_hi = 16 * D2R, df_lo = 0.0, df_hi = 30 * D2R;
+constexpr double alpha_stall_lo = 0.09, alpha_stall_hi = 0.36;
+// landing gear (c172.jl:442-476): strut attachment points, dampers (k_s, k_d_ext, k_d_cmp)
+constexpr double ldg_r[3][3] = {{-0.381, -1.092, 1.902}, {-0.381, 1.092, 1.902}, {1.27, 0.0, 1.9}};
+constexpr double ldg_ks[3] = {39404, 39404, 26269};
+constexpr double ldg_kd[3] = {9340, 9340, 3503};
+constexpr double psi_max = PI / 6;  // DirectSteering default (FlightPhysics/src/landinggear.jl:47-49)
+// contact friction regulator (landinggear.jl:401-409)
+constexpr double frc_kp = 5.0, frc_ki = 400.0, frc_kl = 0.2;
+// power plant (FlightApps/src/c172/c172s/c172s.jl:16-34; FlightPhysics/src/piston.jl:25-35)
+constexpr double P_rated = 735.49875 * 200, w_rated = 2700 * PI / 30, w_stall = 300 * PI / 30, w_idle = 600 * PI / 30;
+constexpr double tau_start = 40, J_eng = 0.05;
+constexpr double f_lean = 0.0625, f_rich = 0.0950;
+constexpr double prop_d = 2.0, prop_Jxx = 0.3, prop_r[3] = {2.055, 0.0, 0.833};
+// airframe mass (c172.jl:26-35): RigidBodyDistribution(767, diag(820,1164,1702)) at r = (0.056, 0, 0.582)
+constexpr double afm_m = 767.0, afm_J[3] = {820.0, 1164.0, 1702.0}, afm_r[3] = {0.056, 0.0, 0.582};
+// payload slots (c172.jl:513-519) and fuel tanks (c172.jl:628-629)
+constexpr double pld_r[5][3] = {{0.183, -0.356, 0.899}, {0.183, 0.356, 0.899}, {-0.681, -0.356, 0.899}, {-0.681, 0.356, 0.899}, {-1.316, 0.0, 0.899}};
+constexpr double fuel_r[2][3] = {{0.325, -2.845, 0.0}, {0.325, 2.845, 0.0}};
+constexpr double m_full = 114.4, m_res = 1.0;
+}  // namespace c172
+
+struct Env {  // fb_params subset, wave-uniform (SGPRs)
+    double T_sl, p_sl, wind_n, wind_e, wind_d, h_trn;
+    int surface;
+};
+struct Inputs {  // per aircraft, constant during a launch
+    double u[FB_NU];
+    int ui;
+};
+// quantities f_step! reads from the y of the last f_ode! (aircraftbase.jl:172-181; c172.jl:715-724)
+struct StepAux {
+    double alpha;       // aero.y.α (c172.jl:375-384)
+    double m_avail;     // fuel.y.m_avail (c172.jl:641)
+    int wow;            // bit g: strut g weight-on-wheel (landinggear.jl:479-483)
+    int crash;          // any strut: α_ts > 60° or -ξ_dot > 10 (landinggear.jl:331-347)
+};
+
+// accumulate point mass into (m, m r, J)  (dynamics.jl:211-214)
+FBD void add_point(double m, const double* r, double& M, v3& Mr, double (&J)[6]) {
+    M += m;
+    Mr = Mr + m * v3{r[0], r[1], r[2]};
+    J[0] += m * (r[1] * r[1] + r[2] * r[2]);
+    J[1] += m * (r[0] * r[0] + r[2] * r[2]);
+    J[2] += m * (r[0] * r[0] + r[1] * r[1]);
+    J[3] -= m * (r[0] * r[1]);  // xy
+    J[4] -= m * (r[0] * r[2]);  // xz
+    J[5] -= m * (r[1] * r[2]);  // yz
+}
+
+// Ground-contact branch of one landing-gear unit (landinggear.jl:260-328, 426-476). Rare and divergent:
+// kept out of line so that the airborne path does not pay its registers.
+struct GroundIn {
+    quat q_eb, q_nb, q_en;
+    v3 r_eb_e, r_bs_e, ks_e, w_eb_b, v_eb_b, loc_Ot;
+    double he_Ot, frc_out0, frc_out1, steer_in, brake_in;
+    int g, steer_engaged, surface;
+};
+struct GroundOut {
+    v3 F_b, tau_b;
+    double v_xy0, v_xy1, xi, xi_dot, F_dmp, alpha_ts;
+    quat q_sc;   // strut -> contact frame rotation, kept between the two phases
+    v3 r_bc_b;   // contact point in body frame
+    int st;
+};
+__device__ FB_GROUND_ATTR void gear_ground_kinematics(const GroundIn& in, GroundOut& o);
+__device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& o);
+
+// ---------------------------------------------------------------------------------------------
+// One RHS evaluation. x[27] -> xd[27]; fills aux (for f_step!) and, if Y != nullptr, the output record.
+// Call order of the reference: world.jl:26-32 -> aircraftbase.jl:221-230,142-170 -> c172.jl:697-713.
+template <bool WITH_Y>
+FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs& in, const Env& env, const Tables& T,
+                double (&xd)[FB_NX], StepAux& aux, double* Y, int64_t n) {
+    using namespace c172;
+    int32_t st = 0;
+    auto YP = [&](int k, double v) { if (WITH_Y) Y[(int64_t)k * n] = v; };
+    auto YP3 = [&](int k, v3 v) { if (WITH_Y) { Y[(int64_t)k * n] = v.x; Y[(int64_t)(k + 1) * n] = v.y; Y[(int64_t)(k + 2) * n] = v.z; } };
+    auto YP4 = [&](int k, quat q) { if (WITH_Y) { Y[(int64_t)k * n] = q.w; Y[(int64_t)(k + 1) * n] = q.x; Y[(int64_t)(k + 2) * n] = q.y; Y[(int64_t)(k + 3) * n] = q.z; } };
+
+    // ===== kinematics: wander-azimuth mechanisation (FlightPhysics/src/kinematics.jl:181-223) =====
+    const quat q_wb = {x[FB_X_Q_WB], x[FB_X_Q_WB + 1], x[FB_X_Q_WB + 2], x[FB_X_Q_WB + 3]};
+    const quat q_ew = {x[FB_X_Q_EW], x[FB_X_Q_EW + 1], x[FB_X_Q_EW + 2], x[FB_X_Q_EW + 3]};
+    const double h_e = x[FB_X_H_E];
+    const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
+    const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
+    if (!(h_e >= H_MIN)) st |= FB_ST_ALT_RANGE;
+
+    // ψ_nw and n_e straight from q_ew (geodesy.jl:62-69, 140-147)
+    const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
+    const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
+    const double psi_nw = atan2(-(dq34 + dq12), dq24 - dq13);
+    const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+    double s_nw, c_nw;
+    sincos(0.5 * psi_nw, &s_nw, &c_nw);
+    const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
+    const quat q_nb = qmul(q_nw, q_wb);
+    const quat q_eb = qmul(q_ew, q_wb);
+
+    double lat, lon;
+    const double N_geoid = geoid_height(T, n_e, lat, lon);
+    const double h_o = h_e - N_geoid;
+    if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
+
+    const v3 v_eb_n = qrot(q_nb, v_eb_b);
+    // radii of curvature and ECEF position (geodesy.jl:125-129, 418-428)
+    const double f_den = sqrt(1 - wgs::e2 * n_e.z * n_e.z);
+    const double R_E = wgs::a / f_den;
+    const double R_N = wgs::a * (1 - wgs::e2) / (f_den * f_den * f_den);
+    const v3 r_eb_e = {(R_E + h_e) * n_e.x, (R_E + h_e) * n_e.y, (R_E * (1 - wgs::e2) + h_e) * n_e.z};
+    // transport rate (kinematics.jl:232-242)
+    const v3 w_ew_n = {v_eb_n.y / (R_E + h_e), -v_eb_n.x / (R_N + h_e), 0.0};
+    const v3 w_ew_w = qrot_inv(q_nw, w_ew_n);
+    const v3 w_ew_b = qrot_inv(q_wb, w_ew_w);
+    const v3 w_wb_b = w_eb_b - w_ew_b;
+
+    {
+        const quat a = qmul(q_wb, quat{0.0, w_wb_b.x, w_wb_b.y, w_wb_b.z});
+        const quat b2 = qmul(q_ew, quat{0.0, w_ew_w.x, w_ew_w.y, w_ew_w.z});
+        xd[FB_X_Q_WB] = 0.5 * a.w; xd[FB_X_Q_WB + 1] = 0.5 * a.x; xd[FB_X_Q_WB + 2] = 0.5 * a.y; xd[FB_X_Q_WB + 3] = 0.5 * a.z;
+        xd[FB_X_Q_EW] = 0.5 * b2.w; xd[FB_X_Q_EW + 1] = 0.5 * b2.x; xd[FB_X_Q_EW + 2] = 0.5 * b2.y; xd[FB_X_Q_EW + 3] = 0.5 * b2.z;
+        xd[FB_X_H_E] = -v_eb_n.z;
+    }
+    quat q_en = {1, 0, 0, 0};
+    if (WITH_Y) {
+        q_en = qmul(q_eb, qconj(q_nb));
+        // Euler angles (attitude.jl:382-391)
+        const double q1 = q_nb.w, q2 = q_nb.x, q3 = q_nb.y, q4 = q_nb.z;
+        YP(FB_Y_KIN + 0, atan2(2 * (q1 * q4 + q2 * q3), 1 - 2 * (q3 * q3 + q4 * q4)));
+        YP(FB_Y_KIN + 1, asin(fmin(fmax(2 * (q1 * q3 - q2 * q4), -1.0), 1.0)));
+        YP(FB_Y_KIN + 2, atan2(2 * (q1 * q2 + q3 * q4), 1 - 2 * (q2 * q2 + q3 * q3)));
+        YP4(FB_Y_KIN + 3, q_nb); YP4(FB_Y_KIN + 7, q_eb); YP4(FB_Y_KIN + 11, q_en);
+        YP(FB_Y_KIN + 15, lat); YP(FB_Y_KIN + 16, lon); YP3(FB_Y_KIN + 17, n_e);
+        YP(FB_Y_KIN + 20, h_e); YP(FB_Y_KIN + 21, h_o); YP3(FB_Y_KIN + 22, r_eb_e);
+        YP3(FB_Y_KIN + 25, w_wb_b); YP3(FB_Y_KIN + 28, w_eb_b); YP3(FB_Y_KIN + 31, v_eb_b); YP3(FB_Y_KIN + 34, v_eb_n);
+        const double v_gnd = norm(v_eb_n);
+        YP(FB_Y_KIN + 37, v_gnd);
+        YP(FB_Y_KIN + 38, v_gnd > 0.1 ? atan2(v_eb_n.y, v_eb_n.x) : 0.0);
+        YP(FB_Y_KIN + 39, v_gnd > 0.1 ? atan2(-v_eb_n.z, sqrt(v_eb_n.x * v_eb_n.x + v_eb_n.y * v_eb_n.y)) : 0.0);
+    }
+
+    // ===== air data (atmosphere.jl:269-283, 220-242) =====
+    double T_air, p_air;
+    isa_data(h_o * wgs::a / (wgs::a + h_o), env.T_sl, env.p_sl, T_air, p_air, st);
+    const double rho = p_air / (isa::R * T_air);
+    const double a_snd = sqrt(isa::gamma * isa::R * T_air);
+    const v3 v_ew_n = {env.wind_n, env.wind_e, env.wind_d};
+    const v3 v_ew_b = qrot_inv(q_nb, v_ew_n);
+    const v3 v_wb_b = v_eb_b - v_ew_b;
+    const double TAS = norm(v_wb_b);
+    const double q_dyn = 0.5 * rho * (TAS * TAS);
+    if (WITH_Y) {
+        YP3(FB_Y_AIR, v_ew_n); YP3(FB_Y_AIR + 3, v_ew_b); YP3(FB_Y_AIR + 6, v_wb_b);
+        const double M = TAS / a_snd;
+        const double Tt = T_air * (1 + (isa::gamma - 1) / 2 * (M * M));
+        const double pt = p_air * pow(Tt / T_air, isa::gamma / (isa::gamma - 1));
+        const double dp = pt - p_air;
+        YP(FB_Y_AIR + 9, T_air); YP(FB_Y_AIR + 10, p_air); YP(FB_Y_AIR + 11, rho); YP(FB_Y_AIR + 12, a_snd);
+        YP(FB_Y_AIR + 13, (isa::beta_s * pow(T_air, 1.5)) / (T_air + isa::S));
+        YP(FB_Y_AIR + 14, M); YP(FB_Y_AIR + 15, Tt); YP(FB_Y_AIR + 16, pt); YP(FB_Y_AIR + 17, dp); YP(FB_Y_AIR + 18, q_dyn);
+        YP(FB_Y_AIR + 19, TAS); YP(FB_Y_AIR + 20, TAS * sqrt(rho / isa::rho_std));
+        YP(FB_Y_AIR + 21, sqrt(2 * isa::gamma / (isa::gamma - 1) * isa::p_std / isa::rho_std *
+                               (pow(1 + dp / isa::p_std, (isa::gamma - 1) / isa::gamma) - 1)));
+    }
+
+    // ===== actuation: mechanical pass-through with sign conventions (c172s.jl:92-120) =====
+    auto clampd = [](double v, double lo, double hi) { return fmin(fmax(v, lo), hi); };
+    const double* u = in.u;
+    const double ail = clampd(u[FB_U_AILERON], -1, 1) + clampd(u[FB_U_AILERON_OFFSET], -1, 1);
+    const double elv = clampd(u[FB_U_ELEVATOR], -1, 1) + clampd(u[FB_U_ELEVATOR_OFFSET], -1, 1);
+    const double rud = clampd(u[FB_U_RUDDER], -1, 1) + clampd(u[FB_U_RUDDER_OFFSET], -1, 1);
+    const double aero_e = clampd(-elv, -1, 1), aero_a = clampd(ail, -1, 1), aero_r = clampd(-rud, -1, 1);
+    const double aero_f = clampd(u[FB_U_FLAPS], 0, 1);
+
+    v3 F_b = {0, 0, 0}, tau_b = {0, 0, 0};  // total external wrench at Ob, body axes
+
+    // ===== aerodynamics (c172.jl:307-373, 226-245) =====
+    {
+        const double* A = T.lds + LDS_AERO;
+        double alpha = 0, beta = 0;
+        if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
+            alpha = atan2(v_wb_b.z, v_wb_b.x);
+            beta = atan2(v_wb_b.y, sqrt(v_wb_b.x * v_wb_b.x + v_wb_b.z * v_wb_b.z));
+        }
+        const double V = fmax(TAS, V_min);
+        const double afd = 1 / tau_filt * (alpha - x[FB_X_ALPHA_FILT]);
+        const double bfd = 1 / tau_filt * (beta - x[FB_X_BETA_FILT]);
+        xd[FB_X_ALPHA_FILT] = afd;
+        xd[FB_X_BETA_FILT] = bfd;
+        const double i2V = 1 / (2 * V);
+        const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
+        const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
+        const double de = de_lo + (de_hi - de_lo) / 2 * (aero_e + 1);
+        const double da = da_lo + (da_hi - da_lo) / 2 * (aero_a + 1);
+        const double dr = dr_lo + (dr_hi - dr_lo) / 2 * (aero_r + 1);
+        const double df = df_lo + (df_hi - df_lo) / 1 * (aero_f - 0);
+        const double dh_nd = (h_o - env.h_trn) / b;
+        const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
+
+        const loc l_ge = grid_locate<13>(A + AT_GE_K, dh_nd, true, true);
+        const loc l_df4 = grid_locate<4>(A + AT_DF4_K, df, true, true);
+        const loc l_df2 = grid_locate<2>(A + AT_DF2_K, df, true, true);
+        const loc l_al26 = grid_locate<26>(A + AT_CD_ALPHA_K, al, true, true);
+        const loc l_al17 = grid_locate<17>(A + AT_CL_ALPHA_K, al, true, true);
+        const loc l_al2 = grid_locate<2>(A + AT_ALPHA2_K, al, true, true);
+        const loc l_be3 = grid_locate<3>(A + AT_CY_BETA_K, be, true, true);
+        const loc l_de = grid_locate<3>(A + AT_UNIT3_K, de, true, true);
+        const loc l_bu = grid_locate<3>(A + AT_UNIT3_K, be, true, true);
+        const loc l_stall = {0, stall ? 1.0 : 0.0};
+        const double* S_ = A + AT_SCALARS;
+
+        const double C_D = S_[AS_CD_ZERO] + lerp1(A + AT_CD_GE_V, l_ge) * (lerp2(A + AT_CD_ALPHA_DF_V, 26, l_al26, l_df4) + lerp1(A + AT_CD_DF_V, l_df4)) +
+                           lerp1(A + AT_CD_DE_V, l_de) + lerp1(A + AT_CD_BETA_V, l_bu);
+        const double C_Y = S_[AS_CY_DR] * dr + S_[AS_CY_DA] * da + lerp2(A + AT_CY_BETA_DF_V, 3, l_be3, l_df2) +
+                           lerp2(A + AT_CY_P_V, 2, l_al2, l_df2) * p_nd + lerp2(A + AT_CY_R_V, 2, l_al2, l_df2) * r_nd;
+        const double C_L = lerp1(A + AT_CL_GE_V, l_ge) * (lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + lerp1(A + AT_CL_DF_V, l_df4)) +
+                           S_[AS_CL_DE] * de + S_[AS_CL_Q] * q_nd + S_[AS_CL_ALPHA_DOT] * ad_nd;
+        const double C_l = S_[AS_Cl_DA] * da + S_[AS_Cl_DR] * dr + S_[AS_Cl_BETA] * be + S_[AS_Cl_P] * p_nd +
+                           lerp2(A + AT_CL_R_V, 2, l_al2, l_df2) * r_nd;
+        const double C_m = S_[AS_CM_ZERO] + S_[AS_CM_DE] * de + lerp1(A + AT_CM_DF_V, l_df4) + S_[AS_CM_ALPHA] * al + S_[AS_CM_Q] * q_nd +
+                           S_[AS_CM_ALPHA_DOT] * ad_nd;
+        const double C_n = S_[AS_CN_DR] * dr + S_[AS_CN_DA] * da + S_[AS_CN_BETA] * be + S_[AS_CN_P] * p_nd + S_[AS_CN_R] * r_nd;
+
+        // stability -> body axes: rotation by Ry(-α) with the UNCLAMPED α (c172.jl:356-359; atmosphere.jl:353-356)
+        double sa, ca;
+        sincos(0.5 * (-alpha), &sa, &ca);
+        const double qS = q_dyn * S;
+        const v3 F_s = {qS * -C_D, qS * C_Y, qS * -C_L};
+        const v3 F_a = qrot(quat{ca, 0.0, sa, 0.0}, F_s);
+        const v3 tau_a = {qS * (C_l * b), qS * (C_m * c), qS * (C_n * b)};
+        F_b = F_b + F_a;
+        tau_b = tau_b + tau_a;
+        aux.alpha = alpha;
+        if (WITH_Y) {
+            YP(FB_Y_AERO, alpha); YP(FB_Y_AERO + 1, beta); YP(FB_Y_AERO + 2, afd); YP(FB_Y_AERO + 3, bfd);
+            YP(FB_Y_AERO + 4, C_D); YP(FB_Y_AERO + 5, C_Y); YP(FB_Y_AERO + 6, C_L); YP(FB_Y_AERO + 7, C_l); YP(FB_Y_AERO + 8, C_m); YP(FB_Y_AERO + 9, C_n);
+            YP3(FB_Y_AERO + 10, F_a); YP3(FB_Y_AERO + 13, tau_a);
+        }
+    }
+
+    // ===== landing gear: left, right, nose (landinggear.jl:524-537, 228-328, 411-476) =====
+    aux.wow = 0;
+    aux.crash = 0;
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
+        const v3 r_bs_e = qrot(q_eb, r_bs_b);
+        const v3 r_ew0_e = r_eb_e + r_bs_e;  // l_0 = 0
+        v3 loc_Ot;
+        double he_Ow0;
+        geodetic_from_ecef(r_ew0_e, loc_Ot, he_Ow0);
+        if (!(he_Ow0 >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        const double he_Ot = env.h_trn + geoid_height(T, loc_Ot);
+        const double dh = he_Ow0 - he_Ot;
+        const bool wow = dh <= 0;
+        const double x0 = x[FB_X_LDG_FRC + 2 * g], x1 = x[FB_X_LDG_FRC + 2 * g + 1];
+        double v_xy0 = 0, v_xy1 = 0;
+        GroundOut go;
+        go.F_b = {0, 0, 0}; go.tau_b = {0, 0, 0}; go.xi = 0; go.xi_dot = 0; go.F_dmp = 0; go.alpha_ts = 0; go.st = 0;
+        GroundIn gi;
+        if (wow) {
+            gi.q_eb = q_eb; gi.q_nb = q_nb; gi.q_en = qmul(q_eb, qconj(q_nb));
+            gi.r_eb_e = r_eb_e; gi.r_bs_e = r_bs_e; gi.ks_e = qrot(q_eb, v3{0, 0, 1});
+            gi.w_eb_b = w_eb_b; gi.v_eb_b = v_eb_b; gi.loc_Ot = loc_Ot; gi.he_Ot = he_Ot;
+            gi.g = g; gi.surface = env.surface;
+            gi.steer_engaged = (in.ui & FB_UI_STEERING_ENGAGED) ? 1 : 0;
+            gi.steer_in = clampd(rud, -1, 1);
+            gi.brake_in = (g == 0) ? clampd(u[FB_U_BRAKE_LEFT], 0, 1) : ((g == 1) ? clampd(u[FB_U_BRAKE_RIGHT], 0, 1) : 0.0);
+            gear_ground_kinematics(gi, go);
+            v_xy0 = go.v_xy0; v_xy1 = go.v_xy1;
+            st |= go.st;
+        }
+        // friction regulator: input = -v_ec_xy (zero when airborne) (landinggear.jl:418-424)
+        double out0, out1;
+        xd[FB_X_LDG_FRC + 2 * g] = pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy0, x0, out0);
+        xd[FB_X_LDG_FRC + 2 * g + 1] = pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy1, x1, out1);
+        if (wow) {
+            gi.frc_out0 = out0; gi.frc_out1 = out1;
+            gear_ground_force(gi, go);
+            F_b = F_b + go.F_b;
+            tau_b = tau_b + go.tau_b;
+            aux.wow |= (1 << g);
+            if (go.alpha_ts * (180 / PI) > 60) aux.crash = 1;
+        }
+        if (-go.xi_dot > 10) aux.crash = 1;
+        if (WITH_Y) {
+            const int k = FB_Y_LDG + 11 * g;
+            YP(k, dh); YP(k + 1, wow ? 1.0 : 0.0); YP(k + 2, go.xi); YP(k + 3, go.xi_dot); YP(k + 4, go.F_dmp);
+            YP3(k + 5, go.F_b); YP3(k + 8, go.tau_b);
+        }
+    }
+
+    // ===== power plant: propeller then engine (piston.jl:575-595; propellers.jl:405-452; piston.jl:314-426) =====
+    v3 h_rot;
+    double mdot;
+    {
+        const double* PT = T.lds + LDS_PISTON;
+        const double* PR = T.lds + LDS_PROP;
+        const double w_eng = x[FB_X_ENG_OMEGA];
+        const double w_prop = w_eng;  // gear ratio 1
+        const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
+        const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
+        const double v_J = norm(v_p);
+        const double J_adv = 2 * PI * v_J / (fmax(fabs(w_prop), 1.0) * prop_d);
+        const double Mt = fabs(w_prop) * (prop_d / 2) / a_snd;
+        const loc lj = range_locate(0.0, 1.5, PR_NJ, J_adv, true);
+        const loc lm = range_locate(0.0, 1.5, PR_NM, Mt, true);
+        const double* c00 = PR + (lj.i + PR_NJ * lm.i) * PR_NC;
+        const double* c10 = c00 + PR_NC;
+        const double* c01 = c00 + PR_NJ * PR_NC;
+        const double* c11 = c01 + PR_NC;
+        const double w00 = (1 - lj.w) * (1 - lm.w), w01 = (1 - lj.w) * lm.w, w10 = lj.w * (1 - lm.w), w11 = lj.w * lm.w;
+        auto coef = [&](int cidx) { return (w00 * c00[cidx] + w01 * c01[cidx]) + (w10 * c10[cidx] + w11 * c11[cidx]); };
+        const double C_Fx = coef(0), C_Mx = coef(1), C_Fz_a = coef(2), C_Mz_a = coef(3);
+        double a_p = 0, b_p = 0;
+        if (!(v_J < 0.1)) {
+            a_p = atan2(v_p.z, v_p.x);
+            b_p = atan2(v_p.y, sqrt(v_p.x * v_p.x + v_p.z * v_p.z));
+        }
+        const double fr = w_prop / (2 * PI), fr2 = fr * fr;
+        constexpr double d4 = prop_d * prop_d * prop_d * prop_d, d5 = d4 * prop_d;
+        const double kF = rho * fr2 * d4, kM = rho * fr2 * d5;
+        const v3 F_p = {kF * C_Fx, kF * (C_Fz_a * b_p), kF * (C_Fz_a * a_p)};
+        const v3 tau_p = {kM * C_Mx, kM * (C_Mz_a * b_p), kM * (C_Mz_a * a_p)};  // CW: sense = +1
+        const v3 tau_pb = tau_p + cross(r_p, F_p);
+        F_b = F_b + F_p;
+        tau_b = tau_b + tau_pb;
+        h_rot = {prop_Jxx * w_prop, 0.0, 0.0};
+
+        // ---- engine ----
+        double out_frc, out_idle;
+        xd[FB_X_ENG_FRC] = pi_ode(5.0, 200.0, 0.0, -1.0, 1.0, -w_eng, x[FB_X_ENG_FRC], out_frc);
+        xd[FB_X_ENG_IDLE] = pi_ode(4.0, 2.0, 0.0, -0.5, 0.5, 1 - w_eng / w_idle, x[FB_X_ENG_IDLE], out_idle);
+        const double mu_ratio_idle = 0.5 + out_idle;
+        const double n_eng = w_eng / w_rated;
+        // T_ISA(p) = T_std (p/p_std)^(-βR/g), δ = (p/p_std) (T_ISA/T_std)^-1/2 (piston.jl:38-41)
+        const double T_ISA = isa::T_std * pow(p_air / isa::p_std, 6.5e-3 * isa::R / isa::g_std);
+        const double delta = (p_air / isa::p_std) / sqrt(T_ISA / isa::T_std);
+        const double throttle = clampd(u[FB_U_THROTTLE], 0, 1), mixture = clampd(u[FB_U_MIXTURE], 0, 1);
+        const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
+        const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
+        const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
+        const double k_f = 1 / sqrt(rho / isa::rho_std);
+        double mixture_pos;
+        if (in.ui & FB_UI_MIXTURE_AUTO) mixture_pos = (f_lean + mixture * (f_rich - f_lean)) / (k_f * f_rich);
+        else mixture_pos = 0.5 * (mixture + 1);
+        double MAP, f_ar = 0, tau_shaft, P_shaft = 0, SFC = 0;
+        mdot = 0;
+        if (eng_state == 0) {
+            MAP = p_air;
+            tau_shaft = out_frc * (0.01 * P_rated / w_rated);
+        } else if (eng_state == 1) {
+            MAP = mu * isa::p_std;
+            tau_shaft = tau_start;
+            P_shaft = tau_shaft * w_eng;
+        } else {
+            f_ar = k_f * (f_rich * mixture_pos);
+            // compute_π_ISA_pow (piston.jl:457-477)
+            const double d_wot = lerp2(PT + PT_DELTA_WOT_V, 2, l_n2, range_locate(0.401, 0.936, 9, mu, false));
+            const double pi_std = lerp2(PT + PT_PISTD_V, 13, grid_locate<13>(PT + PT_PISTD_N_K, n_eng, true, true),
+                                        grid_locate<3>(PT + PT_PISTD_MU_K, mu, true, true));
+            const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, grid_locate<5>(PT + PT_PIWOT_N_K, n_eng, true, true),
+                                        grid_locate<3>(PT + PT_PIWOT_D_K, d_wot, true, false));
+            double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
+            pi_isa = fmax(pi_isa, 0.0);
+            const double pi_pow = pi_isa * sqrt(T_ISA / T_air);
+            const loc l_f = grid_locate<11>(PT + PT_F_K, f_ar, true, true);
+            const double pi_act = pi_pow * lerp1(PT + PT_PI_RATIO_V, l_f);
+            MAP = mu * isa::p_std;
+            P_shaft = P_rated * pi_act;
+            tau_shaft = (w_eng > 0) ? P_shaft / w_eng : 0.0;
+            SFC = lerp2(PT + PT_SFC_POW_V, 5, grid_locate<5>(PT + PT_SFC_N_K, n_eng, false, false),
+                        grid_locate<8>(PT + PT_SFC_PI_K, pi_act, false, false)) * lerp1(PT + PT_SFC_RATIO_V, l_f);
+            mdot = SFC * P_shaft;
+        }
+        const double tau_load = tau_p.x;  // gear_ratio * τ_prop
+        xd[FB_X_ENG_OMEGA] = (tau_shaft + tau_load) / (J_eng + prop_Jxx);
+        if (WITH_Y) {
+            const int k = FB_Y_PWP;
+            YP(k, MAP); YP(k + 1, f_ar); YP(k + 2, mdot); YP(k + 3, w_eng); YP(k + 4, tau_shaft); YP(k + 5, P_shaft); YP(k + 6, SFC);
+            YP(k + 7, out_idle); YP(k + 8, out_frc);
+            YP(k + 9, J_adv); YP(k + 10, Mt); YP3(k + 11, F_p); YP3(k + 14, tau_pb); YP3(k + 17, h_rot);
+            YP(k + 20, rho * fabs(fr * fr2) * d5 * coef(4)); YP(k + 21, coef(5));
+        }
+    }
+
+    // ===== fuel (c172.jl:607-616) =====
+    const double m_fuel_total = m_res + x[FB_X_FUEL] * (m_full - m_res);
+    xd[FB_X_FUEL] = -mdot / (m_full - m_res);
+    aux.m_avail = m_fuel_total - m_res;
+    YP(FB_Y_FUEL, m_fuel_total);
+
+    // ===== total mass properties at Ob (dynamics.jl:328-399; c172.jl:26-44, 542-554, 618-636) =====
+    double M = afm_m;
+    v3 Mr = afm_m * v3{afm_r[0], afm_r[1], afm_r[2]};
+    double J[6] = {afm_J[0] + afm_m * (afm_r[1] * afm_r[1] + afm_r[2] * afm_r[2]),
+                   afm_J[1] + afm_m * (afm_r[0] * afm_r[0] + afm_r[2] * afm_r[2]),
+                   afm_J[2] + afm_m * (afm_r[0] * afm_r[0] + afm_r[1] * afm_r[1]),
+                   -afm_m * (afm_r[0] * afm_r[1]), -afm_m * (afm_r[0] * afm_r[2]), -afm_m * (afm_r[1] * afm_r[2])};
+    {
+        const double m_half = 0.5 * fmax(0.0, m_fuel_total);
+        add_point(m_half, fuel_r[0], M, Mr, J);
+        add_point(m_half, fuel_r[1], M, Mr, J);
+#pragma unroll
+        for (int k = 0; k < 5; k++) add_point(clampd(u[FB_U_M_PILOT + k], 0, 100), pld_r[k], M, Mr, J);
+    }
+    const double iM = 1 / M;
+    const v3 r_bc = iM * Mr;  // CoM position in body frame
+
+    // ===== rigid-body dynamics at the CoM (dynamics.jl:443-525) =====
+    {
+        const v3 w_ie_b = qrot_inv(q_eb, v3{0, 0, wgs::w_ie});
+        // inertia about the CoM: J_c = J_b + m skew(r)^2
+        const double rr = dot(r_bc, r_bc);
+        const double Jxx = J[0] - M * (rr - r_bc.x * r_bc.x), Jyy = J[1] - M * (rr - r_bc.y * r_bc.y), Jzz = J[2] - M * (rr - r_bc.z * r_bc.z);
+        const double Jxy = J[3] + M * (r_bc.x * r_bc.y), Jxz = J[4] + M * (r_bc.x * r_bc.z), Jyz = J[5] + M * (r_bc.y * r_bc.z);
+        auto Jmul = [&](v3 v) { return v3{Jxx * v.x + Jxy * v.y + Jxz * v.z, Jxy * v.x + Jyy * v.y + Jyz * v.z, Jxz * v.x + Jyz * v.y + Jzz * v.z}; };
+        const v3 F_c = F_b;
+        const v3 tau_c = tau_b - cross(r_bc, F_b);
+        const v3 v_ec_c = v_eb_b + cross(w_eb_b, r_bc);
+        const v3 w_ic_c = w_ie_b + w_eb_b;
+        // gravity at the CoM, along -n_e(Oc)
+        const v3 r_ec_e = r_eb_e + qrot(q_eb, r_bc);
+        v3 n_c;
+        double h_c;
+        geodetic_from_ecef(r_ec_e, n_c, h_c);
+        if (!(h_c >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        const double g = normal_gravity(n_c.z, h_c);
+        const v3 g_c_c = qrot_inv(q_eb, (-g) * n_c);
+
+        const v3 hc = Jmul(w_ic_c) + h_rot;
+        const v3 rhs_w = tau_c - Jmul(cross(w_ie_b, w_eb_b)) - cross(w_ic_c, hc);
+        // symmetric 3x3 solve by cofactors
+        const double c11 = Jyy * Jzz - Jyz * Jyz, c12 = Jyz * Jxz - Jxy * Jzz, c13 = Jxy * Jyz - Jyy * Jxz;
+        const double c22 = Jxx * Jzz - Jxz * Jxz, c23 = Jxy * Jxz - Jxx * Jyz, c33 = Jxx * Jyy - Jxy * Jxy;
+        const double idet = 1 / (Jxx * c11 + Jxy * c12 + Jxz * c13);
+        const v3 wd = {(c11 * rhs_w.x + c12 * rhs_w.y + c13 * rhs_w.z) * idet, (c12 * rhs_w.x + c22 * rhs_w.y + c23 * rhs_w.z) * idet,
+                       (c13 * rhs_w.x + c23 * rhs_w.y + c33 * rhs_w.z) * idet};
+        const v3 vd_c = iM * F_c + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
+        const v3 vd_b = vd_c - cross(wd, r_bc);
+        xd[FB_X_OMEGA_EB_B] = wd.x; xd[FB_X_OMEGA_EB_B + 1] = wd.y; xd[FB_X_OMEGA_EB_B + 2] = wd.z;
+        xd[FB_X_V_EB_B] = vd_b.x; xd[FB_X_V_EB_B + 1] = vd_b.y; xd[FB_X_V_EB_B + 2] = vd_b.z;
+        if (WITH_Y) {
+            const int k = FB_Y_DYN;
+            YP(k, M); YP3(k + 1, r_bc);
+            YP(k + 4, J[0]); YP(k + 5, J[3]); YP(k + 6, J[4]); YP(k + 7, J[3]); YP(k + 8, J[1]); YP(k + 9, J[5]); YP(k + 10, J[4]); YP(k + 11, J[5]); YP(k + 12, J[2]);
+            YP3(k + 13, F_b); YP3(k + 16, tau_b); YP3(k + 19, wd); YP3(k + 22, vd_b);
+            const v3 r_eb_b = qrot_inv(q_eb, r_eb_e), r_ec_c = qrot_inv(q_eb, r_ec_e);
+            YP3(k + 25, vd_b + cross(w_eb_b, v_eb_b));
+            YP3(k + 28, vd_b + cross(w_eb_b + 2.0 * w_ie_b, v_eb_b) + cross(w_ie_b, cross(w_ie_b, r_eb_b)));
+            const v3 a_ic = vd_c + cross(w_eb_b + 2.0 * w_ie_b, v_ec_c) + cross(w_ie_b, cross(w_ie_b, r_ec_c));
+            const v3 gam = g_c_c + cross(w_ie_b, cross(w_ie_b, r_ec_c));
+            YP3(k + 31, a_ic - gam); YP3(k + 34, wd - cross(w_eb_b, w_ie_b)); YP3(k + 37, g_c_c);
+        }
+    }
+    return st;
+}
+
+// f_step!(world): kinematics renormalisation, stall hysteresis, contact-regulator reset, crash checks,
+// engine state machine (aircraftbase.jl:172-181; kinematics.jl:226-229,114-118; c172.jl:375-384,715-724;
+// landinggear.jl:331-347,479-483; piston.jl:428-453). Returns true when x or s changed.
+FBD bool f_step(double (&x)[FB_NX], int& stall, int& eng_state, const Inputs& in, const StepAux& aux, int32_t& st) {
+    bool mod = false;
+    {
+        const double n2 = x[FB_X_Q_WB] * x[FB_X_Q_WB] + x[FB_X_Q_WB + 1] * x[FB_X_Q_WB + 1] + x[FB_X_Q_WB + 2] * x[FB_X_Q_WB + 2] + x[FB_X_Q_WB + 3] * x[FB_X_Q_WB + 3];
+        const double nr = sqrt(n2);
+        if (fabs(nr - 1.0) > 1e-8) {
+            x[FB_X_Q_WB] /= nr; x[FB_X_Q_WB + 1] /= nr; x[FB_X_Q_WB + 2] /= nr; x[FB_X_Q_WB + 3] /= nr;
+            mod = true;
+        }
+    }
+    {
+        const double n2 = x[FB_X_Q_EW] * x[FB_X_Q_EW] + x[FB_X_Q_EW + 1] * x[FB_X_Q_EW + 1] + x[FB_X_Q_EW + 2] * x[FB_X_Q_EW + 2] + x[FB_X_Q_EW + 3] * x[FB_X_Q_EW + 3];
+        const double nr = sqrt(n2);
+        if (fabs(nr - 1.0) > 1e-8) {
+            x[FB_X_Q_EW] /= nr; x[FB_X_Q_EW + 1] /= nr; x[FB_X_Q_EW + 2] /= nr; x[FB_X_Q_EW + 3] /= nr;
+            mod = true;
+        }
+    }
+    const int stall0 = stall, eng0 = eng_state;
+    if (aux.alpha > c172::alpha_stall_hi) stall = 1;
+    else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
+    if (aux.crash) st |= FB_ST_GROUND_CRASH;
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        if (!(aux.wow & (1 << g))) {
+            if (x[FB_X_LDG_FRC + 2 * g] != 0.0 || x[FB_X_LDG_FRC + 2 * g + 1] != 0.0) mod = true;
+            x[FB_X_LDG_FRC + 2 * g] = 0.0;
+            x[FB_X_LDG_FRC + 2 * g + 1] = 0.0;
+        }
+    }
+    const double w = x[FB_X_ENG_OMEGA];
+    const bool fuel = aux.m_avail > 0;
+    const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
+    if (eng_state == 0) {
+        if (start) eng_state = 1;
+    } else if (eng_state == 1) {
+        if (!start) eng_state = 0;
+        if (w > c172::w_idle && fuel) eng_state = 2;
+    } else {
+        if (stop || w < c172::w_stall || !fuel) eng_state = 0;
+    }
+    return mod || stall != stall0 || eng_state != eng0;
+}
+
+}  // namespace fbd

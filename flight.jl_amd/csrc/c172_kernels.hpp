@@ -1,0 +1,411 @@
+// c172_kernels.hpp — HIP kernels for gfx950: f_ode, fused RK4 stepper, f_step, trim.
+//
+// Mapping: one lane = one aircraft; 256-lane workgroups; state is structure-of-arrays in HBM
+// (x[k*N + i]) so every load/store is one coalesced 512-B request per wave. The three small tables are
+// copied into LDS once per workgroup. The stepper keeps the state in registers for `nsteps` RK4 steps
+// per launch, so HBM traffic per aircraft-step is (27 x 8 B read + 27 x 8 B write + flags)/nsteps.
+//
+// Stepper semantics (lib/FlightCore/src/sim.jl:204-218,301-328 + OrdinaryDiffEq RK4):
+//   k1 = f(x_n) ; k2 = f(x_n + dt/2 k1) ; k3 = f(x_n + dt/2 k2) ; k4 = f(x_n + dt k3)
+//   x_{n+1} = x_n + dt/6 (2 (k2 + k3) + (k1 + k4)) ; y = f(x_{n+1}) ; f_step!(x_{n+1}, y)
+// The reference evaluates f six times per step (k1..k4, the evaluation at x_{n+1} that feeds the
+// callbacks, and a re-evaluation after the state-modifying callback). f is a pure function of
+// (x, u, s), so the evaluation at x_{n+1} IS k1 of the next step whenever f_step! changed nothing;
+// the kernel reuses it (4 evaluations per step) and re-evaluates only for the lanes whose f_step!
+// did modify x or s (quaternion renormalisation, stall flip, engine state change).
+#pragma once
+#include "c172_device.hpp"
+
+namespace fbd {
+
+// ---- ground contact, out of line (landinggear.jl:260-328, 426-476) ---------------------------
+__device__ FB_GROUND_ATTR void gear_ground_kinematics(const GroundIn& in, GroundOut& o) {
+    using namespace c172;
+    const int g = in.g;
+    const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
+    // terrain point under the wheel, ECEF (geodesy.jl:418-428)
+    const double f_den = sqrt(1 - wgs::e2 * in.loc_Ot.z * in.loc_Ot.z);
+    const double RE = wgs::a / f_den;
+    const v3 r_et_e = {(RE + in.he_Ot) * in.loc_Ot.x, (RE + in.he_Ot) * in.loc_Ot.y, (RE * (1 - wgs::e2) + in.he_Ot) * in.loc_Ot.z};
+    const v3 r_es_e = in.r_eb_e + in.r_bs_e;
+    const v3 r_st_e = r_et_e - r_es_e;
+    const v3 ut_e = qrot(in.q_en, v3{0, 0, 1});
+    const double ut_ks = dot(ut_e, in.ks_e);
+    const double l = dot(ut_e, r_st_e) / ut_ks;
+    o.alpha_ts = acos(fmax(fmin(ut_ks, 1.0), -1.0));
+    o.xi = fmin(0.0, l);
+    const v3 r_bc_b = v3{0, 0, o.xi} + r_bs_b;
+    const v3 v_body = in.v_eb_b + cross(in.w_eb_b, r_bc_b);
+    const double psi_v = atan2(v_body.y, v_body.x);
+    double psi_sw = 0.0;
+    if (g == 2) psi_sw = in.steer_engaged ? in.steer_in * psi_max : psi_v;
+    double s, c;
+    sincos(0.5 * psi_sw, &s, &c);
+    const quat q_nw = qmul(in.q_nb, quat{c, 0, 0, s});
+    const v3 iw_n = qrot(q_nw, v3{1, 0, 0});
+    const v3 kc = {0, 0, 1};
+    const v3 iw_t = iw_n - dot(iw_n, kc) * kc;
+    const v3 ic = (1 / norm(iw_t)) * iw_t;
+    const v3 jc = cross(kc, ic);
+    // RQuat(RMatrix([ic jc kc])) (attitude.jl:192-233)
+    const double R[3][3] = {{ic.x, jc.x, kc.x}, {ic.y, jc.y, kc.y}, {ic.z, jc.z, kc.z}};
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    int imax = 0;
+    double best = tr;
+    if (R[0][0] > best) { best = R[0][0]; imax = 1; }
+    if (R[1][1] > best) { best = R[1][1]; imax = 2; }
+    if (R[2][2] > best) { best = R[2][2]; imax = 3; }
+    quat v;
+    if (imax == 0) v = {1 + tr, R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};
+    else if (imax == 1) v = {R[2][1] - R[1][2], 1 + 2 * R[0][0] - tr, R[0][1] + R[1][0], R[2][0] + R[0][2]};
+    else if (imax == 2) v = {R[0][2] - R[2][0], R[0][1] + R[1][0], 1 + 2 * R[1][1] - tr, R[1][2] + R[2][1]};
+    else v = {R[1][0] - R[0][1], R[2][0] + R[0][2], R[1][2] + R[2][1], 1 + 2 * R[2][2] - tr};
+    const double inv = 1 / sqrt(v.w * v.w + v.x * v.x + v.y * v.y + v.z * v.z);
+    const quat q_nc = {v.w * inv, v.x * inv, v.y * inv, v.z * inv};
+    const quat q_sc = qmul(qconj(in.q_nb), q_nc);  // q_ns = q_nb (q_bs = 1)
+    const v3 v_c_body = qrot_inv(q_sc, v_body);
+    const v3 ks_c = qrot_inv(q_sc, v3{0, 0, 1});
+    o.xi_dot = -v_c_body.z / ks_c.z;
+    const double kd = ldg_kd[g];  // k_d_ext == k_d_cmp for both C172 dampers (c172.jl:444-451)
+    o.F_dmp = -(ldg_ks[g] * o.xi + kd * o.xi_dot);
+    const v3 v_c = v_c_body + o.xi_dot * ks_c;
+    o.st = (fabs(v_c.z) < 1e-8) ? 0 : FB_ST_CONTACT_ASSERT;
+    o.v_xy0 = v_c.x;
+    o.v_xy1 = v_c.y;
+    o.q_sc = q_sc;
+    o.r_bc_b = r_bc_b;
+}
+
+__device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& o) {
+    const double nv = sqrt(o.v_xy0 * o.v_xy0 + o.v_xy1 * o.v_xy1);
+    auto mu = [&](double mu_s, double mu_d) {
+        const double k = fmin(fmax((nv - 0.005) / (0.01 - 0.005), 0.0), 1.0);
+        return k * mu_d + (1 - k) * mu_s;
+    };
+    const double mu_roll = mu(0.03, 0.02);
+    const double mu_skid = in.surface == 0 ? mu(0.75, 0.25) : (in.surface == 1 ? mu(0.25, 0.15) : mu(0.075, 0.025));
+    const double k_br = in.brake_in;  // η_br = 1 (landinggear.jl:106-108); nose gear has NoBraking -> 0
+    const double mu_x = mu_roll + (mu_skid - mu_roll) * k_br;
+    const double psi_cv = (nv < 1e-3) ? PI / 2 : atan2(o.v_xy1, o.v_xy0);
+    const double psi_skid = 10 * (PI / 180), psi_abs = fabs(psi_cv);
+    double mu_y;
+    if (psi_abs < psi_skid) mu_y = mu_skid * psi_abs / psi_skid;
+    else if (psi_abs > PI - psi_skid) mu_y = mu_skid * (1 - (psi_skid + psi_abs - PI) / psi_skid);
+    else mu_y = mu_skid;
+    const double sc = fmin(1.0, mu_skid / sqrt(mu_x * mu_x + mu_y * mu_y));
+    const v3 f_c = {in.frc_out0 * (mu_x * sc), in.frc_out1 * (mu_y * sc), -1.0};
+    const v3 f_s = qrot(o.q_sc, f_c);
+    const double N = fmax(0.0, -o.F_dmp / f_s.z);
+    const v3 F_b = qrot(o.q_sc, N * f_c);  // q_bc = q_sc
+    o.F_b = F_b;
+    o.tau_b = cross(o.r_bc_b, F_b);
+}
+
+// ---- kernel arguments -----------------------------------------------------------------------
+struct KArgs {
+    double* x;          // [FB_NX x n]
+    int32_t* s;         // [FB_NS x n]
+    const double* u;    // [FB_NU x n]
+    const int32_t* ui;  // [n]
+    int32_t* status;    // [n]
+    const double* tables;  // LDS_TABLE_DOUBLES doubles
+    const float* egm96;
+    int64_t n;
+    Env env;
+    double dt;
+};
+
+FBD void stage_tables(double* lds, const double* tables) {
+    for (int k = threadIdx.x; k < LDS_TABLE_DOUBLES; k += blockDim.x) lds[k] = tables[k];
+    __syncthreads();
+}
+FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
+#pragma unroll
+    for (int k = 0; k < FB_NU; k++) in.u[k] = a.u[(int64_t)k * a.n + i];
+    in.ui = a.ui[i];
+}
+
+// f_ode!(world): xdot (optional) and the output record y
+__global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y) {
+    __shared__ double lds[LDS_TABLE_DOUBLES];
+    stage_tables(lds, a.tables);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Tables T = {lds, a.egm96};
+    double x[FB_NX], xd[FB_NX];
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
+    Inputs in;
+    load_inputs(a, i, in);
+    StepAux aux;
+    const int32_t st = rhs<true>(x, a.s[i], a.s[a.n + i], in, a.env, T, xd, aux, y + i, a.n);
+    if (xdot) {
+#pragma unroll
+        for (int k = 0; k < FB_NX; k++) xdot[(int64_t)k * a.n + i] = xd[k];
+    }
+    a.status[i] |= st;
+}
+
+// f_step!(world). The reference acts on the y left behind by the last f_ode!; f_ode! is a pure
+// function of (x,u,s), so it is recomputed here from the current x.
+__global__ __launch_bounds__(256) void k_f_step(KArgs a) {
+    __shared__ double lds[LDS_TABLE_DOUBLES];
+    stage_tables(lds, a.tables);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Tables T = {lds, a.egm96};
+    double x[FB_NX], xd[FB_NX];
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
+    Inputs in;
+    load_inputs(a, i, in);
+    int stall = a.s[i], eng = a.s[a.n + i];
+    StepAux aux;
+    int32_t st = rhs<false>(x, stall, eng, in, a.env, T, xd, aux, nullptr, 0);
+    f_step(x, stall, eng, in, aux, st);
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * a.n + i] = x[k];
+    a.s[i] = stall;
+    a.s[a.n + i] = eng;
+    a.status[i] |= st;
+}
+
+// nsteps x step!(sim), fused.
+__global__ __launch_bounds__(256) void k_step(KArgs a, int nsteps) {
+    __shared__ double lds[LDS_TABLE_DOUBLES];
+    stage_tables(lds, a.tables);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    int32_t st = a.status[i];
+    if (st != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
+    const Tables T = {lds, a.egm96};
+    double xs[FB_NX], xt[FB_NX], a14[FB_NX], a23[FB_NX];
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) { xs[k] = a.x[(int64_t)k * a.n + i]; xt[k] = xs[k]; }
+    Inputs in;
+    load_inputs(a, i, in);
+    int stall = a.s[i], eng = a.s[a.n + i];
+    const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    int stage = 0, step = 0;
+    bool pending_cb = false;
+#pragma unroll 1
+    while (true) {
+        double k[FB_NX];
+        StepAux aux;
+        st |= rhs<false>(xt, stall, eng, in, a.env, T, k, aux, nullptr, 0);
+        if (stage == 0) {
+            if (pending_cb) {  // this evaluation sits at x_{n+1}: run the discrete callbacks on it
+                pending_cb = false;
+                const bool mod = f_step(xs, stall, eng, in, aux, st);
+                step++;
+                if (st != 0 || step == nsteps) break;
+                if (mod) {
+#pragma unroll
+                    for (int j = 0; j < FB_NX; j++) xt[j] = xs[j];
+                    continue;  // re-evaluate k1 on the modified state
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FB_NX; j++) { a14[j] = k[j]; xt[j] = xs[j] + hdt * k[j]; }
+            stage = 1;
+        } else if (stage == 1) {
+#pragma unroll
+            for (int j = 0; j < FB_NX; j++) { a23[j] = k[j]; xt[j] = xs[j] + hdt * k[j]; }
+            stage = 2;
+        } else if (stage == 2) {
+#pragma unroll
+            for (int j = 0; j < FB_NX; j++) { a23[j] = a23[j] + k[j]; xt[j] = xs[j] + dt * k[j]; }
+            stage = 3;
+        } else {
+#pragma unroll
+            for (int j = 0; j < FB_NX; j++) {
+                xs[j] = xs[j] + dt6 * (2 * a23[j] + (a14[j] + k[j]));
+                xt[j] = xs[j];
+            }
+            stage = 0;
+            pending_cb = true;
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xs[j]);
+    if (bad) st |= FB_ST_NAN;
+#pragma unroll
+    for (int j = 0; j < FB_NX; j++) a.x[(int64_t)j * a.n + i] = xs[j];
+    a.s[i] = stall;
+    a.s[a.n + i] = eng;
+    a.status[i] = st;
+}
+
+// ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------
+struct TrimP {
+    v3 n_e;
+    double h_e, psi_nb, EAS, gamma_wb_n, psi_wb_dot, theta_wb_dot, beta_a, fuel_load, mixture, flaps, payload[5];
+};
+// assign!(vehicle, params, state): trim unknowns -> (x, u, s)   (c172s.jl:227-263,168-220; c172.jl:825-854;
+// aircraftbase.jl:76-86,110-118; kinematics.jl:155-178)
+__device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const Env& env, const Tables& T, double (&x)[FB_NX], Inputs& in) {
+    using namespace c172;
+    const double alpha_a = z[FB_TS_ALPHA_A], phi = z[FB_TS_PHI_NB];
+    // atmosphere at Ob (ellipsoidal -> orthometric -> geopotential)
+    const double h_o = p.h_e - geoid_height(T, p.n_e);
+    double T_air, p_air;
+    int32_t st = 0;
+    isa_data(h_o * wgs::a / (wgs::a + h_o), env.T_sl, env.p_sl, T_air, p_air, st);
+    const double rho = p_air / (isa::R * T_air);
+    const double TAS = p.EAS * sqrt(isa::rho_std / rho);
+    const double cb = cos(p.beta_a);
+    const v3 v_wb_b = {TAS * (cos(alpha_a) * cb), TAS * sin(p.beta_a), TAS * (sin(alpha_a) * cb)};
+    // θ constraint (aircraftbase.jl:110-118)
+    const double a_ = v_wb_b.x / TAS;
+    const double b_ = (v_wb_b.y * sin(phi) + v_wb_b.z * cos(phi)) / TAS;
+    const double sg = sin(p.gamma_wb_n);
+    const double theta = atan((a_ * b_ + sg * sqrt(a_ * a_ + b_ * b_ - sg * sg)) / (a_ * a_ - sg * sg));
+    // q_nb = Rz(ψ) ∘ Ry(θ) ∘ Rx(φ)
+    double s1, c1, s2, c2, s3, c3;
+    sincos(0.5 * p.psi_nb, &s1, &c1);
+    sincos(0.5 * theta, &s2, &c2);
+    sincos(0.5 * phi, &s3, &c3);
+    const quat q_nb = qmul(qmul(quat{c1, 0, 0, s1}, quat{c2, 0, s2, 0}), quat{c3, s3, 0, 0});
+    // ω_wb_b from Euler rates (attitude.jl:460-474), ė = (ψ̇, θ̇, 0)
+    const double sth = sin(theta), cth = cos(theta), sph = sin(phi), cph = cos(phi);
+    const v3 w_wb_b = {-sth * p.psi_wb_dot, cth * sph * p.psi_wb_dot + cph * p.theta_wb_dot, cth * cph * p.psi_wb_dot - sph * p.theta_wb_dot};
+    const v3 v_eb_n = v3{env.wind_n, env.wind_e, env.wind_d} + qrot(q_nb, v_wb_b);
+    // WA initialisation
+    const double f_den = sqrt(1 - wgs::e2 * p.n_e.z * p.n_e.z);
+    const double R_E = wgs::a / f_den, R_N = wgs::a * (1 - wgs::e2) / (f_den * f_den * f_den);
+    const v3 w_ew_n = {v_eb_n.y / (R_E + p.h_e), -v_eb_n.x / (R_N + p.h_e), 0.0};
+    const v3 w_eb_b = qrot_inv(q_nb, w_ew_n) + w_wb_b;
+    const v3 v_eb_b = qrot_inv(q_nb, v_eb_n);
+    // q_ew = ltf(n_e) = Rz(λ) ∘ Ry(-(ϕ + π/2)) ∘ Rz(0)   (geodesy.jl:132-135)
+    const double lat = atan2(p.n_e.z, sqrt(p.n_e.x * p.n_e.x + p.n_e.y * p.n_e.y)), lon = atan2(p.n_e.y, p.n_e.x);
+    double sl, cl, sp, cp;
+    sincos(0.5 * lon, &sl, &cl);
+    sincos(0.5 * (-(lat + 0.5 * PI)), &sp, &cp);
+    const quat q_ew = qmul(quat{cl, 0, 0, sl}, quat{cp, 0, sp, 0});
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) x[k] = 0.0;
+    x[FB_X_Q_WB] = q_nb.w; x[FB_X_Q_WB + 1] = q_nb.x; x[FB_X_Q_WB + 2] = q_nb.y; x[FB_X_Q_WB + 3] = q_nb.z;
+    x[FB_X_Q_EW] = q_ew.w; x[FB_X_Q_EW + 1] = q_ew.x; x[FB_X_Q_EW + 2] = q_ew.y; x[FB_X_Q_EW + 3] = q_ew.z;
+    x[FB_X_H_E] = p.h_e;
+    x[FB_X_OMEGA_EB_B] = w_eb_b.x; x[FB_X_OMEGA_EB_B + 1] = w_eb_b.y; x[FB_X_OMEGA_EB_B + 2] = w_eb_b.z;
+    x[FB_X_V_EB_B] = v_eb_b.x; x[FB_X_V_EB_B + 1] = v_eb_b.y; x[FB_X_V_EB_B + 2] = v_eb_b.z;
+    x[FB_X_ENG_OMEGA] = z[FB_TS_N_ENG] * w_rated;
+    x[FB_X_ALPHA_FILT] = alpha_a;
+    x[FB_X_BETA_FILT] = p.beta_a;
+    x[FB_X_FUEL] = fmin(fmax(p.fuel_load, 0.0), 1.0);
+#pragma unroll
+    for (int k = 0; k < FB_NU; k++) in.u[k] = 0.0;
+    in.u[FB_U_THROTTLE] = z[FB_TS_THROTTLE]; in.u[FB_U_MIXTURE] = p.mixture;
+    in.u[FB_U_AILERON] = z[FB_TS_AILERON]; in.u[FB_U_ELEVATOR] = z[FB_TS_ELEVATOR]; in.u[FB_U_RUDDER] = z[FB_TS_RUDDER];
+    in.u[FB_U_FLAPS] = p.flaps;
+#pragma unroll
+    for (int k = 0; k < 5; k++) in.u[FB_U_M_PILOT + k] = p.payload[k];
+    in.ui = FB_UI_MIXTURE_AUTO | FB_UI_STEERING_ENGAGED;
+}
+// residuals whose squared sum is the reference's cost (c172.jl:857-867)
+__device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) {
+    double x[FB_NX], xd[FB_NX];
+    Inputs in;
+    trim_assign(p, z, env, T, x, in);
+    StepAux aux;
+    rhs<false>(x, 0, 2, in, env, T, xd, aux, nullptr, 0);
+    const double nv = sqrt(x[FB_X_V_EB_B] * x[FB_X_V_EB_B] + x[FB_X_V_EB_B + 1] * x[FB_X_V_EB_B + 1] + x[FB_X_V_EB_B + 2] * x[FB_X_V_EB_B + 2]);
+    r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
+    r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
+    r[6] = xd[FB_X_ENG_OMEGA] / c172::w_rated;
+}
+// One lane trims one aircraft. The reference minimises cost = Σ r² with NLopt's BOBYQA until
+// cost <= 1e-16 inside box bounds (c172.jl:901-934); here the same zero-residual point is found by a
+// bounded, damped Newton iteration on the 7 residuals with a central-difference Jacobian — a batched,
+// branch-light solver that maps onto one lane per aircraft.
+__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out) {
+    __shared__ double lds[LDS_TABLE_DOUBLES];
+    stage_tables(lds, a.tables);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const Tables T = {lds, a.egm96};
+    const int64_t n = a.n;
+    TrimP p;
+    p.n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
+    p.h_e = tp[(int64_t)FB_TP_H_E * n + i]; p.psi_nb = tp[(int64_t)FB_TP_PSI_NB * n + i]; p.EAS = tp[(int64_t)FB_TP_EAS * n + i];
+    p.gamma_wb_n = tp[(int64_t)FB_TP_GAMMA_WB_N * n + i]; p.psi_wb_dot = tp[(int64_t)FB_TP_PSI_WB_DOT * n + i];
+    p.theta_wb_dot = tp[(int64_t)FB_TP_THETA_WB_DOT * n + i]; p.beta_a = tp[(int64_t)FB_TP_BETA_A * n + i];
+    p.fuel_load = tp[(int64_t)FB_TP_FUEL_LOAD * n + i]; p.mixture = tp[(int64_t)FB_TP_MIXTURE * n + i]; p.flaps = tp[(int64_t)FB_TP_FLAPS * n + i];
+    for (int k = 0; k < 5; k++) p.payload[k] = tp[(int64_t)(FB_TP_PAYLOAD + k) * n + i];
+    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};
+    const double hi[7] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};
+    double z[7], r[7];
+    for (int k = 0; k < 7; k++) z[k] = ts[(int64_t)k * n + i];
+    trim_resid(p, z, a.env, T, r);
+    double cost = 0;
+    for (int k = 0; k < 7; k++) cost += r[k] * r[k];
+#pragma unroll 1
+    for (int it = 0; it < 60 && cost > 1e-26; it++) {
+        double A[7][8];
+#pragma unroll 1
+        for (int j = 0; j < 7; j++) {
+            const double h = 1e-6;
+            double zz[7], rp[7], rm[7];
+            for (int k = 0; k < 7; k++) zz[k] = z[k];
+            zz[j] = z[j] + h;
+            trim_resid(p, zz, a.env, T, rp);
+            zz[j] = z[j] - h;
+            trim_resid(p, zz, a.env, T, rm);
+            for (int k = 0; k < 7; k++) A[k][j] = (rp[k] - rm[k]) / (2 * h);
+        }
+        for (int k = 0; k < 7; k++) A[k][7] = -r[k];
+        bool singular = false;
+#pragma unroll 1
+        for (int c = 0; c < 7; c++) {
+            int pv = c;
+            for (int q = c + 1; q < 7; q++) if (fabs(A[q][c]) > fabs(A[pv][c])) pv = q;
+            if (fabs(A[pv][c]) < 1e-300) { singular = true; break; }
+            if (pv != c) for (int q = 0; q < 8; q++) { const double t = A[pv][q]; A[pv][q] = A[c][q]; A[c][q] = t; }
+            for (int q = c + 1; q < 7; q++) {
+                const double f = A[q][c] / A[c][c];
+                for (int w = c; w < 8; w++) A[q][w] -= f * A[c][w];
+            }
+        }
+        if (singular) break;
+        double dz[7];
+        for (int q = 6; q >= 0; q--) {
+            double sum = A[q][7];
+            for (int w = q + 1; w < 7; w++) sum -= A[q][w] * dz[w];
+            dz[q] = sum / A[q][q];
+        }
+        double lam = 1.0;
+        bool improved = false;
+#pragma unroll 1
+        for (int ls = 0; ls < 20; ls++) {
+            double zn[7], rn[7];
+            for (int k = 0; k < 7; k++) zn[k] = fmin(fmax(z[k] + lam * dz[k], lo[k]), hi[k]);
+            trim_resid(p, zn, a.env, T, rn);
+            double cn = 0;
+            for (int k = 0; k < 7; k++) cn += rn[k] * rn[k];
+            if (cn < cost) {
+                for (int k = 0; k < 7; k++) { z[k] = zn[k]; r[k] = rn[k]; }
+                cost = cn;
+                improved = true;
+                break;
+            }
+            lam *= 0.5;
+        }
+        if (!improved) break;
+    }
+    // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s
+    double x[FB_NX];
+    Inputs in;
+    trim_assign(p, z, a.env, T, x, in);
+    for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * n + i] = x[k];
+    double* uw = const_cast<double*>(a.u);
+    for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = in.u[k];
+    const_cast<int32_t*>(a.ui)[i] = in.ui;
+    a.s[i] = 0;        // stall = false
+    a.s[n + i] = 2;    // EngineState.running
+    for (int k = 0; k < 7; k++) ts[(int64_t)k * n + i] = z[k];
+    if (success) success[i] = cost <= 1e-16;
+    if (cost_out) cost_out[i] = cost;
+}
+
+}  // namespace fbd

@@ -1,0 +1,350 @@
+// fb_capi.hip — C ABI of libflightbatch (include/flightbatch.h) over the gfx950 kernels.
+// One handle = one HIP device + one stream + SoA device buffers. No CPU fallback: every compute entry
+// point launches a kernel; fb_create fails loudly when no HIP device is present.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "c172_kernels.hpp"
+
+using namespace fbd;
+
+static thread_local std::string g_err;
+static int32_t fail(const char* fmt, const char* what = "") {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, fmt, what);
+    g_err = buf;
+    return -1;
+}
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char b_[512];                                                                   \
+            std::snprintf(b_, sizeof b_, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+            g_err = b_;                                                                     \
+            return -2;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+struct fb_handle_s {
+    int32_t model = 0, kin = 0, dtype = 0, device = 0;
+    int64_t n = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *x_own = nullptr, *x = nullptr;
+    int32_t *s_own = nullptr, *s = nullptr;
+    double* u = nullptr;
+    int32_t* ui = nullptr;
+    int32_t* status = nullptr;
+    double* y = nullptr;      // [FB_NY x n], allocated on first use
+    double* xdot = nullptr;   // scratch [FB_NX x n]
+    double* tables = nullptr; // LDS_TABLE_DOUBLES
+    float* egm96 = nullptr;
+    double* trim_buf = nullptr;  // tp | ts | cost
+    int32_t* trim_ok = nullptr;
+    bool have_table[4] = {false, false, false, false};
+    fb_params params;
+    int32_t steps_per_launch = 1;
+    double t = 0.0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    int64_t launches = 0;
+};
+
+static KArgs make_args(fb_handle h) {
+    KArgs a;
+    a.x = h->x; a.s = h->s; a.u = h->u; a.ui = h->ui; a.status = h->status; a.tables = h->tables; a.egm96 = h->egm96;
+    a.n = h->n;
+    a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface};
+    a.dt = h->params.dt;
+    return a;
+}
+static int32_t check_ready(fb_handle h) {
+    if (!h) return fail("null handle");
+    for (int k = 0; k < 4; k++)
+        if (!h->have_table[k]) {
+            static const char* names[4] = {"EGM96", "PROPELLER", "PISTON", "AERO"};
+            return fail("table %s has not been uploaded (fb_set_table)", names[k]);
+        }
+    return 0;
+}
+static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+extern "C" {
+
+const char* fb_last_error(void) { return g_err.c_str(); }
+const char* fb_version(void) { return "flightbatch 0.1 (gfx950)"; }
+
+int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out) {
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (model_id != FB_MODEL_C172S0) return fail("model not implemented (only FB_MODEL_C172S0)");
+    if (kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
+    if (dtype != FB_F64) return fail("dtype not implemented (only FB_F64)");
+    if (n <= 0) return fail("n must be positive");
+    if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: libflightbatch requires a GPU");
+    if (device_id >= ndev) return fail("device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    fb_handle h = new fb_handle_s();
+    h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
+    h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
+    h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
+    h->params.wind_ned[0] = h->params.wind_ned[1] = h->params.wind_ned[2] = 0.0;
+    h->params.h_terrain = 0.0;
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPCHK(hipMalloc(&h->x_own, sizeof(double) * FB_NX * n));
+    HIPCHK(hipMalloc(&h->s_own, sizeof(int32_t) * FB_NS * n));
+    HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
+    HIPCHK(hipMalloc(&h->ui, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->status, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->tables, sizeof(double) * LDS_TABLE_DOUBLES));
+    HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
+    h->x = h->x_own; h->s = h->s_own;
+    HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * FB_NX * n, h->stream));
+    HIPCHK(hipMemsetAsync(h->s, 0, sizeof(int32_t) * FB_NS * n, h->stream));
+    HIPCHK(hipMemsetAsync(h->u, 0, sizeof(double) * FB_NU * n, h->stream));
+    HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * n, h->stream));
+    {
+        std::vector<int32_t> ui((size_t)n, FB_UI_DEFAULT);
+        HIPCHK(hipMemcpyAsync(h->ui, ui.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    *out = h;
+    return 0;
+}
+int32_t fb_destroy(fb_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
+    hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
+    hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+int64_t fb_size(fb_handle h) { return h ? h->n : -1; }
+
+int32_t fb_set_stream(fb_handle h, void* hip_stream) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return 0;
+}
+int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev) {
+    if (!h) return fail("null handle");
+    if ((x_dev == nullptr) != (s_dev == nullptr)) return fail("x_dev and s_dev must both be given or both be NULL");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->x = x_dev ? (double*)x_dev : h->x_own;
+    h->s = s_dev ? (int32_t*)s_dev : h->s_own;
+    return 0;
+}
+
+int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t* dims, int32_t ndims) {
+    if (!h || !data || !dims) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    int64_t count = 1;
+    for (int k = 0; k < ndims; k++) count *= dims[k];
+    switch (kind) {
+        case FB_TABLE_EGM96:
+            if (ndims != 2 || dims[0] != 721 || dims[1] != 1441) return fail("EGM96 table must be float32 [721 x 1441]");
+            HIPCHK(hipMemcpy(h->egm96, data, sizeof(float) * 721 * 1441, hipMemcpyHostToDevice));
+            break;
+        case FB_TABLE_PROPELLER: {
+            if (ndims != 3 || dims[0] != PR_NJ || dims[1] != PR_NM || dims[2] != PR_NC) return fail("propeller table must be [21 x 21 x 6]");
+            const double* src = (const double*)data;  // column-major (J, Mt, c)
+            std::vector<double> il(PR_SIZE);
+            for (int c = 0; c < PR_NC; c++)
+                for (int j = 0; j < PR_NM; j++)
+                    for (int i = 0; i < PR_NJ; i++) il[(i + PR_NJ * j) * PR_NC + c] = src[i + PR_NJ * (j + PR_NM * c)];
+            HIPCHK(hipMemcpy(h->tables + LDS_PROP, il.data(), sizeof(double) * PR_SIZE, hipMemcpyHostToDevice));
+            break;
+        }
+        case FB_TABLE_PISTON:
+            if (count != PT_SIZE) return fail("piston blob must hold PT_SIZE doubles (csrc/tables.h)");
+            HIPCHK(hipMemcpy(h->tables + LDS_PISTON, data, sizeof(double) * PT_SIZE, hipMemcpyHostToDevice));
+            break;
+        case FB_TABLE_AERO:
+            if (count != AT_SIZE) return fail("aero blob must hold AT_SIZE doubles (csrc/tables.h)");
+            HIPCHK(hipMemcpy(h->tables + LDS_AERO, data, sizeof(double) * AT_SIZE, hipMemcpyHostToDevice));
+            break;
+        default: return fail("unknown table kind");
+    }
+    h->have_table[kind] = true;
+    return 0;
+}
+int32_t fb_set_params(fb_handle h, const fb_params* p) {
+    if (!h || !p) return fail("null argument");
+    if (!(p->dt > 0)) return fail("dt must be positive");
+    h->params = *p;
+    return 0;
+}
+int32_t fb_get_params(fb_handle h, fb_params* p) {
+    if (!h || !p) return fail("null argument");
+    *p = h->params;
+    return 0;
+}
+
+int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (x) HIPCHK(hipMemcpyAsync(h->x, x, sizeof(double) * FB_NX * h->n, hipMemcpyHostToDevice, h->stream));
+    if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->t = 0.0;
+    return 0;
+}
+int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (x) HIPCHK(hipMemcpyAsync(x, h->x, sizeof(double) * FB_NX * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (s) HIPCHK(hipMemcpyAsync(s, h->s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (u) HIPCHK(hipMemcpyAsync(h->u, u, sizeof(double) * FB_NU * h->n, hipMemcpyHostToDevice, h->stream));
+    if (ui) HIPCHK(hipMemcpyAsync(h->ui, ui, sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (u) HIPCHK(hipMemcpyAsync(u, h->u, sizeof(double) * FB_NU * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (ui) HIPCHK(hipMemcpyAsync(ui, h->ui, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost) {
+    if (int32_t rc = check_ready(h)) return rc;
+    if (!trim_params || !trim_state) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    if (!h->trim_buf) {
+        HIPCHK(hipMalloc(&h->trim_buf, sizeof(double) * (FB_NTP + FB_NTS + 1) * n));
+        HIPCHK(hipMalloc(&h->trim_ok, sizeof(int32_t) * n));
+    }
+    double* d_tp = h->trim_buf;
+    double* d_ts = d_tp + (int64_t)FB_NTP * n;
+    double* d_cost = d_ts + (int64_t)FB_NTS * n;
+    HIPCHK(hipMemcpyAsync(d_tp, trim_params, sizeof(double) * FB_NTP * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_ts, trim_state, sizeof(double) * FB_NTS * n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_trim, grid_for(n, 64), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * n, h->stream));
+    HIPCHK(hipMemcpyAsync(trim_state, d_ts, sizeof(double) * FB_NTS * n, hipMemcpyDeviceToHost, h->stream));
+    if (success) HIPCHK(hipMemcpyAsync(success, h->trim_ok, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIPCHK(hipMemcpyAsync(cost, d_cost, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->t = 0.0;
+    return 0;
+}
+
+int32_t fb_f_ode(fb_handle h, double* xdot) {
+    if (int32_t rc = check_ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    if (!h->y) HIPCHK(hipMalloc(&h->y, sizeof(double) * FB_NY * n));
+    if (xdot && !h->xdot) HIPCHK(hipMalloc(&h->xdot, sizeof(double) * FB_NX * n));
+    hipLaunchKernelGGL(k_f_ode, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
+    HIPCHK(hipGetLastError());
+    if (xdot) {
+        HIPCHK(hipMemcpyAsync(xdot, h->xdot, sizeof(double) * FB_NX * n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+int32_t fb_f_step(fb_handle h) {
+    if (int32_t rc = check_ready(h)) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_f_step, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int32_t fb_f_periodic(fb_handle h) {
+    if (!h) return fail("null handle");
+    return 0;  // Cessna172Sv0: NoAvionics and @no_periodic systems — nothing to do (c172.jl:695; aircraftbase.jl:131)
+}
+int32_t fb_get_outputs(fb_handle h, double* y) {
+    if (!h || !y) return fail("null argument");
+    if (!h->y) return fail("no outputs yet: call fb_f_ode first");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(y, h->y, sizeof(double) * FB_NY * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
+    if (!h) return fail("null handle");
+    if (k < 1) return fail("steps per launch must be >= 1");
+    h->steps_per_launch = k;
+    return 0;
+}
+int32_t fb_step(fb_handle h, int64_t nsteps) {
+    if (int32_t rc = check_ready(h)) return rc;
+    if (nsteps < 0) return fail("nsteps must be >= 0");
+    HIPCHK(hipSetDevice(h->device));
+    const KArgs a = make_args(h);
+    int64_t left = nsteps;
+    while (left > 0) {
+        const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
+        hipLaunchKernelGGL(k_step, grid_for(h->n, 256), dim3(256), 0, h->stream, a, k);
+        left -= k;
+        h->launches++;
+    }
+    HIPCHK(hipGetLastError());
+    h->t += (double)nsteps * h->params.dt;
+    return 0;
+}
+int32_t fb_sync(fb_handle h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+double fb_time(fb_handle h) { return h ? h->t : 0.0; }
+
+int32_t fb_status(fb_handle h, int32_t* status) {
+    if (!h || !status) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(status, h->status, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t fb_timing_begin(fb_handle h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    h->launches = 0;
+    h->timing = true;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+int32_t fb_timing_end(fb_handle h, float* ms, int64_t* n_launches) {
+    if (!h) return fail("null handle");
+    if (!h->timing) return fail("fb_timing_end without fb_timing_begin");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    if (ms) *ms = t;
+    if (n_launches) *n_launches = h->launches;
+    h->timing = false;
+    return 0;
+}
+
+}  // extern "C"

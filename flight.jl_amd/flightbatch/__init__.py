@@ -1,0 +1,10 @@
+"""flightbatch — Python host mirror of the Flight.jl operator surface over libflightbatch (HIP, gfx950).
+
+Julia is the reference's host language and is not available in this environment; this package plays the
+role the `FlightBatch.jl` ccall shim (flight.jl_amd/julia/FlightBatch.jl) plays for a
+Julia host. Importing it requires the built shared library; there is no CPU fallback.
+"""
+from ._lib import K, EXPORTED, LIB_PATH, FlightBatchError, lib  # noqa: F401
+from .modeling import (BatchedWorld, Simulation, SimulationTermination, TimeSeries, TrimParameters, TrimState,  # noqa: F401
+                       f_init, f_ode, f_periodic, f_step, init, run, step)
+from . import tables  # noqa: F401

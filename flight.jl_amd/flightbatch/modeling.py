@@ -1,0 +1,341 @@
+"""Python mirror of the Flight.jl operator surface for the batched path.
+
+Same verbs, argument meaning and ordering as the reference (Julia's ``!`` cannot appear in a Python
+identifier, so ``f_ode!`` is ``f_ode`` etc.):
+
+    reference (file:line)                                        here
+    ------------------------------------------------------------ ------------------------------------
+    Model(SimpleWorld(Cessna172Sv0()))  FC/modeling.jl:103-153    BatchedWorld(n, device=0)
+    f_init!(world, C172.TrimParameters())  FP/world.jl:49-57      f_init(world, TrimParameters(...))
+    f_ode!(world)       FP/world.jl:26-32                         f_ode(world)
+    f_step!(world)      FP/world.jl:34-39                         f_step(world)
+    f_periodic!(Unconditional(), world)  FP/world.jl:41-47        f_periodic(world)
+    Simulation(mdl; dt, Δt, t_start, t_end)  FC/sim.jl:183-255     Simulation(mdl, dt=, Δt=, ...)
+    init!(sim, args...)  FC/sim.jl:390-414                         init(sim, *args)
+    step!(sim[, Δt_total, stop_at_tdt])  FC/sim.jl:386              step(sim[, Δt_total, stop_at_tdt])
+    run!(sim)  FC/sim.jl:611-638                                    run(sim)
+    TimeSeries(sim)  FC/sim.jl:644-704                              TimeSeries(sim)
+
+All verbs return None and mutate the model in place, like the reference (FC/modeling.jl:192-194).
+All arrays are [field, aircraft] (aircraft index fastest in memory = the C ABI's SoA layout).
+(FC = lib/FlightCore/src, FP = lib/FlightPhysics/src, FA = lib/FlightApps/src.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+import numpy as np
+
+from . import tables as _tables
+from ._lib import K, FlightBatchError, check, fb_params, lib
+
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+
+
+def _pd(a):
+    return a.ctypes.data_as(_D)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_I)
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class TrimParameters:
+    """C172.TrimParameters — FA/c172/c172.jl:806-818 (same defaults). Scalars broadcast over the batch;
+    arrays of length n give per-aircraft values."""
+    n_e: object = (1.0, 0.0, 0.0)        # Ob location, n-vector
+    h_e: object = 1050.0                 # Ob ellipsoidal altitude
+    ψ_nb: object = 0.0
+    EAS: object = 50.0
+    γ_wb_n: object = 0.0
+    ψ_wb_dot: object = 0.0
+    θ_wb_dot: object = 0.0
+    β_a: object = 0.0
+    fuel_load: object = 0.5
+    mixture: object = 0.5
+    flaps: object = 0.0
+    payload: object = (75.0, 75.0, 0.0, 0.0, 50.0)  # PayloadY defaults, c172.jl:529-535
+
+    def pack(self, n: int) -> np.ndarray:
+        tp = np.zeros((K["FB_NTP"], n))
+        ne = np.asarray(self.n_e, dtype=np.float64)
+        tp[K["FB_TP_N_E"]:K["FB_TP_N_E"] + 3] = ne.reshape(3, -1) if ne.ndim == 2 else ne[:, None]
+        for key, val in (("FB_TP_H_E", self.h_e), ("FB_TP_PSI_NB", self.ψ_nb), ("FB_TP_EAS", self.EAS),
+                         ("FB_TP_GAMMA_WB_N", self.γ_wb_n), ("FB_TP_PSI_WB_DOT", self.ψ_wb_dot),
+                         ("FB_TP_THETA_WB_DOT", self.θ_wb_dot), ("FB_TP_BETA_A", self.β_a),
+                         ("FB_TP_FUEL_LOAD", self.fuel_load), ("FB_TP_MIXTURE", self.mixture), ("FB_TP_FLAPS", self.flaps)):
+            tp[K[key]] = np.asarray(val, dtype=np.float64)
+        pl = np.asarray(self.payload, dtype=np.float64)
+        tp[K["FB_TP_PAYLOAD"]:K["FB_TP_PAYLOAD"] + 5] = pl.reshape(5, -1) if pl.ndim == 2 else pl[:, None]
+        return tp
+
+
+def TrimState(n: int = 1) -> np.ndarray:
+    """C172.TrimState() initial guess — FA/c172/c172.jl:796-804. Returns [7, n]."""
+    return np.repeat(np.array([0.1, 0.0, 0.75, 0.47, 0.014, -0.0015, 0.02])[:, None], n, axis=1).copy()
+
+
+class SimulationTermination(Exception):
+    """FC/sim.jl:32. In the batch nothing is thrown from the kernels: terminated aircraft carry a sticky
+    status word (BatchedWorld.status) and freeze; the rest of the batch continues."""
+
+
+# ------------------------------------------------------------------------------------------------------
+class BatchedWorld:
+    """N independent ``Model(SimpleWorld(Cessna172Sv0()))`` instances resident on one MI355X."""
+
+    def __init__(self, n: int, device: int = 0, tables: dict | None = None):
+        self.n = int(n)
+        self._h = C.c_void_p()
+        check(lib.fb_create(K["FB_MODEL_C172S0"], K["FB_KIN_WA"], K["FB_F64"], self.n, int(device), C.byref(self._h)))
+        tb = tables or _tables.default_tables()
+        self._set_table("FB_TABLE_EGM96", np.asfortranarray(tb["egm96"], dtype=np.float32), (721, 1441))
+        self._set_table("FB_TABLE_PROPELLER", np.asfortranarray(tb["propeller"], dtype=np.float64), (21, 21, 6))
+        self._set_table("FB_TABLE_PISTON", np.ascontiguousarray(tb["piston"], dtype=np.float64), (tb["piston"].size,))
+        self._set_table("FB_TABLE_AERO", np.ascontiguousarray(tb["aero"], dtype=np.float64), (tb["aero"].size,))
+        self.t = 0.0
+        self._Δt_root = 1.0   # FC/modeling.jl:98
+        self._n = 0           # periodic update counter, FC/modeling.jl:99
+        self.trim_state = None
+        self.trim_success = None
+        self.trim_cost = None
+
+    # -- plumbing --
+    def _set_table(self, kind, arr, dims):
+        d = (C.c_int64 * len(dims))(*dims)
+        check(lib.fb_set_table(self._h, K[kind], arr.ctypes.data_as(C.c_void_p), d, len(dims)))
+
+    def close(self):
+        if self._h:
+            lib.fb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- world-level parameters (atmosphere.u / terrain, FP/atmosphere.jl:75-78,165; FP/terrain.jl:34-38) --
+    @property
+    def params(self) -> fb_params:
+        p = fb_params()
+        check(lib.fb_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.params
+        for k, v in kw.items():
+            if k == "wind_ned":
+                for j in range(3):
+                    p.wind_ned[j] = float(v[j])
+            else:
+                setattr(p, k, v)
+        check(lib.fb_set_params(self._h, C.byref(p)))
+
+    # -- mdl.x / mdl.s / mdl.u (FC/modeling.jl:89-101) --
+    @property
+    def x(self) -> np.ndarray:
+        x = np.empty((K["FB_NX"], self.n))
+        check(lib.fb_get_state(self._h, _pd(x), None))
+        return x
+
+    @x.setter
+    def x(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NX"], self.n)
+        check(lib.fb_set_state(self._h, _pd(v), None))
+
+    @property
+    def s(self) -> np.ndarray:
+        s = np.empty((K["FB_NS"], self.n), dtype=np.int32)
+        check(lib.fb_get_state(self._h, None, _pi(s)))
+        return s
+
+    @s.setter
+    def s(self, v):
+        v = np.ascontiguousarray(v, dtype=np.int32).reshape(K["FB_NS"], self.n)
+        check(lib.fb_set_state(self._h, None, _pi(v)))
+
+    def set_state(self, x, s):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(K["FB_NX"], self.n)
+        s = np.ascontiguousarray(s, dtype=np.int32).reshape(K["FB_NS"], self.n)
+        check(lib.fb_set_state(self._h, _pd(x), _pi(s)))
+
+    @property
+    def u(self) -> np.ndarray:
+        u = np.empty((K["FB_NU"], self.n))
+        check(lib.fb_get_inputs(self._h, _pd(u), None))
+        return u
+
+    @u.setter
+    def u(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NU"], self.n)
+        check(lib.fb_set_inputs(self._h, _pd(v), None))
+
+    @property
+    def ui(self) -> np.ndarray:
+        ui = np.empty(self.n, dtype=np.int32)
+        check(lib.fb_get_inputs(self._h, None, _pi(ui)))
+        return ui
+
+    @ui.setter
+    def ui(self, v):
+        v = np.ascontiguousarray(v, dtype=np.int32).reshape(self.n)
+        check(lib.fb_set_inputs(self._h, None, _pi(v)))
+
+    @property
+    def y(self) -> np.ndarray:
+        """mdl.y of the last f_ode!: [FB_NY, n] (layout: include/flightbatch.h FB_Y_*)."""
+        y = np.empty((K["FB_NY"], self.n))
+        check(lib.fb_get_outputs(self._h, _pd(y)))
+        return y
+
+    @property
+    def status(self) -> np.ndarray:
+        st = np.empty(self.n, dtype=np.int32)
+        check(lib.fb_status(self._h, _pi(st)))
+        return st
+
+    def sync(self):
+        check(lib.fb_sync(self._h))
+
+
+# ---- the verbs (all return None) ---------------------------------------------------------------------
+def f_init(world: BatchedWorld, init, trim_state: np.ndarray | None = None) -> None:
+    """f_init!(world, trim_params): FP/world.jl:49-57 -> FA/c172/c172.jl:883-942."""
+    if not isinstance(init, TrimParameters):
+        raise TypeError(f"no f_init method for {type(init).__name__}")  # MethodError, FC/modeling.jl:205-207
+    tp = init.pack(world.n)
+    ts = TrimState(world.n) if trim_state is None else np.ascontiguousarray(trim_state, dtype=np.float64).reshape(7, world.n)
+    ok = np.zeros(world.n, dtype=np.int32)
+    cost = np.zeros(world.n)
+    check(lib.fb_trim(world._h, _pd(tp), _pd(ts), _pi(ok), _pd(cost)))
+    world.trim_state, world.trim_success, world.trim_cost = ts, ok.astype(bool), cost
+    world.t = 0.0
+    return None
+
+
+def f_ode(world: BatchedWorld, xdot: np.ndarray | None = None) -> None:
+    """f_ode!(world): FP/world.jl:26-32. Fills ẋ (into `xdot` if given, [FB_NX, n]) and world.y."""
+    if xdot is not None:
+        assert xdot.dtype == np.float64 and xdot.shape == (K["FB_NX"], world.n) and xdot.flags.c_contiguous
+    check(lib.fb_f_ode(world._h, _pd(xdot) if xdot is not None else None))
+    return None
+
+
+def f_step(world: BatchedWorld) -> None:
+    """f_step!(world): FP/world.jl:34-39."""
+    check(lib.fb_f_step(world._h))
+    return None
+
+
+def f_periodic(world: BatchedWorld) -> None:
+    """f_periodic!(Unconditional(), world): FP/world.jl:41-47."""
+    check(lib.fb_f_periodic(world._h))
+    return None
+
+
+# ---- Simulation (FC/sim.jl) --------------------------------------------------------------------------
+class Simulation:
+    """Simulation(mdl; algorithm = RK4(), adaptive = false, dt = 0.02, Δt = dt, t_start = 0, t_end = 10000,
+    save_on = true, saveat = []) — FC/sim.jl:183-196. Only the fixed-step RK4 path exists here.
+    `saveat` (seconds) thins the log; saving is a device->host copy of x (and y) at those instants."""
+
+    def __init__(self, mdl: BatchedWorld, dt: float = 0.02, Δt: float | None = None, t_start: float = 0.0,
+                 t_end: float = 10000.0, save_on: bool = True, saveat: float | None = None, steps_per_launch: int | None = None,
+                 save_outputs: bool = False):
+        self.mdl = mdl
+        self.dt = float(dt)
+        self.Δt = float(Δt if Δt is not None else dt)
+        ratio = self.Δt / self.dt
+        if abs(ratio - round(ratio)) > 1e-9 or round(ratio) < 1:
+            raise ValueError("Δt must be an integer multiple of dt on the batched path")
+        self.t_start, self.t_end = float(t_start), float(t_end)
+        self.save_on = save_on
+        self.save_every = max(1, int(round((saveat if saveat else self.dt) / self.dt)))
+        self.save_outputs = save_outputs
+        mdl._Δt_root = self.Δt  # FC/sim.jl:198
+        mdl.set_params(dt=self.dt, periodic_n=int(round(ratio)))
+        self._nstep = 0
+        self.log_t: list = []
+        self.log_x: list = []
+        self.log_y: list = []
+        k = steps_per_launch or (self.save_every if save_on else 50)
+        check(lib.fb_set_steps_per_launch(mdl._h, int(k)))
+
+    # property forwarding, FC/sim.jl:261-275
+    @property
+    def t(self):
+        return self.t_start + self._nstep * self.dt
+
+    @property
+    def x(self):
+        return self.mdl.x
+
+    @property
+    def y(self):
+        return self.mdl.y
+
+    @property
+    def u(self):
+        return self.mdl.u
+
+    @property
+    def s(self):
+        return self.mdl.s
+
+    def _save(self):
+        self.log_t.append(self.t)
+        self.log_x.append(self.mdl.x)
+        if self.save_outputs:
+            f_ode(self.mdl)
+            self.log_y.append(self.mdl.y)
+
+
+def init(sim: Simulation, *init_args, **init_kwargs) -> None:
+    """init!(sim, init_args...): FC/sim.jl:390-414 — clears the log, f_init!s the model, saves y(t0)."""
+    sim.log_t.clear(); sim.log_x.clear(); sim.log_y.clear()
+    if init_args:
+        f_init(sim.mdl, *init_args, **init_kwargs)
+    sim._nstep = 0
+    sim.mdl._n = 0  # cb_periodic_init!, FC/sim.jl:358-362
+    if sim.save_on:
+        sim._save()
+    return None
+
+
+def step(sim: Simulation, Δt_total: float | None = None, stop_at_tdt: bool = True) -> None:
+    """step!(sim) / step!(sim, Δt_total, true): FC/sim.jl:386 (OrdinaryDiffEq step!)."""
+    n = 1 if Δt_total is None else int(round(Δt_total / sim.dt))
+    done = 0
+    while done < n:
+        k = min(n - done, sim.save_every - (sim._nstep % sim.save_every)) if sim.save_on else n - done
+        check(lib.fb_step(sim.mdl._h, k))
+        done += k
+        sim._nstep += k
+        if sim.save_on and sim._nstep % sim.save_every == 0:
+            sim._save()
+    sim.mdl.t = sim.t
+    return None
+
+
+def run(sim: Simulation) -> None:
+    """run!(sim) headless (pace = Inf): FC/sim.jl:611-638 — steps to t_end."""
+    step(sim, sim.t_end - sim.t, True)
+    sim.mdl.sync()
+    return None
+
+
+class TimeSeries:
+    """TimeSeries(sim): FC/sim.jl:644-704 — logged samples as arrays: t [m], x [m, FB_NX, n], y [m, FB_NY, n]."""
+
+    def __init__(self, sim: Simulation):
+        self.t = np.array(sim.log_t)
+        self.x = np.stack(sim.log_x) if sim.log_x else np.zeros((0, K["FB_NX"], sim.mdl.n))
+        self.y = np.stack(sim.log_y) if sim.log_y else None
+
+    def __len__(self):
+        return len(self.t)

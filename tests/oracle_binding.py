@@ -1,0 +1,79 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so). TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+EGM96 = os.path.join(ROOT, "flight.jl_amd", "data", "ww15mgh_le.bin")
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+
+
+def _p(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(_D if a.dtype == np.float64 else _I)
+
+
+class Oracle:
+    _lib = None
+
+    def __init__(self):
+        if Oracle._lib is None:
+            if not os.path.exists(ORACLE_SO):
+                subprocess.run(["make", "-s", "-C", os.path.dirname(ORACLE_SO)], check=True)
+            lib = C.CDLL(ORACLE_SO)
+            rc = lib.fo_init(EGM96.encode())
+            assert rc == 0, f"fo_init failed: {rc}"
+            for name in ("fo_c172_trim_cost", "fo_psi_nw_from_qew", "fo_geoid_height", "fo_gravity", "fo_h_geop_from_orth",
+                         "fo_h_orth_from_geop", "fo_h2delta", "fo_piston_lookup", "fo_engine_tau_shaft", "fo_get_mu"):
+                getattr(lib, name).restype = C.c_double
+            Oracle._lib = lib
+        self.lib = Oracle._lib
+
+    @staticmethod
+    def default_env(T_sl=288.15, p_sl=101325.0, wind=(0.0, 0.0, 0.0), h_trn=0.0, surface=0):
+        return np.array([T_sl, p_sl, wind[0], wind[1], wind[2], h_trn, float(surface)])
+
+    def max_threads(self):
+        return int(self.lib.fo_max_threads())
+
+    def f_ode(self, x, u, ui, s, env):
+        n = x.shape[1]
+        x = np.ascontiguousarray(x); u = np.ascontiguousarray(u); ui = np.ascontiguousarray(ui, dtype=np.int32); s = np.ascontiguousarray(s, dtype=np.int32)
+        xd = np.zeros((27, n)); y = np.zeros((174, n)); st = np.zeros(n, np.int32)
+        self.lib.fo_c172_f_ode(C.c_int64(n), _p(x), _p(u), _p(ui), _p(s), _p(env), _p(xd), _p(y), _p(st))
+        return xd, y, st
+
+    def f_step(self, x, u, ui, s, env):
+        n = x.shape[1]
+        x = np.array(x, dtype=np.float64, order="C"); s = np.array(s, dtype=np.int32, order="C")
+        u = np.ascontiguousarray(u); ui = np.ascontiguousarray(ui, dtype=np.int32)
+        st = np.zeros(n, np.int32)
+        self.lib.fo_c172_f_step(C.c_int64(n), _p(x), _p(u), _p(ui), _p(s), _p(env), _p(st))
+        return x, s, st
+
+    def step(self, x, u, ui, s, env, dt, nsteps, threads=0, reference_like=False, save_every=0):
+        n = x.shape[1]
+        x = np.array(x, dtype=np.float64, order="C"); s = np.array(s, dtype=np.int32, order="C")
+        u = np.ascontiguousarray(u); ui = np.ascontiguousarray(ui, dtype=np.int32)
+        st = np.zeros(n, np.int32)
+        traj = None
+        if save_every > 0:
+            traj = np.zeros((nsteps // save_every + 1, 27, n))
+        self.lib.fo_c172_step(C.c_int64(n), _p(x), _p(u), _p(ui), _p(s), _p(env), C.c_double(dt), C.c_int64(nsteps), _p(st),
+                              C.c_int32(threads), C.c_int32(1 if reference_like else 0), _p(traj), C.c_int64(save_every))
+        if save_every > 0:
+            return x, s, st, traj
+        return x, s, st
+
+    def trim(self, tp, ts, env, threads=0):
+        n = tp.shape[1]
+        tp = np.ascontiguousarray(tp); ts = np.array(ts, dtype=np.float64, order="C")
+        x = np.zeros((27, n)); u = np.zeros((16, n)); ui = np.zeros(n, np.int32); s = np.zeros((2, n), np.int32)
+        ok = np.zeros(n, np.int32); cost = np.zeros(n)
+        self.lib.fo_c172_trim(C.c_int64(n), _p(tp), _p(ts), _p(env), _p(x), _p(u), _p(ui), _p(s), _p(ok), _p(cost), C.c_int32(threads))
+        return dict(ts=ts, x=x, u=u, ui=ui, s=s, ok=ok.astype(bool), cost=cost)
