@@ -9,9 +9,10 @@
 //   * identity frame rotations of the C172 (every t_b* is a pure translation, FlightApps/src/c172/
 //     c172.jl:32,455-471,514-518,628-629; c172s.jl:30) are elided — exact, x∘1 = x in floating point;
 //   * half-angle sin/cos pairs are produced by one sincos();
-//   * the local-level frame at the centre of mass is not built through lat/lon and three quaternion
-//     products (FlightPhysics/src/dynamics.jl:476-488): gravity points along -n_e(Oc) in ECEF, so
-//     g_c = q_eb'(-g n_e); same vector, two atan2 + two sincos + three products cheaper;
+//   * every rotation that involves a STATE quaternion keeps the reference's composition order: the
+//     states q_wb, q_ew are only renormalised in f_step! (kinematics.jl:226-229), so at RK stages they
+//     are off unit norm by ~1e-8, and the reference's rotate formula is not associative for non-unit
+//     quaternions (measured: re-associating the gravity rotation moves v̇ by 5e-7 m/s²);
 //   * ECEF->geodetic (Fukushima) is evaluated once per point, not once per consumer
 //     (dynamics.jl:476,487 call it twice on the same Oc);
 //   * total mass properties are accumulated as Σm, Σm r, ΣJ with one division instead of the
@@ -644,7 +645,16 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         geodetic_from_ecef(r_ec_e, n_c, h_c);
         if (!(h_c >= H_MIN)) st |= FB_ST_ALT_RANGE;
         const double g = normal_gravity(n_c.z, h_c);
-        const v3 g_c_c = qrot_inv(q_eb, (-g) * n_c);
+        // q_el = ltf(Oc) = Rz(λ) ∘ Ry(-(ϕ + π/2)) (geodesy.jl:132-135), q_cl = q_eb' ∘ q_el, g_c = q_cl(0,0,g).
+        // The composition order must be the reference's: at RK stages q_eb is not exactly unit, and
+        // v + 2 q_im x (q_re v + q_im x v) with a non-unit q does not commute with re-association.
+        const double lat_c = atan2(n_c.z, sqrt(n_c.x * n_c.x + n_c.y * n_c.y)), lon_c = atan2(n_c.y, n_c.x);
+        double sl, cl, sp, cp;
+        sincos(0.5 * lon_c, &sl, &cl);
+        sincos(0.5 * (-(lat_c + 0.5 * PI)), &sp, &cp);
+        const quat q_el = {cl * cp, -(sl * sp), cl * sp, sl * cp};
+        const quat q_cl = qmul(qconj(q_eb), q_el);
+        const v3 g_c_c = qrot(q_cl, v3{0.0, 0.0, g});
 
         const v3 hc = Jmul(w_ic_c) + h_rot;
         const v3 rhs_w = tau_c - Jmul(cross(w_ie_b, w_eb_b)) - cross(w_ic_c, hc);

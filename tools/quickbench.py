@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo/flight.jl_amd"); sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "flight.jl_amd")); 
 import flightbatch as fb, ctypes as C
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1<<20
 t0=time.time(); w = fb.BatchedWorld(n); print("create+tables", time.time()-t0)
