@@ -27,6 +27,11 @@
 namespace fbd {
 
 #define FBD __device__ __forceinline__
+// Scheduling fence between the phases of one RHS: keeps the machine scheduler from interleaving the
+// phases for ILP, which at one wave per SIMD costs more in spills than it gains.
+#ifndef FB_PHASE_FENCE
+#define FB_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef FB_GROUND_ATTR
 #define FB_GROUND_ATTR __noinline__
 #endif
@@ -243,10 +248,36 @@ struct Env {  // fb_params subset, wave-uniform (SGPRs)
     double T_sl, p_sl, wind_n, wind_e, wind_d, h_trn;
     int surface;
 };
-struct Inputs {  // per aircraft, constant during a launch
-    double u[FB_NU];
-    int ui;
+// Per-aircraft inputs, constant during a launch. Only what the airborne path needs every RHS lives in
+// registers (deflections are pre-scaled once); the ground-only inputs (steering, brakes) are fetched from
+// global memory inside the rare contact branch.
+struct Inputs {
+    double de, da, dr, df;     // surface deflections [rad] (c172s.jl:92-120 sign conventions + c172.jl:337-340 scaling)
+    double throttle, mixture;  // engine (Ranged [0,1])
+    double m_pld[5];           // payload masses (Ranged [0,100])
+    int ui;                    // FB_UI_* bits
+    const double* u_glob;      // &u[0*n + i] for ground-only inputs; may be null (then they read as 0)
+    int64_t n;
 };
+FBD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+// mechanical actuation + Ranged saturation + linear_scaling, from the raw FB_U_* inputs
+FBD void make_inputs(Inputs& in, const double* u, int64_t stride, int ui) {
+    using namespace c172;
+    const double ail = clampd(u[FB_U_AILERON * stride], -1, 1) + clampd(u[FB_U_AILERON_OFFSET * stride], -1, 1);
+    const double elv = clampd(u[FB_U_ELEVATOR * stride], -1, 1) + clampd(u[FB_U_ELEVATOR_OFFSET * stride], -1, 1);
+    const double rud = clampd(u[FB_U_RUDDER * stride], -1, 1) + clampd(u[FB_U_RUDDER_OFFSET * stride], -1, 1);
+    const double aero_e = clampd(-elv, -1, 1), aero_a = clampd(ail, -1, 1), aero_r = clampd(-rud, -1, 1);
+    const double aero_f = clampd(u[FB_U_FLAPS * stride], 0, 1);
+    in.de = de_lo + (de_hi - de_lo) / 2 * (aero_e + 1);
+    in.da = da_lo + (da_hi - da_lo) / 2 * (aero_a + 1);
+    in.dr = dr_lo + (dr_hi - dr_lo) / 2 * (aero_r + 1);
+    in.df = df_lo + (df_hi - df_lo) / 1 * (aero_f - 0);
+    in.throttle = clampd(u[FB_U_THROTTLE * stride], 0, 1);
+    in.mixture = clampd(u[FB_U_MIXTURE * stride], 0, 1);
+#pragma unroll
+    for (int k = 0; k < 5; k++) in.m_pld[k] = clampd(u[(FB_U_M_PILOT + k) * stride], 0, 100);
+    in.ui = ui;
+}
 // quantities f_step! reads from the y of the last f_ode! (aircraftbase.jl:172-181; c172.jl:715-724)
 struct StepAux {
     double alpha;       // aero.y.α (c172.jl:375-384)
@@ -286,11 +317,14 @@ __device__ FB_GROUND_ATTR void gear_ground_kinematics(const GroundIn& in, Ground
 __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& o);
 
 // ---------------------------------------------------------------------------------------------
-// One RHS evaluation. x[27] -> xd[27]; fills aux (for f_step!) and, if Y != nullptr, the output record.
+// One RHS evaluation. x[27] -> 27 derivatives through emit(); fills aux (for f_step!) and, if Y != nullptr, the output record.
 // Call order of the reference: world.jl:26-32 -> aircraftbase.jl:221-230,142-170 -> c172.jl:697-713.
-template <bool WITH_Y>
+// Every derivative component is handed to `emit(index, value)` the moment it is known, so that the
+// caller can consume it at once (the stepping kernel folds it into the RK stage sums in LDS) instead of
+// keeping a 27-double array alive across the whole evaluation.
+template <bool WITH_Y, class Emit>
 FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs& in, const Env& env, const Tables& T,
-                double (&xd)[FB_NX], StepAux& aux, double* Y, int64_t n) {
+                Emit&& emit, StepAux& aux, double* Y, int64_t n) {
     using namespace c172;
     int32_t st = 0;
     auto YP = [&](int k, double v) { if (WITH_Y) Y[(int64_t)k * n] = v; };
@@ -336,9 +370,9 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     {
         const quat a = qmul(q_wb, quat{0.0, w_wb_b.x, w_wb_b.y, w_wb_b.z});
         const quat b2 = qmul(q_ew, quat{0.0, w_ew_w.x, w_ew_w.y, w_ew_w.z});
-        xd[FB_X_Q_WB] = 0.5 * a.w; xd[FB_X_Q_WB + 1] = 0.5 * a.x; xd[FB_X_Q_WB + 2] = 0.5 * a.y; xd[FB_X_Q_WB + 3] = 0.5 * a.z;
-        xd[FB_X_Q_EW] = 0.5 * b2.w; xd[FB_X_Q_EW + 1] = 0.5 * b2.x; xd[FB_X_Q_EW + 2] = 0.5 * b2.y; xd[FB_X_Q_EW + 3] = 0.5 * b2.z;
-        xd[FB_X_H_E] = -v_eb_n.z;
+        emit(FB_X_Q_WB, 0.5 * a.w); emit(FB_X_Q_WB + 1, 0.5 * a.x); emit(FB_X_Q_WB + 2, 0.5 * a.y); emit(FB_X_Q_WB + 3, 0.5 * a.z);
+        emit(FB_X_Q_EW, 0.5 * b2.w); emit(FB_X_Q_EW + 1, 0.5 * b2.x); emit(FB_X_Q_EW + 2, 0.5 * b2.y); emit(FB_X_Q_EW + 3, 0.5 * b2.z);
+        emit(FB_X_H_E, -v_eb_n.z);
     }
     quat q_en = {1, 0, 0, 0};
     if (WITH_Y) {
@@ -358,6 +392,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         YP(FB_Y_KIN + 39, v_gnd > 0.1 ? atan2(-v_eb_n.z, sqrt(v_eb_n.x * v_eb_n.x + v_eb_n.y * v_eb_n.y)) : 0.0);
     }
 
+    FB_PHASE_FENCE();
     // ===== air data (atmosphere.jl:269-283, 220-242) =====
     double T_air, p_air;
     isa_data(h_o * wgs::a / (wgs::a + h_o), env.T_sl, env.p_sl, T_air, p_air, st);
@@ -382,17 +417,9 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
                                (pow(1 + dp / isa::p_std, (isa::gamma - 1) / isa::gamma) - 1)));
     }
 
-    // ===== actuation: mechanical pass-through with sign conventions (c172s.jl:92-120) =====
-    auto clampd = [](double v, double lo, double hi) { return fmin(fmax(v, lo), hi); };
-    const double* u = in.u;
-    const double ail = clampd(u[FB_U_AILERON], -1, 1) + clampd(u[FB_U_AILERON_OFFSET], -1, 1);
-    const double elv = clampd(u[FB_U_ELEVATOR], -1, 1) + clampd(u[FB_U_ELEVATOR_OFFSET], -1, 1);
-    const double rud = clampd(u[FB_U_RUDDER], -1, 1) + clampd(u[FB_U_RUDDER_OFFSET], -1, 1);
-    const double aero_e = clampd(-elv, -1, 1), aero_a = clampd(ail, -1, 1), aero_r = clampd(-rud, -1, 1);
-    const double aero_f = clampd(u[FB_U_FLAPS], 0, 1);
-
     v3 F_b = {0, 0, 0}, tau_b = {0, 0, 0};  // total external wrench at Ob, body axes
 
+    FB_PHASE_FENCE();
     // ===== aerodynamics (c172.jl:307-373, 226-245) =====
     {
         const double* A = T.lds + LDS_AERO;
@@ -404,15 +431,12 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const double V = fmax(TAS, V_min);
         const double afd = 1 / tau_filt * (alpha - x[FB_X_ALPHA_FILT]);
         const double bfd = 1 / tau_filt * (beta - x[FB_X_BETA_FILT]);
-        xd[FB_X_ALPHA_FILT] = afd;
-        xd[FB_X_BETA_FILT] = bfd;
+        emit(FB_X_ALPHA_FILT, afd);
+        emit(FB_X_BETA_FILT, bfd);
         const double i2V = 1 / (2 * V);
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
         const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
-        const double de = de_lo + (de_hi - de_lo) / 2 * (aero_e + 1);
-        const double da = da_lo + (da_hi - da_lo) / 2 * (aero_a + 1);
-        const double dr = dr_lo + (dr_hi - dr_lo) / 2 * (aero_r + 1);
-        const double df = df_lo + (df_hi - df_lo) / 1 * (aero_f - 0);
+        const double de = in.de, da = in.da, dr = in.dr, df = in.df;
         const double dh_nd = (h_o - env.h_trn) / b;
         const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
 
@@ -457,11 +481,13 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         }
     }
 
+    FB_PHASE_FENCE();
     // ===== landing gear: left, right, nose (landinggear.jl:524-537, 228-328, 411-476) =====
     aux.wow = 0;
     aux.crash = 0;
 #pragma unroll
     for (int g = 0; g < 3; g++) {
+        FB_PHASE_FENCE();
         const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
         const v3 r_bs_e = qrot(q_eb, r_bs_b);
         const v3 r_ew0_e = r_eb_e + r_bs_e;  // l_0 = 0
@@ -483,16 +509,22 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
             gi.w_eb_b = w_eb_b; gi.v_eb_b = v_eb_b; gi.loc_Ot = loc_Ot; gi.he_Ot = he_Ot;
             gi.g = g; gi.surface = env.surface;
             gi.steer_engaged = (in.ui & FB_UI_STEERING_ENGAGED) ? 1 : 0;
-            gi.steer_in = clampd(rud, -1, 1);
-            gi.brake_in = (g == 0) ? clampd(u[FB_U_BRAKE_LEFT], 0, 1) : ((g == 1) ? clampd(u[FB_U_BRAKE_RIGHT], 0, 1) : 0.0);
+            // ground-only inputs, fetched on demand (c172s.jl:107-110)
+            gi.steer_in = 0.0;
+            gi.brake_in = 0.0;
+            if (in.u_glob) {
+                const double* ug = in.u_glob;
+                if (g == 2) gi.steer_in = clampd(clampd(ug[FB_U_RUDDER * in.n], -1, 1) + clampd(ug[FB_U_RUDDER_OFFSET * in.n], -1, 1), -1, 1);
+                else gi.brake_in = clampd(ug[(g == 0 ? FB_U_BRAKE_LEFT : FB_U_BRAKE_RIGHT) * in.n], 0, 1);
+            }
             gear_ground_kinematics(gi, go);
             v_xy0 = go.v_xy0; v_xy1 = go.v_xy1;
             st |= go.st;
         }
         // friction regulator: input = -v_ec_xy (zero when airborne) (landinggear.jl:418-424)
         double out0, out1;
-        xd[FB_X_LDG_FRC + 2 * g] = pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy0, x0, out0);
-        xd[FB_X_LDG_FRC + 2 * g + 1] = pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy1, x1, out1);
+        emit(FB_X_LDG_FRC + 2 * g, pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy0, x0, out0));
+        emit(FB_X_LDG_FRC + 2 * g + 1, pi_ode(frc_kp, frc_ki, frc_kl, -1.0, 1.0, -v_xy1, x1, out1));
         if (wow) {
             gi.frc_out0 = out0; gi.frc_out1 = out1;
             gear_ground_force(gi, go);
@@ -509,6 +541,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         }
     }
 
+    FB_PHASE_FENCE();
     // ===== power plant: propeller then engine (piston.jl:575-595; propellers.jl:405-452; piston.jl:314-426) =====
     v3 h_rot;
     double mdot;
@@ -548,14 +581,14 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
 
         // ---- engine ----
         double out_frc, out_idle;
-        xd[FB_X_ENG_FRC] = pi_ode(5.0, 200.0, 0.0, -1.0, 1.0, -w_eng, x[FB_X_ENG_FRC], out_frc);
-        xd[FB_X_ENG_IDLE] = pi_ode(4.0, 2.0, 0.0, -0.5, 0.5, 1 - w_eng / w_idle, x[FB_X_ENG_IDLE], out_idle);
+        emit(FB_X_ENG_FRC, pi_ode(5.0, 200.0, 0.0, -1.0, 1.0, -w_eng, x[FB_X_ENG_FRC], out_frc));
+        emit(FB_X_ENG_IDLE, pi_ode(4.0, 2.0, 0.0, -0.5, 0.5, 1 - w_eng / w_idle, x[FB_X_ENG_IDLE], out_idle));
         const double mu_ratio_idle = 0.5 + out_idle;
         const double n_eng = w_eng / w_rated;
         // T_ISA(p) = T_std (p/p_std)^(-βR/g), δ = (p/p_std) (T_ISA/T_std)^-1/2 (piston.jl:38-41)
         const double T_ISA = isa::T_std * pow(p_air / isa::p_std, 6.5e-3 * isa::R / isa::g_std);
         const double delta = (p_air / isa::p_std) / sqrt(T_ISA / isa::T_std);
-        const double throttle = clampd(u[FB_U_THROTTLE], 0, 1), mixture = clampd(u[FB_U_MIXTURE], 0, 1);
+        const double throttle = in.throttle, mixture = in.mixture;
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
         const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
         const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
@@ -593,7 +626,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
             mdot = SFC * P_shaft;
         }
         const double tau_load = tau_p.x;  // gear_ratio * τ_prop
-        xd[FB_X_ENG_OMEGA] = (tau_shaft + tau_load) / (J_eng + prop_Jxx);
+        emit(FB_X_ENG_OMEGA, (tau_shaft + tau_load) / (J_eng + prop_Jxx));
         if (WITH_Y) {
             const int k = FB_Y_PWP;
             YP(k, MAP); YP(k + 1, f_ar); YP(k + 2, mdot); YP(k + 3, w_eng); YP(k + 4, tau_shaft); YP(k + 5, P_shaft); YP(k + 6, SFC);
@@ -603,12 +636,14 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         }
     }
 
+    FB_PHASE_FENCE();
     // ===== fuel (c172.jl:607-616) =====
     const double m_fuel_total = m_res + x[FB_X_FUEL] * (m_full - m_res);
-    xd[FB_X_FUEL] = -mdot / (m_full - m_res);
+    emit(FB_X_FUEL, -mdot / (m_full - m_res));
     aux.m_avail = m_fuel_total - m_res;
     YP(FB_Y_FUEL, m_fuel_total);
 
+    FB_PHASE_FENCE();
     // ===== total mass properties at Ob (dynamics.jl:328-399; c172.jl:26-44, 542-554, 618-636) =====
     double M = afm_m;
     v3 Mr = afm_m * v3{afm_r[0], afm_r[1], afm_r[2]};
@@ -621,11 +656,12 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         add_point(m_half, fuel_r[0], M, Mr, J);
         add_point(m_half, fuel_r[1], M, Mr, J);
 #pragma unroll
-        for (int k = 0; k < 5; k++) add_point(clampd(u[FB_U_M_PILOT + k], 0, 100), pld_r[k], M, Mr, J);
+        for (int k = 0; k < 5; k++) add_point(in.m_pld[k], pld_r[k], M, Mr, J);
     }
     const double iM = 1 / M;
     const v3 r_bc = iM * Mr;  // CoM position in body frame
 
+    FB_PHASE_FENCE();
     // ===== rigid-body dynamics at the CoM (dynamics.jl:443-525) =====
     {
         const v3 w_ie_b = qrot_inv(q_eb, v3{0, 0, wgs::w_ie});
@@ -666,8 +702,8 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
                        (c13 * rhs_w.x + c23 * rhs_w.y + c33 * rhs_w.z) * idet};
         const v3 vd_c = iM * F_c + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
         const v3 vd_b = vd_c - cross(wd, r_bc);
-        xd[FB_X_OMEGA_EB_B] = wd.x; xd[FB_X_OMEGA_EB_B + 1] = wd.y; xd[FB_X_OMEGA_EB_B + 2] = wd.z;
-        xd[FB_X_V_EB_B] = vd_b.x; xd[FB_X_V_EB_B + 1] = vd_b.y; xd[FB_X_V_EB_B + 2] = vd_b.z;
+        emit(FB_X_OMEGA_EB_B, wd.x); emit(FB_X_OMEGA_EB_B + 1, wd.y); emit(FB_X_OMEGA_EB_B + 2, wd.z);
+        emit(FB_X_V_EB_B, vd_b.x); emit(FB_X_V_EB_B + 1, vd_b.y); emit(FB_X_V_EB_B + 2, vd_b.z);
         if (WITH_Y) {
             const int k = FB_Y_DYN;
             YP(k, M); YP3(k + 1, r_bc);

@@ -115,14 +115,16 @@ struct KArgs {
     double dt;
 };
 
+constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
+
 FBD void stage_tables(double* lds, const double* tables) {
     for (int k = threadIdx.x; k < LDS_TABLE_DOUBLES; k += blockDim.x) lds[k] = tables[k];
     __syncthreads();
 }
 FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
-#pragma unroll
-    for (int k = 0; k < FB_NU; k++) in.u[k] = a.u[(int64_t)k * a.n + i];
-    in.ui = a.ui[i];
+    make_inputs(in, a.u + i, a.n, a.ui[i]);
+    in.u_glob = a.u + i;
+    in.n = a.n;
 }
 
 // f_ode!(world): xdot (optional) and the output record y
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     Inputs in;
     load_inputs(a, i, in);
     StepAux aux;
-    const int32_t st = rhs<true>(x, a.s[i], a.s[a.n + i], in, a.env, T, xd, aux, y + i, a.n);
+    const int32_t st = rhs<true>(x, a.s[i], a.s[a.n + i], in, a.env, T, [&](int j, double v) { xd[j] = v; }, aux, y + i, a.n);
     if (xdot) {
 #pragma unroll
         for (int k = 0; k < FB_NX; k++) xdot[(int64_t)k * a.n + i] = xd[k];
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     load_inputs(a, i, in);
     int stall = a.s[i], eng = a.s[a.n + i];
     StepAux aux;
-    int32_t st = rhs<false>(x, stall, eng, in, a.env, T, xd, aux, nullptr, 0);
+    int32_t st = rhs<false>(x, stall, eng, in, a.env, T, [&](int j, double v) { xd[j] = v; }, aux, nullptr, 0);
     f_step(x, stall, eng, in, aux, st);
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * a.n + i] = x[k];
@@ -171,17 +173,30 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 }
 
 // nsteps x step!(sim), fused.
-__global__ __launch_bounds__(256) void k_step(KArgs a, int nsteps) {
+//
+// Registers are the limiter of this kernel: VALU instructions address 256 VGPRs (the AGPR half of the
+// file is only a spill cache), one fp64 value takes two, and a single RHS keeps ~200 fp64 values alive.
+// So the RK4 bookkeeping does not live in registers at all:
+//   * per lane, x_n (27 doubles) and the running stage sum (27 doubles) sit in two [27][256] LDS panels
+//     (lane-contiguous rows: conflict-free ds_read_b64/ds_write_b64). LDS per workgroup: 25 KB of tables
+//     + 108 KB of panels = one 256-lane workgroup per CU, one wave per SIMD;
+//   * the stage update is fused INTO the RHS: each derivative k_j is consumed the moment it is produced
+//     (acc_j += w k_j in LDS, x_next_j = x_n,j + c dt k_j), so no k[27] array is ever alive.
+// Stage sum: acc = k1 + 2 k2 + 2 k3, x_{n+1} = x_n + dt/6 (acc + k4) — the classic RK4 combination
+// (OrdinaryDiffEq writes it as dt/6 (2 (k2 + k3) + (k1 + k4)); same value up to the last bit).
+__global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     __shared__ double lds[LDS_TABLE_DOUBLES];
+    __shared__ double xs_l[FB_NX * STEP_BLOCK];   // x_n
+    __shared__ double acc_l[FB_NX * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
     stage_tables(lds, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t st = a.status[i];
     if (st != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
-    const Tables T = {lds, a.egm96};
-    double xs[FB_NX], xt[FB_NX], a14[FB_NX], a23[FB_NX];
+    const int t = threadIdx.x;
+    double xt[FB_NX];
 #pragma unroll
-    for (int k = 0; k < FB_NX; k++) { xs[k] = a.x[(int64_t)k * a.n + i]; xt[k] = xs[k]; }
+    for (int k = 0; k < FB_NX; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
     Inputs in;
     load_inputs(a, i, in);
     int stall = a.s[i], eng = a.s[a.n + i];
@@ -190,48 +205,58 @@ __global__ __launch_bounds__(256) void k_step(KArgs a, int nsteps) {
     bool pending_cb = false;
 #pragma unroll 1
     while (true) {
-        double k[FB_NX];
+        double xn[FB_NX];
         StepAux aux;
-        st |= rhs<false>(xt, stall, eng, in, a.env, T, k, aux, nullptr, 0);
-        if (stage == 0) {
-            if (pending_cb) {  // this evaluation sits at x_{n+1}: run the discrete callbacks on it
-                pending_cb = false;
-                const bool mod = f_step(xs, stall, eng, in, aux, st);
-                step++;
-                if (st != 0 || step == nsteps) break;
-                if (mod) {
-#pragma unroll
-                    for (int j = 0; j < FB_NX; j++) xt[j] = xs[j];
-                    continue;  // re-evaluate k1 on the modified state
-                }
+        // Opaque (always zero) LDS offset: without it LICM hoists every loop-invariant table load
+        // (~150 knots/values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
+        int lds_off = 0;
+        asm volatile("" : "+s"(lds_off));
+        const Tables T = {lds + lds_off, a.egm96};
+        // same for the per-lane inputs: keep the 11 raw values, not the dozens of products derived from them
+        Inputs inl = in;
+        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
+        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+        const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
+        auto emit = [&](int j, double kj) {
+            const int idx = j * STEP_BLOCK + t;
+            const double xs = xs_l[idx];
+            if (stage == 0) {
+                acc_l[idx] = kj;
+                xn[j] = xs + cdt * kj;
+            } else if (stage < 3) {
+                acc_l[idx] = acc_l[idx] + 2 * kj;
+                xn[j] = xs + cdt * kj;
+            } else {
+                const double v = xs + dt6 * (acc_l[idx] + kj);
+                xs_l[idx] = v;
+                xn[j] = v;
             }
+        };
+        // NB: a stage-3 emit overwrites x_n in LDS component by component; the RHS itself reads its state
+        // from the registers xt[], never from the panel, so this is safe.
+        st |= rhs<false>(xt, stall, eng, inl, a.env, T, emit, aux, nullptr, 0);
+        if (stage == 0 && pending_cb) {  // this evaluation sits at x_{n+1} (= xt): run the discrete callbacks on it
+            pending_cb = false;
+            const bool mod = f_step(xt, stall, eng, in, aux, st);
+            step++;
+            if (mod) {
 #pragma unroll
-            for (int j = 0; j < FB_NX; j++) { a14[j] = k[j]; xt[j] = xs[j] + hdt * k[j]; }
-            stage = 1;
-        } else if (stage == 1) {
-#pragma unroll
-            for (int j = 0; j < FB_NX; j++) { a23[j] = k[j]; xt[j] = xs[j] + hdt * k[j]; }
-            stage = 2;
-        } else if (stage == 2) {
-#pragma unroll
-            for (int j = 0; j < FB_NX; j++) { a23[j] = a23[j] + k[j]; xt[j] = xs[j] + dt * k[j]; }
-            stage = 3;
-        } else {
-#pragma unroll
-            for (int j = 0; j < FB_NX; j++) {
-                xs[j] = xs[j] + dt6 * (2 * a23[j] + (a14[j] + k[j]));
-                xt[j] = xs[j];
+                for (int j = 0; j < FB_NX; j++) xs_l[j * STEP_BLOCK + t] = xt[j];
             }
-            stage = 0;
-            pending_cb = true;
+            if (st != 0 || step == nsteps) break;
+            if (mod) continue;  // re-evaluate k1 on the modified state (this pass's stage-0 emits are simply redone)
         }
+#pragma unroll
+        for (int j = 0; j < FB_NX; j++) xt[j] = xn[j];
+        stage = (stage + 1) & 3;
+        pending_cb = (stage == 0);
     }
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xs[j]);
+    for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xt[j]);
     if (bad) st |= FB_ST_NAN;
 #pragma unroll
-    for (int j = 0; j < FB_NX; j++) a.x[(int64_t)j * a.n + i] = xs[j];
+    for (int j = 0; j < FB_NX; j++) a.x[(int64_t)j * a.n + i] = xt[j];
     a.s[i] = stall;
     a.s[a.n + i] = eng;
     a.status[i] = st;
@@ -244,7 +269,7 @@ struct TrimP {
 };
 // assign!(vehicle, params, state): trim unknowns -> (x, u, s)   (c172s.jl:227-263,168-220; c172.jl:825-854;
 // aircraftbase.jl:76-86,110-118; kinematics.jl:155-178)
-__device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const Env& env, const Tables& T, double (&x)[FB_NX], Inputs& in) {
+__device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const Env& env, const Tables& T, double (&x)[FB_NX], Inputs& in, double (&uraw)[FB_NU]) {
     using namespace c172;
     const double alpha_a = z[FB_TS_ALPHA_A], phi = z[FB_TS_PHI_NB];
     // atmosphere at Ob (ellipsoidal -> orthometric -> geopotential)
@@ -295,21 +320,24 @@ __device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const 
     x[FB_X_BETA_FILT] = p.beta_a;
     x[FB_X_FUEL] = fmin(fmax(p.fuel_load, 0.0), 1.0);
 #pragma unroll
-    for (int k = 0; k < FB_NU; k++) in.u[k] = 0.0;
-    in.u[FB_U_THROTTLE] = z[FB_TS_THROTTLE]; in.u[FB_U_MIXTURE] = p.mixture;
-    in.u[FB_U_AILERON] = z[FB_TS_AILERON]; in.u[FB_U_ELEVATOR] = z[FB_TS_ELEVATOR]; in.u[FB_U_RUDDER] = z[FB_TS_RUDDER];
-    in.u[FB_U_FLAPS] = p.flaps;
+    for (int k = 0; k < FB_NU; k++) uraw[k] = 0.0;
+    uraw[FB_U_THROTTLE] = z[FB_TS_THROTTLE]; uraw[FB_U_MIXTURE] = p.mixture;
+    uraw[FB_U_AILERON] = z[FB_TS_AILERON]; uraw[FB_U_ELEVATOR] = z[FB_TS_ELEVATOR]; uraw[FB_U_RUDDER] = z[FB_TS_RUDDER];
+    uraw[FB_U_FLAPS] = p.flaps;
 #pragma unroll
-    for (int k = 0; k < 5; k++) in.u[FB_U_M_PILOT + k] = p.payload[k];
-    in.ui = FB_UI_MIXTURE_AUTO | FB_UI_STEERING_ENGAGED;
+    for (int k = 0; k < 5; k++) uraw[FB_U_M_PILOT + k] = p.payload[k];
+    make_inputs(in, uraw, 1, FB_UI_MIXTURE_AUTO | FB_UI_STEERING_ENGAGED);
+    in.u_glob = nullptr;  // trim is an airborne condition (c172s.jl:256 asserts no weight on wheels)
+    in.n = 0;
 }
 // residuals whose squared sum is the reference's cost (c172.jl:857-867)
 __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) {
     double x[FB_NX], xd[FB_NX];
     Inputs in;
-    trim_assign(p, z, env, T, x, in);
+    double uraw[FB_NU];
+    trim_assign(p, z, env, T, x, in, uraw);
     StepAux aux;
-    rhs<false>(x, 0, 2, in, env, T, xd, aux, nullptr, 0);
+    rhs<false>(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, nullptr, 0);
     const double nv = sqrt(x[FB_X_V_EB_B] * x[FB_X_V_EB_B] + x[FB_X_V_EB_B + 1] * x[FB_X_V_EB_B + 1] + x[FB_X_V_EB_B + 2] * x[FB_X_V_EB_B + 2]);
     r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
@@ -394,12 +422,12 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
         if (!improved) break;
     }
     // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s
-    double x[FB_NX];
+    double x[FB_NX], uraw[FB_NU];
     Inputs in;
-    trim_assign(p, z, a.env, T, x, in);
+    trim_assign(p, z, a.env, T, x, in, uraw);
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * n + i] = x[k];
     double* uw = const_cast<double*>(a.u);
-    for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = in.u[k];
+    for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = uraw[k];
     const_cast<int32_t*>(a.ui)[i] = in.ui;
     a.s[i] = 0;        // stall = false
     a.s[n + i] = 2;    // EngineState.running

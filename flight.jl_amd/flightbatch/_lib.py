@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libflightbatch.so")
+LIB_PATH = os.environ.get("FLIGHTBATCH_LIB") or os.path.join(os.path.dirname(_HERE), "libflightbatch.so")  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "flightbatch.h")
 
 
