@@ -58,19 +58,19 @@ def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     orc = Oracle()
-    threads = orc.max_threads()
+    threads = min(orc.max_threads(), len(os.sched_getaffinity(0)))   # the cores this process may actually use
     env = orc.default_env()
-    m = min(4096, x0.shape[1])
+    m = min(16384, x0.shape[1])
     sel = slice(0, m)
     xs, us, uis, ss = (np.ascontiguousarray(x0[:, sel]), np.ascontiguousarray(u0[:, sel]), np.ascontiguousarray(ui0[sel]),
                        np.ascontiguousarray(s0[:, sel]))
     t0 = time.perf_counter()
-    orc.step(xs, us, uis, ss, env, DT, 20, threads=0, reference_like=True)
+    orc.step(xs, us, uis, ss, env, DT, 20, threads=threads, reference_like=True)
     probe = time.perf_counter() - t0
     rate = m * 20 / probe
     nsteps = int(max(20, min(2000, budget_s * rate / m)))
     t0 = time.perf_counter()
-    orc.step(xs, us, uis, ss, env, DT, nsteps, threads=0, reference_like=True)
+    orc.step(xs, us, uis, ss, env, DT, nsteps, threads=threads, reference_like=True)
     el = time.perf_counter() - t0
     t1 = time.perf_counter()
     m1 = 256
@@ -148,10 +148,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # trajectory collection: ONE RCCL all-gather of the final states over xGMI (north star)
-        out = torch.empty((world,) + tuple(x_dev.shape), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize(); g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, x_dev)
+        gathered = fb.sharding.all_gather_state(x_dev, n * world)
         torch.cuda.synchronize(); gather_ms = (time.perf_counter() - g0) * 1e3
+        assert gathered.shape == (fb.K["FB_NX"], n * world)
     else:
         gather_ms = None
 

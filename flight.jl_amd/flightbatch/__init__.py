@@ -8,3 +8,4 @@ from ._lib import K, EXPORTED, LIB_PATH, FlightBatchError, lib  # noqa: F401
 from .modeling import (BatchedWorld, Simulation, SimulationTermination, TimeSeries, TrimParameters, TrimState,  # noqa: F401
                        f_init, f_ode, f_periodic, f_step, init, run, step)
 from . import tables  # noqa: F401
+from . import sharding  # noqa: F401

@@ -1,0 +1,42 @@
+"""Multi-GPU layout of the batch: aircraft are independent, so the batch is cut into
+contiguous index ranges, one per rank (one process per GPU), with NO communication while stepping.
+The only exchange is trajectory collection: one all-gather (RCCL over xGMI on GPUs; gloo in CPU tests)
+of the per-rank state panels.  The reference has no counterpart (one aircraft per Simulation,
+lib/FlightCore/src/sim.jl:173-255)."""
+from __future__ import annotations
+
+
+def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous slice [lo, hi) of aircraft owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_state(x_local, n_total: int | None = None):
+    """Gather [nfield, n_local] panels from every rank into [nfield, n_total] (aircraft order = rank order).
+    x_local: torch tensor on the rank's device (CUDA -> RCCL, CPU -> gloo). Ragged shards are padded to the
+    largest shard for the collective and trimmed afterwards."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    nfield, n_local = x_local.shape
+    sizes = torch.tensor([n_local], dtype=torch.int64, device=x_local.device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [int(s.item()) for s in all_sizes]
+    n_max = max(all_sizes)
+    pad = x_local
+    if n_local < n_max:
+        pad = torch.zeros((nfield, n_max), dtype=x_local.dtype, device=x_local.device)
+        pad[:, :n_local] = x_local
+    out = torch.empty((world * nfield, n_max), dtype=x_local.dtype, device=x_local.device)  # concatenation along dim 0
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    out = out.view(world, nfield, n_max)
+    parts = [out[r, :, :all_sizes[r]] for r in range(world)]
+    res = torch.cat(parts, dim=1)
+    if n_total is not None and res.shape[1] != n_total:
+        raise RuntimeError(f"gathered {res.shape[1]} aircraft, expected {n_total}")
+    return res

@@ -9,6 +9,7 @@
 // cite each one); the 1e-6 trajectory figure against a real Julia run remains "parity unpinned".
 #include "fo_c172.hpp"
 #include "../include/flightbatch.h"
+#include "../flight.jl_amd/csrc/tables.h"  // blob layout constants only (to cross-check the product host's table packer)
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -252,6 +253,24 @@ int32_t fo_get_piston_table(int32_t kind, double* out) {
     }
     std::memcpy(out, v->data(), v->size() * sizeof(double));
     return (int32_t)v->size();
+}
+
+// the oracle's own aero tables packed in the csrc/tables.h layout
+int32_t fo_get_aero_blob(double* b) {
+    const AeroTables& t = g_model->aero_tb;
+    auto put = [&](int off, const std::vector<double>& v) { for (size_t i = 0; i < v.size(); i++) b[off + i] = v[i]; };
+    for (int i = 0; i < AT_SIZE; i++) b[i] = 0;
+    put(AT_GE_K, t.C_D_ge.k); put(AT_CD_GE_V, t.C_D_ge.v); put(AT_CL_GE_V, t.C_L_ge.v);
+    put(AT_DF4_K, t.C_D_df.k); put(AT_CD_DF_V, t.C_D_df.v); put(AT_CL_DF_V, t.C_L_df.v); put(AT_CM_DF_V, t.C_m_df.v);
+    put(AT_UNIT3_K, t.C_D_de.k); put(AT_CD_DE_V, t.C_D_de.v); put(AT_CD_BETA_V, t.C_D_beta.v);
+    put(AT_CD_ALPHA_K, t.C_D_alpha_df.k1); put(AT_CD_ALPHA_DF_V, t.C_D_alpha_df.v);
+    put(AT_CY_BETA_K, t.C_Y_beta_df.k1); put(AT_DF2_K, t.C_Y_beta_df.k2); put(AT_CY_BETA_DF_V, t.C_Y_beta_df.v);
+    put(AT_ALPHA2_K, t.C_Y_p.k1); put(AT_CY_P_V, t.C_Y_p.v); put(AT_CY_R_V, t.C_Y_r.v); put(AT_CL_R_V, t.C_l_r.v);
+    put(AT_CL_ALPHA_K, t.C_L_alpha.k1); put(AT_CL_ALPHA_V, t.C_L_alpha.v);
+    const double sc[AS_COUNT] = {t.C_D_zero, t.C_Y_dr, t.C_Y_da, t.C_L_de, t.C_L_q, t.C_L_alpha_dot, t.C_l_da, t.C_l_dr, t.C_l_beta, t.C_l_p,
+                                 t.C_m_zero, t.C_m_de, t.C_m_alpha, t.C_m_q, t.C_m_alpha_dot, t.C_n_dr, t.C_n_da, t.C_n_beta, t.C_n_p, t.C_n_r};
+    for (int i = 0; i < AS_COUNT; i++) b[AT_SCALARS + i] = sc[i];
+    return AT_SIZE;
 }
 
 // ============================ known-answer test helpers ======================================

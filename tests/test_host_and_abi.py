@@ -1,0 +1,122 @@
+"""CPU-side checks (no GPU compute): the C-ABI library loads and exports every symbol include/flightbatch.h
+declares; layout constants agree across header / tables.h / Python host; the host's table builders agree with
+the oracle's independent C++ builders; the host mirror of the Flight.jl operator surface behaves like the
+reference's (names, argument meaning, error behaviour)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_D = C.POINTER(C.c_double)
+
+
+def test_library_exports_every_declared_symbol(fb):
+    header = open(os.path.join(ROOT, "include", "flightbatch.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(fb_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 25
+    lib = C.CDLL(fb.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"libflightbatch.so does not export {name}"
+    assert sorted(fb.EXPORTED) == declared, "Python binding and header disagree on the ABI surface"
+    out = subprocess.run(["nm", "-D", "--defined-only", fb.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), f"{name} is not an exported text symbol"
+
+
+def test_no_cpu_fallback(fb):
+    """The product path must fail loudly without a GPU: fb_create errors (no CPU backend)."""
+    import torch
+    h = C.c_void_p()
+    rc = fb.lib.fb_create(fb.K["FB_MODEL_C172S0"], fb.K["FB_KIN_WA"], fb.K["FB_F64"], 8, -1, C.byref(h))
+    assert rc != 0 and b"no CPU backend" in fb.lib.fb_last_error()
+    if not torch.cuda.is_available():
+        with pytest.raises(fb.FlightBatchError, match="requires a GPU|no HIP device"):
+            fb.BatchedWorld(8)
+    # unsupported models / dtypes are refused, not silently substituted
+    assert fb.lib.fb_create(fb.K["FB_MODEL_ROBOT2D"], 0, 0, 8, 0, C.byref(h)) != 0
+    assert fb.lib.fb_create(0, 0, fb.K["FB_F32"], 8, 0, C.byref(h)) != 0
+
+
+def test_product_does_not_link_or_import_the_oracle(fb):
+    out = subprocess.run(["ldd", fb.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    pkg = os.path.join(ROOT, "flight.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".h", ".hip", ".jl")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "oracle_binding" not in text and "fo_c172" not in text, f
+
+
+def test_layout_constants_consistent(fb):
+    K = fb.K
+    assert K["FB_NX"] == 27 and K["FB_NS"] == 2 and K["FB_NU"] == 16 and K["FB_NY"] == 174 and K["FB_NTP"] == 18 and K["FB_NTS"] == 7
+    assert K["FB_Y_AIR"] == 40 and K["FB_Y_AERO"] == 62 and K["FB_Y_LDG"] == 78 and K["FB_Y_PWP"] == 111 and K["FB_Y_DYN"] == 134
+    th = open(os.path.join(ROOT, "flight.jl_amd", "csrc", "tables.h")).read()
+    for key, val in fb.tables.AT.items():
+        m = re.search(rf"\bAT_{key}\s*=\s*(\d+)", th)
+        assert m and int(m.group(1)) == val, key
+    for key, val in fb.tables.PT.items():
+        m = re.search(rf"\bPT_{key}\s*=\s*(\d+)", th)
+        assert m and int(m.group(1)) == val, key
+
+
+def test_host_tables_match_oracle_builders(fb, oracle):
+    """Two independent implementations (numpy, vectorised, in the product host; scalar C++ in the oracle) of the
+    reference's construction-time tables: FlightPhysics/src/propellers.jl:131-276, piston.jl:70-195, c172.jl:51-199."""
+    tb = fb.tables.default_tables()
+    ref = np.zeros(441 * 6)
+    oracle.lib.fo_get_prop_table(ref.ctypes.data_as(_D))
+    ref = ref.reshape((21, 21, 6), order="F")
+    assert np.max(np.abs(tb["propeller"] - ref)) < 1e-13
+    assert np.max(np.abs(tb["propeller"] - ref) / (np.abs(ref) + 1e-9)) < 1e-12
+    for kind, (key, n) in enumerate([("DELTA_WOT_V", 18), ("MU_WOT_V", 18), ("PISTD_V", 39), ("PIWOT_V", 15), ("PI_RATIO_V", 11),
+                                     ("SFC_RATIO_V", 11), ("SFC_POW_V", 40)]):
+        out = np.zeros(64)
+        assert oracle.lib.fo_get_piston_table(kind, out.ctypes.data_as(_D)) == n
+        a = tb["piston"][fb.tables.PT[key]:fb.tables.PT[key] + n]
+        assert np.max(np.abs(a - out[:n])) < 1e-15, key
+    blob = np.zeros(fb.tables.AT["SIZE"])
+    assert oracle.lib.fo_get_aero_blob(blob.ctypes.data_as(_D)) == fb.tables.AT["SIZE"]
+    assert np.array_equal(tb["aero"], blob)
+    # EGM96 file integrity (the reference asserts the same hash, FlightPhysics/src/geodesy.jl:169)
+    assert tb["egm96"].shape == (721, 1441) and tb["egm96"].dtype == np.float32
+    n = np.array([np.cos(0.3) * np.cos(1.0), np.cos(0.3) * np.sin(1.0), np.sin(0.3)])
+    lat, lon = 0.3, 1.0
+    xi, xj = (lat + np.pi / 2) / (np.pi / 720), lon / (2 * np.pi / 1440)
+    i, j = int(xi), int(xj)
+    wi, wj = xi - i, xj - j
+    A = tb["egm96"].astype(np.float64)
+    host = (1 - wi) * ((1 - wj) * A[i, j] + wj * A[i, j + 1]) + wi * ((1 - wj) * A[i + 1, j] + wj * A[i + 1, j + 1])
+    assert abs(host - oracle.lib.fo_geoid_height(n.ctypes.data_as(_D))) < 1e-9
+
+
+def test_trim_parameter_packing(fb):
+    """C172.TrimParameters defaults (FlightApps/src/c172/c172.jl:806-818) and C172.TrimState (:796-804)."""
+    K = fb.K
+    tp = fb.TrimParameters().pack(3)
+    assert tp.shape == (K["FB_NTP"], 3)
+    assert np.array_equal(tp[:3, 0], [1, 0, 0]) and tp[K["FB_TP_H_E"], 0] == 1050 and tp[K["FB_TP_EAS"], 0] == 50
+    assert tp[K["FB_TP_FUEL_LOAD"], 0] == 0.5 and tp[K["FB_TP_MIXTURE"], 0] == 0.5 and tp[K["FB_TP_FLAPS"], 0] == 0
+    assert np.array_equal(tp[K["FB_TP_PAYLOAD"]:K["FB_TP_PAYLOAD"] + 5, 1], [75, 75, 0, 0, 50])
+    tp2 = fb.TrimParameters(EAS=np.array([40.0, 45.0, 50.0]), h_e=500.0).pack(3)
+    assert np.array_equal(tp2[K["FB_TP_EAS"]], [40, 45, 50]) and (tp2[K["FB_TP_H_E"]] == 500).all()
+    ts = fb.TrimState(2)
+    assert ts.shape == (7, 2) and np.array_equal(ts[:, 0], [0.1, 0.0, 0.75, 0.47, 0.014, -0.0015, 0.02])
+
+
+def test_verbs_mirror_reference_names(fb):
+    """Operator surface of lib/FlightCore/src/modeling.jl:201-254 and sim.jl:183-196,386-414,611-638."""
+    for name in ("f_init", "f_ode", "f_step", "f_periodic", "Simulation", "init", "step", "run", "TimeSeries", "TrimParameters",
+                 "TrimState", "BatchedWorld", "SimulationTermination"):
+        assert hasattr(fb, name)
+    import inspect
+    sig = inspect.signature(fb.Simulation.__init__)
+    for kw in ("dt", "Δt", "t_start", "t_end", "save_on", "saveat"):
+        assert kw in sig.parameters
+    assert sig.parameters["dt"].default == 0.02 and sig.parameters["t_end"].default == 10000.0   # sim.jl:188-191
