@@ -1,0 +1,132 @@
+"""
+    FlightBatch
+
+Julia-side binding of `libflightbatch` (include/flightbatch.h): the drop-in for the hot path of
+`Model(SimpleWorld(Cessna172Sv0()))` — `f_ode!` / `f_step!` / `f_periodic!` / `init!` / `step!` — executed for N
+independent aircraft on one MI355X. It follows the only in-tree FFI precedent of Flight.jl, the plain
+`ccall((:sym, lib), Ret, (ArgTypes...), args...)` pattern of `lib/FlightCore/src/joysticks.jl:45-53`.
+
+NOT EXECUTED in this repository's CI (no Julia toolchain in the build environment); the Python package
+`flightbatch` is the executed mirror of exactly these calls. Array convention of the C ABI: column-major
+`[N x Nfield]`, aircraft index fastest — i.e. a Julia `Matrix{Float64}(undef, N, Nfield)` passes as is.
+
+Usage (what a Flight.jl maintainer would write):
+
+    using Flight, FlightBatch
+    world  = FlightBatch.BatchedWorld(1_048_576)              # ≙ Model(SimpleWorld(Cessna172Sv0())) x N
+    sim    = FlightBatch.BatchedSimulation(world; dt = 0.01)   # ≙ Simulation(world; dt = 0.01)
+    FlightBatch.init!(sim, C172.TrimParameters())               # ≙ init!(sim, C172.TrimParameters())
+    FlightBatch.step!(sim, 10.0, true)                          # ≙ step!(sim, 10.0, true)
+    x = FlightBatch.state(world)                                # N x 27, same component order as world.x
+"""
+module FlightBatch
+
+using Flight.FlightCore.Modeling: ModelDefinition
+import Flight.FlightCore.Modeling: f_init!, f_ode!, f_step!, f_periodic!
+using Flight.FlightApps: C172
+using Flight.FlightPhysics: Propellers, Piston, Geodesy
+
+const lib = get(ENV, "FLIGHTBATCH_LIB", "libflightbatch")
+
+# layout constants of include/flightbatch.h
+const NX, NS, NU, NY, NTP, NTS = 27, 2, 16, 174, 18, 7
+const TABLE_EGM96, TABLE_PROPELLER, TABLE_PISTON, TABLE_AERO = Cint(0), Cint(1), Cint(2), Cint(3)
+
+struct Params   # fb_params
+    dt::Cdouble; periodic_n::Cint; surface::Cint; T_sl::Cdouble; p_sl::Cdouble
+    wind_ned::NTuple{3,Cdouble}; h_terrain::Cdouble
+end
+
+check(rc::Integer) = rc == 0 || error(unsafe_string(ccall((:fb_last_error, lib), Cstring, ())))
+
+"N instances of SimpleWorld(Cessna172Sv0()) resident on one GPU (the batched counterpart of a root Model)."
+mutable struct BatchedWorld <: ModelDefinition
+    handle::Ptr{Cvoid}
+    n::Int
+    function BatchedWorld(n::Integer; device::Integer = 0)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:fb_create, lib), Cint, (Cint, Cint, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}), 0, 0, 0, n, device, h))
+        w = new(h[], n)
+        finalizer(w -> ccall((:fb_destroy, lib), Cint, (Ptr{Cvoid},), w.handle), w)
+        upload_tables!(w)
+        return w
+    end
+end
+
+function set_table!(w::BatchedWorld, kind::Cint, data::Array)
+    dims = Int64[size(data)...]
+    check(ccall((:fb_set_table, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Int64}, Cint), w.handle, kind, data, dims, length(dims)))
+end
+
+"Hand the library the very tables Flight.jl builds at construction time (SURVEY.md Appendix B)."
+function upload_tables!(w::BatchedWorld)
+    # EGM96: the Float32 721 x 1441 grid behind Geodesy.egm96_interp (geodesy.jl:186-198)
+    egm = Matrix{Float32}(undef, 721, 1441)
+    read!(joinpath(dirname(pathof(Geodesy.eval(:(@__MODULE__)))), "data", "ww15mgh_le.bin"), egm)
+    set_table!(w, TABLE_EGM96, egm)
+    # propeller: Lookup(2, Blade()).data, six 21 x 21 x 1 arrays (propellers.jl:235-250) -> [21, 21, 6]
+    lookup = Propellers.Lookup(2, Propellers.Blade())
+    d = lookup.data
+    prop = cat((dropdims(getfield(d, f); dims = 3) for f in (:C_Fx, :C_Mx, :C_Fz_α, :C_Mz_α, :C_P, :η_p))...; dims = 3)
+    set_table!(w, TABLE_PROPELLER, prop)
+    # piston and aero blobs are packed in the csrc/tables.h layout by the helpers below
+    set_table!(w, TABLE_PISTON, pack_piston(Piston.PistonEngineLookup(300 / 2700, 3100 / 2700)))
+    set_table!(w, TABLE_AERO, pack_aero(C172.aero_lookup))
+end
+
+# The two packers read the interpolation objects' knots/coefs and lay them out as csrc/tables.h documents
+# (AT_* / PT_* offsets); flightbatch/tables.py is the executed equivalent and serves as their specification.
+pack_piston(lookup)::Vector{Float64} = error("see flightbatch/tables.py: piston_blob() for the layout to replicate")
+pack_aero(lookup)::Vector{Float64} = error("see flightbatch/tables.py: aero_blob() for the layout to replicate")
+
+# ---- the verbs --------------------------------------------------------------------------------------------
+state(w::BatchedWorld) = (x = Matrix{Float64}(undef, w.n, NX); s = Matrix{Int32}(undef, w.n, NS);
+    check(ccall((:fb_get_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int32}), w.handle, x, s)); x)
+outputs(w::BatchedWorld) = (y = Matrix{Float64}(undef, w.n, NY);
+    check(ccall((:fb_get_outputs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, y)); y)
+
+"f_init!(world, C172.TrimParameters()) — one trim per aircraft, on the device."
+function f_init!(w::BatchedWorld, trim::C172.TrimParameters)
+    tp = Matrix{Float64}(undef, w.n, NTP)
+    tp[:, 1:3] .= trim.Ob.loc[:]'; tp[:, 4] .= Float64(trim.Ob.h); tp[:, 5] .= trim.ψ_nb; tp[:, 6] .= trim.EAS
+    tp[:, 7] .= trim.γ_wb_n; tp[:, 8] .= trim.ψ_wb_dot; tp[:, 9] .= trim.θ_wb_dot; tp[:, 10] .= trim.β_a
+    tp[:, 11] .= Float64(trim.fuel_load); tp[:, 12] .= Float64(trim.mixture); tp[:, 13] .= Float64(trim.flaps)
+    p = trim.payload
+    tp[:, 14:18] .= Float64[p.m_pilot p.m_copilot p.m_lpass p.m_rpass p.m_baggage]
+    ts = repeat(collect(C172.TrimState())', w.n)          # initial guess, c172.jl:796-804
+    ok = Vector{Int32}(undef, w.n); cost = Vector{Float64}(undef, w.n)
+    check(ccall((:fb_trim, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}), w.handle, tp, ts, ok, cost))
+    all(==(1), ok) || @warn("Trimming failed for $(count(!=(1), ok)) aircraft")    # c172.jl:936-938
+    return nothing
+end
+f_ode!(w::BatchedWorld) = (check(ccall((:fb_f_ode, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, C_NULL)); nothing)
+f_step!(w::BatchedWorld) = (check(ccall((:fb_f_step, lib), Cint, (Ptr{Cvoid},), w.handle)); nothing)
+f_periodic!(w::BatchedWorld) = (check(ccall((:fb_f_periodic, lib), Cint, (Ptr{Cvoid},), w.handle)); nothing)
+
+"Simulation(world; dt, Δt) for the batch: fixed-step RK4 + Flight.jl's callback order, fused on the GPU."
+mutable struct BatchedSimulation
+    mdl::BatchedWorld
+    dt::Float64
+    Δt::Float64
+    nstep::Int
+    function BatchedSimulation(mdl::BatchedWorld; dt::Real = 0.02, Δt::Real = dt, steps_per_launch::Integer = 50)
+        p = Ref{Params}()
+        check(ccall((:fb_get_params, lib), Cint, (Ptr{Cvoid}, Ptr{Params}), mdl.handle, p))
+        q = p[]
+        p[] = Params(dt, round(Cint, Δt / dt), q.surface, q.T_sl, q.p_sl, q.wind_ned, q.h_terrain)
+        check(ccall((:fb_set_params, lib), Cint, (Ptr{Cvoid}, Ptr{Params}), mdl.handle, p))
+        check(ccall((:fb_set_steps_per_launch, lib), Cint, (Ptr{Cvoid}, Cint), mdl.handle, steps_per_launch))
+        new(mdl, dt, Δt, 0)
+    end
+end
+init!(sim::BatchedSimulation, args...) = (f_init!(sim.mdl, args...); sim.nstep = 0; nothing)
+function step!(sim::BatchedSimulation, Δt_total::Real = sim.dt, stop_at_tdt::Bool = true)
+    n = round(Int, Δt_total / sim.dt)
+    check(ccall((:fb_step, lib), Cint, (Ptr{Cvoid}, Int64), sim.mdl.handle, n))
+    check(ccall((:fb_sync, lib), Cint, (Ptr{Cvoid},), sim.mdl.handle))
+    sim.nstep += n
+    return nothing
+end
+Base.getproperty(sim::BatchedSimulation, s::Symbol) = s === :t ? getfield(sim, :nstep) * getfield(sim, :dt) : getfield(sim, s)
+
+end # module

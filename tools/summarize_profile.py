@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarises a tools/collect_profile.sh run into gpurun_out/prof_TAG/summary/ (to be copied into profiles/)."""
+import csv, glob, json, os, shutil, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+N, INNER = 1 << 20, 50
+summ = os.path.join(out, "summary"); os.makedirs(summ, exist_ok=True)
+for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(summ, f"{tag}_kernel_stats.csv"))
+ctr = {"k_step": collections.defaultdict(list), "k_f_ode": collections.defaultdict(list)}
+dur = {"k_step": [], "k_f_ode": []}
+for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        for k in ctr:
+            if k + "(" in r["Kernel_Name"] or r["Kernel_Name"].endswith(k):
+                ctr[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+mean = lambda v: sum(v) / len(v) if v else None
+S = {k: {c: mean(v) for c, v in d.items()} for k, d in ctr.items()}
+res = {"n": N, "inner": INNER, "tag": tag, "counters_k_step_mean_per_launch": S["k_step"], "counters_k_f_ode": S["k_f_ode"]}
+# calibration on k_f_ode (known byte counts): reads x 27*8 + u 16*8 + ui 4 + s 8 + status 4; writes y 174*8 + xdot 27*8 + status 4
+known_rd, known_wr = N * (216 + 128 + 4 + 8 + 4), N * (1392 + 216 + 4)
+fo = S["k_f_ode"]
+if fo.get("FETCH_SIZE") and fo.get("WRITE_SIZE"):
+    cal_rd = known_rd / (fo["FETCH_SIZE"] * 1024); cal_wr = known_wr / (fo["WRITE_SIZE"] * 1024)
+    res["calibration"] = {"kernel": "k_f_ode", "known_read_bytes": known_rd, "known_write_bytes": known_wr,
+                          "FETCH_SIZE_KB": fo["FETCH_SIZE"], "WRITE_SIZE_KB": fo["WRITE_SIZE"], "read_factor": cal_rd, "write_factor": cal_wr}
+    ks = S["k_step"]
+    # gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM); the factor measured on
+    # k_f_ode's 8 B/lane pattern is applied when it is within [1, 2.5], otherwise the raw counter x 2 is reported.
+    f_rd = cal_rd if 0.9 <= cal_rd <= 2.5 else 2.0
+    f_wr = cal_wr if 0.8 <= cal_wr <= 1.5 else 1.0
+    res["hbm_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024 * f_rd + ks["WRITE_SIZE"] * 1024 * f_wr
+    res["hbm_read_bytes_per_launch"] = ks["FETCH_SIZE"] * 1024 * f_rd
+    res["hbm_write_bytes_per_launch"] = ks["WRITE_SIZE"] * 1024 * f_wr
+ks = S["k_step"]
+if ks.get("SQ_INSTS_VALU_FMA_F64"):
+    flops = 64 * (ks["SQ_INSTS_VALU_ADD_F64"] + ks["SQ_INSTS_VALU_MUL_F64"] + 2 * ks["SQ_INSTS_VALU_FMA_F64"] + ks["SQ_INSTS_VALU_TRANS_F64"])
+    res["fp64_flops_per_launch"] = flops
+    res["fp64_flops_per_aircraft_step"] = flops / (N * INNER)
+    res["valu_insts_per_aircraft_step"] = ks["SQ_INSTS_VALU"] * 64 / (N * INNER) / 64 * 64 / 64
+res["k_step_mean_ns_under_pmc"] = mean(dur["k_step"])
+json.dump(res, open(os.path.join(summ, f"{tag}_counters.json"), "w"), indent=1)
+print(json.dumps({k: res.get(k) for k in ("hbm_bytes_per_launch", "fp64_flops_per_aircraft_step", "calibration", "k_step_mean_ns_under_pmc")}, indent=1))
