@@ -51,6 +51,26 @@ def lattice(rank: int):
     return EAS, h, psi
 
 
+def usable_cores() -> int:
+    """Cores this process can really use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose
+    128 logical CPUs but grant a 16-core share per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, 16) if n > 64 else n   # no quota visible on a 128-CPU host: stay within the documented 16-core share
+
+
 def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
     """The CPU oracle (a C++ port of the reference path) timed on this box's host cores on a bounded
     sample of the same workload. Reference-like arithmetic: 6 RHS evaluations per step, as
@@ -58,7 +78,7 @@ def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
     orc = Oracle()
-    threads = min(orc.max_threads(), len(os.sched_getaffinity(0)))   # the cores this process may actually use
+    threads = min(orc.max_threads(), usable_cores())   # the cores this process may actually use
     env = orc.default_env()
     m = min(16384, x0.shape[1])
     sel = slice(0, m)

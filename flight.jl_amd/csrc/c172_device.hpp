@@ -85,7 +85,26 @@ constexpr double H_MIN = -1000.0;
 struct Tables {
     const double* lds;   // [aero | piston | propeller] blob in LDS
     const float* egm96;  // 721 x 1441 float32, column-major [lat, lon], global memory
+    const double* rk;    // rk[j] = 1 / (lds[j+1] - lds[j]) over the aero|piston part: reciprocal knot spacings
 };
+constexpr int LDS_RK_DOUBLES = AT_SIZE + PT_SIZE;
+
+// cos and sin of atan2(y, x) / 2 without evaluating the angle: half-angle identities arranged so that the
+// square root is always taken of a number >= 1/2 (no cancellation). Used for the z- and y-rotation quaternions
+// of the local-level frames, where only cos(angle/2), sin(angle/2) are needed (attitude.jl:288-308).
+FBD void half_angle_cs(double y, double x, double& c, double& s) {
+    const double r2 = x * x + y * y;
+    if (!(r2 > 0)) { c = 1.0; s = 0.0; return; }   // atan2(0, 0) = 0
+    const double ir = rsqrt(r2);
+    const double cx = x * ir, sy = y * ir;
+    if (x >= 0) {
+        c = sqrt(0.5 * (1 + cx));
+        s = sy / (2 * c);
+    } else {
+        s = copysign(sqrt(0.5 * (1 - cx)), y);
+        c = sy / (2 * s);
+    }
+}
 
 // EGM96 geoid height at a location given by its n-vector (geodesy.jl:103-106, 186-211).
 // Bilinear on the uniform grid lat ∈ [-π/2, π/2] (721), lon ∈ [0, 2π] (1441), linear extrapolation.
@@ -94,8 +113,8 @@ FBD double geoid_height(const Tables& T, v3 n, double& lat, double& lon) {
     lon = atan2(n.y, n.x);
     double lam = fmod(lon + 2 * PI, 2 * PI);
     lam = lam < 0 ? lam + 2 * PI : lam;
-    const double xi = (lat + PI / 2) / (PI / 720);
-    const double xj = lam / (2 * PI / 1440);
+    const double xi = (lat + PI / 2) * (720 / PI);
+    const double xj = lam * (1440 / (2 * PI));
     const int i = min(max((int)floor(xi), 0), 719);
     const int j = min(max((int)floor(xj), 0), 1439);
     const double wi = xi - i, wj = xj - j;
@@ -157,19 +176,21 @@ FBD double normal_gravity(double nz, double h) {
 // ---------------------------------------------------------------------------------------------
 // table lookups (Interpolations.jl semantics: Gridded(Linear) knot search = searchsortedlast clamped)
 struct loc { int i; double w; };
+// k: knots in LDS; rk: reciprocal spacings 1/(k[j+1]-k[j]) in LDS (computed once per workgroup), so the
+// interpolation weight costs a multiply instead of an fp64 division (~12 VALU instructions each, ~20 per RHS).
 template <int N>
-FBD loc grid_locate(const double* k, double x, bool flat_lo, bool flat_hi) {
+FBD loc grid_locate(const double* k, const double* rk, double x, bool flat_lo, bool flat_hi) {
     x = (flat_lo && x < k[0]) ? k[0] : x;
     x = (flat_hi && x > k[N - 1]) ? k[N - 1] : x;
     int i = 0;
 #pragma unroll
     for (int j = 1; j <= N - 2; j++) i += (k[j] <= x) ? 1 : 0;  // knots ascending: count = index of last knot <= x
-    const double k0 = k[i], k1 = k[i + 1];
-    return {i, (x - k0) / (k1 - k0)};
+    return {i, (x - k[i]) * rk[i]};
 }
+// uniform knots a + j (b-a)/(n-1): a, b, n are literals at every call site, so the reciprocal step folds at compile time
 FBD loc range_locate(double a, double b, int n, double x, bool flat) {
     if (flat) x = fmin(fmax(x, a), b);
-    const double xi = (x - a) / ((b - a) / (n - 1));
+    const double xi = (x - a) * ((n - 1) / (b - a));
     const int i = min(max((int)floor(xi), 0), n - 2);
     return {i, xi - i};
 }
@@ -197,7 +218,7 @@ FBD void isa_data(double h, double T_sl, double p_sl, double& T, double& p, int3
         done = h < hc[i];
         const double Tn = Tb + beta[i] * (hh - hb);
         double pn;
-        if (beta[i] != 0.0) pn = pb * pow(1 + beta[i] / Tb * (hh - hb), -isa::g_std / (beta[i] * isa::R));
+        if (beta[i] != 0.0) pn = pb * exp(-isa::g_std / (beta[i] * isa::R) * log(1 + beta[i] / Tb * (hh - hb)));
         else pn = pb * exp(-isa::g_std / (isa::R * Tb) * (hh - hb));
         T = Tn; p = pn;
         hb = hc[i]; Tb = Tn; pb = pn;
@@ -342,10 +363,10 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     // ψ_nw and n_e straight from q_ew (geodesy.jl:62-69, 140-147)
     const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
     const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
-    const double psi_nw = atan2(-(dq34 + dq12), dq24 - dq13);
     const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+    // q_nw = Rz(ψ_nw), ψ_nw = atan2(-(dq34+dq12), dq24-dq13): only cos, sin of ψ_nw/2 are needed
     double s_nw, c_nw;
-    sincos(0.5 * psi_nw, &s_nw, &c_nw);
+    half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
     const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
     const quat q_nb = qmul(q_nw, q_wb);
     const quat q_eb = qmul(q_ew, q_wb);
@@ -423,6 +444,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     // ===== aerodynamics (c172.jl:307-373, 226-245) =====
     {
         const double* A = T.lds + LDS_AERO;
+        const double* RA = T.rk + LDS_AERO;
         double alpha = 0, beta = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
             alpha = atan2(v_wb_b.z, v_wb_b.x);
@@ -440,15 +462,15 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const double dh_nd = (h_o - env.h_trn) / b;
         const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
 
-        const loc l_ge = grid_locate<13>(A + AT_GE_K, dh_nd, true, true);
-        const loc l_df4 = grid_locate<4>(A + AT_DF4_K, df, true, true);
-        const loc l_df2 = grid_locate<2>(A + AT_DF2_K, df, true, true);
-        const loc l_al26 = grid_locate<26>(A + AT_CD_ALPHA_K, al, true, true);
-        const loc l_al17 = grid_locate<17>(A + AT_CL_ALPHA_K, al, true, true);
-        const loc l_al2 = grid_locate<2>(A + AT_ALPHA2_K, al, true, true);
-        const loc l_be3 = grid_locate<3>(A + AT_CY_BETA_K, be, true, true);
-        const loc l_de = grid_locate<3>(A + AT_UNIT3_K, de, true, true);
-        const loc l_bu = grid_locate<3>(A + AT_UNIT3_K, be, true, true);
+        const loc l_ge = grid_locate<13>(A + AT_GE_K, RA + AT_GE_K, dh_nd, true, true);
+        const loc l_df4 = grid_locate<4>(A + AT_DF4_K, RA + AT_DF4_K, df, true, true);
+        const loc l_df2 = grid_locate<2>(A + AT_DF2_K, RA + AT_DF2_K, df, true, true);
+        const loc l_al26 = grid_locate<26>(A + AT_CD_ALPHA_K, RA + AT_CD_ALPHA_K, al, true, true);
+        const loc l_al17 = grid_locate<17>(A + AT_CL_ALPHA_K, RA + AT_CL_ALPHA_K, al, true, true);
+        const loc l_al2 = grid_locate<2>(A + AT_ALPHA2_K, RA + AT_ALPHA2_K, al, true, true);
+        const loc l_be3 = grid_locate<3>(A + AT_CY_BETA_K, RA + AT_CY_BETA_K, be, true, true);
+        const loc l_de = grid_locate<3>(A + AT_UNIT3_K, RA + AT_UNIT3_K, de, true, true);
+        const loc l_bu = grid_locate<3>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true);
         const loc l_stall = {0, stall ? 1.0 : 0.0};
         const double* S_ = A + AT_SCALARS;
 
@@ -485,19 +507,28 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     // ===== landing gear: left, right, nose (landinggear.jl:524-537, 228-328, 411-476) =====
     aux.wow = 0;
     aux.crash = 0;
+    // High-clearance shortcut (exact for the state): every strut attachment is within 2.3 m of Ob and the geoid
+    // moves by < 1 mm over that distance, so when Ob is more than 10 m above the terrain no wheel can touch it:
+    // wow = false, zero wrench, regulator input 0 (landinggear.jl:255-258, 418-424) without evaluating the three
+    // ECEF->geodetic conversions and geoid gathers. Not taken when the output record (which logs Δh) is requested.
+    const bool high_clearance = !WITH_Y && (h_o - env.h_trn > 10.0);
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         FB_PHASE_FENCE();
-        const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
-        const v3 r_bs_e = qrot(q_eb, r_bs_b);
-        const v3 r_ew0_e = r_eb_e + r_bs_e;  // l_0 = 0
-        v3 loc_Ot;
-        double he_Ow0;
-        geodetic_from_ecef(r_ew0_e, loc_Ot, he_Ow0);
-        if (!(he_Ow0 >= H_MIN)) st |= FB_ST_ALT_RANGE;
-        const double he_Ot = env.h_trn + geoid_height(T, loc_Ot);
-        const double dh = he_Ow0 - he_Ot;
-        const bool wow = dh <= 0;
+        v3 r_bs_e = {0, 0, 0}, loc_Ot = {1, 0, 0};
+        double he_Ot = 0, dh = 0;
+        bool wow = false;
+        if (!high_clearance) {
+            const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
+            r_bs_e = qrot(q_eb, r_bs_b);
+            const v3 r_ew0_e = r_eb_e + r_bs_e;  // l_0 = 0
+            double he_Ow0;
+            geodetic_from_ecef(r_ew0_e, loc_Ot, he_Ow0);
+            if (!(he_Ow0 >= H_MIN)) st |= FB_ST_ALT_RANGE;
+            he_Ot = env.h_trn + geoid_height(T, loc_Ot);
+            dh = he_Ow0 - he_Ot;
+            wow = dh <= 0;
+        }
         const double x0 = x[FB_X_LDG_FRC + 2 * g], x1 = x[FB_X_LDG_FRC + 2 * g + 1];
         double v_xy0 = 0, v_xy1 = 0;
         GroundOut go;
@@ -547,6 +578,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     double mdot;
     {
         const double* PT = T.lds + LDS_PISTON;
+        const double* RPT = T.rk + LDS_PISTON;
         const double* PR = T.lds + LDS_PROP;
         const double w_eng = x[FB_X_ENG_OMEGA];
         const double w_prop = w_eng;  // gear ratio 1
@@ -586,7 +618,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const double mu_ratio_idle = 0.5 + out_idle;
         const double n_eng = w_eng / w_rated;
         // T_ISA(p) = T_std (p/p_std)^(-βR/g), δ = (p/p_std) (T_ISA/T_std)^-1/2 (piston.jl:38-41)
-        const double T_ISA = isa::T_std * pow(p_air / isa::p_std, 6.5e-3 * isa::R / isa::g_std);
+        const double T_ISA = isa::T_std * exp((6.5e-3 * isa::R / isa::g_std) * log(p_air * (1 / isa::p_std)));
         const double delta = (p_air / isa::p_std) / sqrt(T_ISA / isa::T_std);
         const double throttle = in.throttle, mixture = in.mixture;
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
@@ -609,20 +641,20 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
             f_ar = k_f * (f_rich * mixture_pos);
             // compute_π_ISA_pow (piston.jl:457-477)
             const double d_wot = lerp2(PT + PT_DELTA_WOT_V, 2, l_n2, range_locate(0.401, 0.936, 9, mu, false));
-            const double pi_std = lerp2(PT + PT_PISTD_V, 13, grid_locate<13>(PT + PT_PISTD_N_K, n_eng, true, true),
-                                        grid_locate<3>(PT + PT_PISTD_MU_K, mu, true, true));
-            const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, grid_locate<5>(PT + PT_PIWOT_N_K, n_eng, true, true),
-                                        grid_locate<3>(PT + PT_PIWOT_D_K, d_wot, true, false));
+            const double pi_std = lerp2(PT + PT_PISTD_V, 13, grid_locate<13>(PT + PT_PISTD_N_K, RPT + PT_PISTD_N_K, n_eng, true, true),
+                                        grid_locate<3>(PT + PT_PISTD_MU_K, RPT + PT_PISTD_MU_K, mu, true, true));
+            const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, grid_locate<5>(PT + PT_PIWOT_N_K, RPT + PT_PIWOT_N_K, n_eng, true, true),
+                                        grid_locate<3>(PT + PT_PIWOT_D_K, RPT + PT_PIWOT_D_K, d_wot, true, false));
             double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
             pi_isa = fmax(pi_isa, 0.0);
             const double pi_pow = pi_isa * sqrt(T_ISA / T_air);
-            const loc l_f = grid_locate<11>(PT + PT_F_K, f_ar, true, true);
+            const loc l_f = grid_locate<11>(PT + PT_F_K, RPT + PT_F_K, f_ar, true, true);
             const double pi_act = pi_pow * lerp1(PT + PT_PI_RATIO_V, l_f);
             MAP = mu * isa::p_std;
             P_shaft = P_rated * pi_act;
             tau_shaft = (w_eng > 0) ? P_shaft / w_eng : 0.0;
-            SFC = lerp2(PT + PT_SFC_POW_V, 5, grid_locate<5>(PT + PT_SFC_N_K, n_eng, false, false),
-                        grid_locate<8>(PT + PT_SFC_PI_K, pi_act, false, false)) * lerp1(PT + PT_SFC_RATIO_V, l_f);
+            SFC = lerp2(PT + PT_SFC_POW_V, 5, grid_locate<5>(PT + PT_SFC_N_K, RPT + PT_SFC_N_K, n_eng, false, false),
+                        grid_locate<8>(PT + PT_SFC_PI_K, RPT + PT_SFC_PI_K, pi_act, false, false)) * lerp1(PT + PT_SFC_RATIO_V, l_f);
             mdot = SFC * P_shaft;
         }
         const double tau_load = tau_p.x;  // gear_ratio * τ_prop
@@ -684,10 +716,10 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         // q_el = ltf(Oc) = Rz(λ) ∘ Ry(-(ϕ + π/2)) (geodesy.jl:132-135), q_cl = q_eb' ∘ q_el, g_c = q_cl(0,0,g).
         // The composition order must be the reference's: at RK stages q_eb is not exactly unit, and
         // v + 2 q_im x (q_re v + q_im x v) with a non-unit q does not commute with re-association.
-        const double lat_c = atan2(n_c.z, sqrt(n_c.x * n_c.x + n_c.y * n_c.y)), lon_c = atan2(n_c.y, n_c.x);
+        // λ = atan2(n_y, n_x); θ = -(ϕ + π/2) = atan2(-p, -n_z) with p = |(n_x, n_y)|: half-angle forms, no atan2/sincos
         double sl, cl, sp, cp;
-        sincos(0.5 * lon_c, &sl, &cl);
-        sincos(0.5 * (-(lat_c + 0.5 * PI)), &sp, &cp);
+        half_angle_cs(n_c.y, n_c.x, cl, sl);
+        half_angle_cs(-sqrt(n_c.x * n_c.x + n_c.y * n_c.y), -n_c.z, cp, sp);
         const quat q_el = {cl * cp, -(sl * sp), cl * sp, sl * cp};
         const quat q_cl = qmul(qconj(q_eb), q_el);
         const v3 g_c_c = qrot(q_cl, v3{0.0, 0.0, g});

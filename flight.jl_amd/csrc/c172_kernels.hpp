@@ -117,8 +117,11 @@ struct KArgs {
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
 
-FBD void stage_tables(double* lds, const double* tables) {
+FBD void stage_tables(double* lds, double* rk, const double* tables) {
     for (int k = threadIdx.x; k < LDS_TABLE_DOUBLES; k += blockDim.x) lds[k] = tables[k];
+    __syncthreads();
+    // reciprocal knot spacings for every position of the aero|piston blob (only knot positions are ever read)
+    for (int k = threadIdx.x; k < LDS_RK_DOUBLES; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
     __syncthreads();
 }
 FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
@@ -130,10 +133,11 @@ FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
 // f_ode!(world): xdot (optional) and the output record y
 __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y) {
     __shared__ double lds[LDS_TABLE_DOUBLES];
-    stage_tables(lds, a.tables);
+    __shared__ double rk[LDS_RK_DOUBLES];
+    stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96};
+    const Tables T = {lds, a.egm96, rk};
     double x[FB_NX], xd[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -152,10 +156,11 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
 // function of (x,u,s), so it is recomputed here from the current x.
 __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     __shared__ double lds[LDS_TABLE_DOUBLES];
-    stage_tables(lds, a.tables);
+    __shared__ double rk[LDS_RK_DOUBLES];
+    stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96};
+    const Tables T = {lds, a.egm96, rk};
     double x[FB_NX], xd[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -186,9 +191,10 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 // (OrdinaryDiffEq writes it as dt/6 (2 (k2 + k3) + (k1 + k4)); same value up to the last bit).
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     __shared__ double lds[LDS_TABLE_DOUBLES];
+    __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[FB_NX * STEP_BLOCK];   // x_n
     __shared__ double acc_l[FB_NX * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
-    stage_tables(lds, a.tables);
+    stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     int32_t st = a.status[i];
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         // (~150 knots/values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
-        const Tables T = {lds + lds_off, a.egm96};
+        const Tables T = {lds + lds_off, a.egm96, rk + lds_off};
         // same for the per-lane inputs: keep the 11 raw values, not the dozens of products derived from them
         Inputs inl = in;
         asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
@@ -349,10 +355,11 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
 // branch-light solver that maps onto one lane per aircraft.
 __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out) {
     __shared__ double lds[LDS_TABLE_DOUBLES];
-    stage_tables(lds, a.tables);
+    __shared__ double rk[LDS_RK_DOUBLES];
+    stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96};
+    const Tables T = {lds, a.egm96, rk};
     const int64_t n = a.n;
     TrimP p;
     p.n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
