@@ -82,10 +82,15 @@ constexpr double k_g = b * g_b / (a * g_a) - 1;
 }  // namespace wgs
 constexpr double H_MIN = -1000.0;
 
+// LDS pointers carry their address space: a generic `double*` into LDS compiles to flat_load/flat_store, whose
+// LDS aperture only reaches the first 64 KB of a workgroup's allocation on gfx950 (measured: panels above that
+// read back garbage through generic pointers) and which is slower than ds_read/ds_write anyway.
+typedef __attribute__((address_space(3))) const double* lds_cptr;
+typedef __attribute__((address_space(3))) double* lds_ptr;
 struct Tables {
-    const double* lds;   // [aero | piston | propeller] blob in LDS
+    lds_cptr lds;        // [aero | piston | propeller] blob in LDS
     const float* egm96;  // 721 x 1441 float32, column-major [lat, lon], global memory
-    const double* rk;    // rk[j] = 1 / (lds[j+1] - lds[j]) over the aero|piston part: reciprocal knot spacings
+    lds_cptr rk;         // rk[j] = 1 / (lds[j+1] - lds[j]) over the aero|piston part: reciprocal knot spacings
 };
 constexpr int LDS_RK_DOUBLES = AT_SIZE + PT_SIZE;
 
@@ -179,7 +184,7 @@ struct loc { int i; double w; };
 // k: knots in LDS; rk: reciprocal spacings 1/(k[j+1]-k[j]) in LDS (computed once per workgroup), so the
 // interpolation weight costs a multiply instead of an fp64 division (~12 VALU instructions each, ~20 per RHS).
 template <int N>
-FBD loc grid_locate(const double* k, const double* rk, double x, bool flat_lo, bool flat_hi) {
+FBD loc grid_locate(lds_cptr k, lds_cptr rk, double x, bool flat_lo, bool flat_hi) {
     x = (flat_lo && x < k[0]) ? k[0] : x;
     x = (flat_hi && x > k[N - 1]) ? k[N - 1] : x;
     int i = 0;
@@ -194,9 +199,9 @@ FBD loc range_locate(double a, double b, int n, double x, bool flat) {
     const int i = min(max((int)floor(xi), 0), n - 2);
     return {i, xi - i};
 }
-FBD double lerp1(const double* v, loc l) { return (1 - l.w) * v[l.i] + l.w * v[l.i + 1]; }
-FBD double lerp2(const double* v, int n1, loc l1, loc l2) {
-    const double* p = v + l1.i + n1 * l2.i;
+FBD double lerp1(lds_cptr v, loc l) { return (1 - l.w) * v[l.i] + l.w * v[l.i + 1]; }
+FBD double lerp2(lds_cptr v, int n1, loc l1, loc l2) {
+    lds_cptr p = v + l1.i + n1 * l2.i;
     return (1 - l1.w) * ((1 - l2.w) * p[0] + l2.w * p[n1]) + l1.w * ((1 - l2.w) * p[1] + l2.w * p[n1 + 1]);
 }
 
@@ -279,7 +284,38 @@ struct Inputs {
     int ui;                    // FB_UI_* bits
     const double* u_glob;      // &u[0*n + i] for ground-only inputs; may be null (then they read as 0)
     int64_t n;
+    FBD double get_de() const { return de; }
+    FBD double get_da() const { return da; }
+    FBD double get_dr() const { return dr; }
+    FBD double get_df() const { return df; }
+    FBD double get_throttle() const { return throttle; }
+    FBD double get_mixture() const { return mixture; }
+    FBD double get_m_pld(int k) const { return m_pld[k]; }
 };
+// The same eleven values parked in an LDS panel [11][STRIDE] (row = quantity, column = lane) and read at the
+// point of use: the stepping kernel cannot afford 22 VGPRs for values that are touched once per RHS.
+template <int STRIDE>
+struct InputsLds {
+    lds_cptr p;                // &panel[lane]
+    int ui;
+    const double* u_glob;
+    int64_t n;
+    FBD double get_de() const { return p[0 * STRIDE]; }
+    FBD double get_da() const { return p[1 * STRIDE]; }
+    FBD double get_dr() const { return p[2 * STRIDE]; }
+    FBD double get_df() const { return p[3 * STRIDE]; }
+    FBD double get_throttle() const { return p[4 * STRIDE]; }
+    FBD double get_mixture() const { return p[5 * STRIDE]; }
+    FBD double get_m_pld(int k) const { return p[(6 + k) * STRIDE]; }
+    FBD void store(lds_ptr q, const Inputs& in) {
+        q[0 * STRIDE] = in.de; q[1 * STRIDE] = in.da; q[2 * STRIDE] = in.dr; q[3 * STRIDE] = in.df;
+        q[4 * STRIDE] = in.throttle; q[5 * STRIDE] = in.mixture;
+#pragma unroll
+        for (int k = 0; k < 5; k++) q[(6 + k) * STRIDE] = in.m_pld[k];
+        p = q; ui = in.ui; u_glob = in.u_glob; n = in.n;
+    }
+};
+constexpr int INPUT_PANEL_ROWS = 11;
 FBD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 // mechanical actuation + Ranged saturation + linear_scaling, from the raw FB_U_* inputs
 FBD void make_inputs(Inputs& in, const double* u, int64_t stride, int ui) {
@@ -343,8 +379,8 @@ __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& 
 // Every derivative component is handed to `emit(index, value)` the moment it is known, so that the
 // caller can consume it at once (the stepping kernel folds it into the RK stage sums in LDS) instead of
 // keeping a 27-double array alive across the whole evaluation.
-template <bool WITH_Y, class Emit>
-FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs& in, const Env& env, const Tables& T,
+template <bool WITH_Y, class Emit, class In>
+FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in, const Env& env, const Tables& T,
                 Emit&& emit, StepAux& aux, double* Y, int64_t n) {
     using namespace c172;
     int32_t st = 0;
@@ -443,8 +479,8 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     FB_PHASE_FENCE();
     // ===== aerodynamics (c172.jl:307-373, 226-245) =====
     {
-        const double* A = T.lds + LDS_AERO;
-        const double* RA = T.rk + LDS_AERO;
+        lds_cptr A = T.lds + LDS_AERO;
+        lds_cptr RA = T.rk + LDS_AERO;
         double alpha = 0, beta = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
             alpha = atan2(v_wb_b.z, v_wb_b.x);
@@ -458,7 +494,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const double i2V = 1 / (2 * V);
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
         const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
-        const double de = in.de, da = in.da, dr = in.dr, df = in.df;
+        const double de = in.get_de(), da = in.get_da(), dr = in.get_dr(), df = in.get_df();
         const double dh_nd = (h_o - env.h_trn) / b;
         const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
 
@@ -472,7 +508,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const loc l_de = grid_locate<3>(A + AT_UNIT3_K, RA + AT_UNIT3_K, de, true, true);
         const loc l_bu = grid_locate<3>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true);
         const loc l_stall = {0, stall ? 1.0 : 0.0};
-        const double* S_ = A + AT_SCALARS;
+        lds_cptr S_ = A + AT_SCALARS;
 
         const double C_D = S_[AS_CD_ZERO] + lerp1(A + AT_CD_GE_V, l_ge) * (lerp2(A + AT_CD_ALPHA_DF_V, 26, l_al26, l_df4) + lerp1(A + AT_CD_DF_V, l_df4)) +
                            lerp1(A + AT_CD_DE_V, l_de) + lerp1(A + AT_CD_BETA_V, l_bu);
@@ -577,9 +613,9 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
     v3 h_rot;
     double mdot;
     {
-        const double* PT = T.lds + LDS_PISTON;
-        const double* RPT = T.rk + LDS_PISTON;
-        const double* PR = T.lds + LDS_PROP;
+        lds_cptr PT = T.lds + LDS_PISTON;
+        lds_cptr RPT = T.rk + LDS_PISTON;
+        lds_cptr PR = T.lds + LDS_PROP;
         const double w_eng = x[FB_X_ENG_OMEGA];
         const double w_prop = w_eng;  // gear ratio 1
         const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
@@ -589,10 +625,10 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         const double Mt = fabs(w_prop) * (prop_d / 2) / a_snd;
         const loc lj = range_locate(0.0, 1.5, PR_NJ, J_adv, true);
         const loc lm = range_locate(0.0, 1.5, PR_NM, Mt, true);
-        const double* c00 = PR + (lj.i + PR_NJ * lm.i) * PR_NC;
-        const double* c10 = c00 + PR_NC;
-        const double* c01 = c00 + PR_NJ * PR_NC;
-        const double* c11 = c01 + PR_NC;
+        lds_cptr c00 = PR + (lj.i + PR_NJ * lm.i) * PR_NC;
+        lds_cptr c10 = c00 + PR_NC;
+        lds_cptr c01 = c00 + PR_NJ * PR_NC;
+        lds_cptr c11 = c01 + PR_NC;
         const double w00 = (1 - lj.w) * (1 - lm.w), w01 = (1 - lj.w) * lm.w, w10 = lj.w * (1 - lm.w), w11 = lj.w * lm.w;
         auto coef = [&](int cidx) { return (w00 * c00[cidx] + w01 * c01[cidx]) + (w10 * c10[cidx] + w11 * c11[cidx]); };
         const double C_Fx = coef(0), C_Mx = coef(1), C_Fz_a = coef(2), C_Mz_a = coef(3);
@@ -620,43 +656,40 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         // T_ISA(p) = T_std (p/p_std)^(-βR/g), δ = (p/p_std) (T_ISA/T_std)^-1/2 (piston.jl:38-41)
         const double T_ISA = isa::T_std * exp((6.5e-3 * isa::R / isa::g_std) * log(p_air * (1 / isa::p_std)));
         const double delta = (p_air / isa::p_std) / sqrt(T_ISA / isa::T_std);
-        const double throttle = in.throttle, mixture = in.mixture;
+        const double throttle = in.get_throttle(), mixture = in.get_mixture();
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
         const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
         const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
         const double k_f = 1 / sqrt(rho / isa::rho_std);
-        double mixture_pos;
-        if (in.ui & FB_UI_MIXTURE_AUTO) mixture_pos = (f_lean + mixture * (f_rich - f_lean)) / (k_f * f_rich);
-        else mixture_pos = 0.5 * (mixture + 1);
-        double MAP, f_ar = 0, tau_shaft, P_shaft = 0, SFC = 0;
-        mdot = 0;
-        if (eng_state == 0) {
-            MAP = p_air;
-            tau_shaft = out_frc * (0.01 * P_rated / w_rated);
-        } else if (eng_state == 1) {
-            MAP = mu * isa::p_std;
-            tau_shaft = tau_start;
-            P_shaft = tau_shaft * w_eng;
-        } else {
-            f_ar = k_f * (f_rich * mixture_pos);
-            // compute_π_ISA_pow (piston.jl:457-477)
-            const double d_wot = lerp2(PT + PT_DELTA_WOT_V, 2, l_n2, range_locate(0.401, 0.936, 9, mu, false));
-            const double pi_std = lerp2(PT + PT_PISTD_V, 13, grid_locate<13>(PT + PT_PISTD_N_K, RPT + PT_PISTD_N_K, n_eng, true, true),
-                                        grid_locate<3>(PT + PT_PISTD_MU_K, RPT + PT_PISTD_MU_K, mu, true, true));
-            const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, grid_locate<5>(PT + PT_PIWOT_N_K, RPT + PT_PIWOT_N_K, n_eng, true, true),
-                                        grid_locate<3>(PT + PT_PIWOT_D_K, RPT + PT_PIWOT_D_K, d_wot, true, false));
-            double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
-            pi_isa = fmax(pi_isa, 0.0);
-            const double pi_pow = pi_isa * sqrt(T_ISA / T_air);
-            const loc l_f = grid_locate<11>(PT + PT_F_K, RPT + PT_F_K, f_ar, true, true);
-            const double pi_act = pi_pow * lerp1(PT + PT_PI_RATIO_V, l_f);
-            MAP = mu * isa::p_std;
-            P_shaft = P_rated * pi_act;
-            tau_shaft = (w_eng > 0) ? P_shaft / w_eng : 0.0;
-            SFC = lerp2(PT + PT_SFC_POW_V, 5, grid_locate<5>(PT + PT_SFC_N_K, RPT + PT_SFC_N_K, n_eng, false, false),
-                        grid_locate<8>(PT + PT_SFC_PI_K, RPT + PT_SFC_PI_K, pi_act, false, false)) * lerp1(PT + PT_SFC_RATIO_V, l_f);
-            mdot = SFC * P_shaft;
-        }
+        // Branch-free on purpose: the running-engine chain (five dependent table lookups) is evaluated for every
+        // lane and the off / starting cases are selected at the end, so that the whole power-plant phase is one
+        // basic block the scheduler can interleave (at one wave per SIMD, LDS latency is hidden only by ILP).
+        // Every lookup clamps or extrapolates its index, so evaluating it for a stopped engine is harmless.
+        const double mixture_pos = (in.ui & FB_UI_MIXTURE_AUTO) ? (f_lean + mixture * (f_rich - f_lean)) / (k_f * f_rich) : 0.5 * (mixture + 1);
+        const double f_run = k_f * (f_rich * mixture_pos);
+        // compute_π_ISA_pow (piston.jl:457-477)
+        const loc l_n13 = grid_locate<13>(PT + PT_PISTD_N_K, RPT + PT_PISTD_N_K, n_eng, true, true);
+        const loc l_n5w = grid_locate<5>(PT + PT_PIWOT_N_K, RPT + PT_PIWOT_N_K, n_eng, true, true);
+        const loc l_n5s = grid_locate<5>(PT + PT_SFC_N_K, RPT + PT_SFC_N_K, n_eng, false, false);
+        const loc l_f = grid_locate<11>(PT + PT_F_K, RPT + PT_F_K, f_run, true, true);
+        const double pi_ratio = lerp1(PT + PT_PI_RATIO_V, l_f), sfc_ratio = lerp1(PT + PT_SFC_RATIO_V, l_f);
+        const double d_wot = lerp2(PT + PT_DELTA_WOT_V, 2, l_n2, range_locate(0.401, 0.936, 9, mu, false));
+        const double pi_std = lerp2(PT + PT_PISTD_V, 13, l_n13, grid_locate<3>(PT + PT_PISTD_MU_K, RPT + PT_PISTD_MU_K, mu, true, true));
+        const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, l_n5w, grid_locate<3>(PT + PT_PIWOT_D_K, RPT + PT_PIWOT_D_K, d_wot, true, false));
+        double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
+        pi_isa = fmax(pi_isa, 0.0);
+        const double pi_pow = pi_isa * sqrt(T_ISA / T_air);
+        const double pi_act = pi_pow * pi_ratio;
+        const double P_run = P_rated * pi_act;
+        const double tau_run = (w_eng > 0) ? P_run / w_eng : 0.0;
+        const double SFC_run = lerp2(PT + PT_SFC_POW_V, 5, l_n5s, grid_locate<8>(PT + PT_SFC_PI_K, RPT + PT_SFC_PI_K, pi_act, false, false)) * sfc_ratio;
+        const bool eng_off = eng_state == 0, eng_starting = eng_state == 1, eng_running = !(eng_off || eng_starting);
+        const double MAP = eng_off ? p_air : mu * isa::p_std;
+        const double f_ar = eng_running ? f_run : 0.0;
+        const double tau_shaft = eng_off ? out_frc * (0.01 * P_rated / w_rated) : (eng_starting ? tau_start : tau_run);
+        const double P_shaft = eng_off ? 0.0 : (eng_starting ? tau_start * w_eng : P_run);
+        const double SFC = eng_running ? SFC_run : 0.0;
+        mdot = eng_running ? SFC_run * P_run : 0.0;
         const double tau_load = tau_p.x;  // gear_ratio * τ_prop
         emit(FB_X_ENG_OMEGA, (tau_shaft + tau_load) / (J_eng + prop_Jxx));
         if (WITH_Y) {
@@ -688,7 +721,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
         add_point(m_half, fuel_r[0], M, Mr, J);
         add_point(m_half, fuel_r[1], M, Mr, J);
 #pragma unroll
-        for (int k = 0; k < 5; k++) add_point(in.m_pld[k], pld_r[k], M, Mr, J);
+        for (int k = 0; k < 5; k++) add_point(in.get_m_pld(k), pld_r[k], M, Mr, J);
     }
     const double iM = 1 / M;
     const v3 r_bc = iM * Mr;  // CoM position in body frame
@@ -755,7 +788,8 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const Inputs
 // f_step!(world): kinematics renormalisation, stall hysteresis, contact-regulator reset, crash checks,
 // engine state machine (aircraftbase.jl:172-181; kinematics.jl:226-229,114-118; c172.jl:375-384,715-724;
 // landinggear.jl:331-347,479-483; piston.jl:428-453). Returns true when x or s changed.
-FBD bool f_step(double (&x)[FB_NX], int& stall, int& eng_state, const Inputs& in, const StepAux& aux, int32_t& st) {
+template <class In>
+FBD bool f_step(double (&x)[FB_NX], int& stall, int& eng_state, const In& in, const StepAux& aux, int32_t& st) {
     bool mod = false;
     {
         const double n2 = x[FB_X_Q_WB] * x[FB_X_Q_WB] + x[FB_X_Q_WB + 1] * x[FB_X_Q_WB + 1] + x[FB_X_Q_WB + 2] * x[FB_X_Q_WB + 2] + x[FB_X_Q_WB + 3] * x[FB_X_Q_WB + 3];

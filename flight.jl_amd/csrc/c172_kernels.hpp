@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96, rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
     double x[FB_NX], xd[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96, rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
     double x[FB_NX], xd[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[FB_NX * STEP_BLOCK];   // x_n
     __shared__ double acc_l[FB_NX * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
+    __shared__ double in_l[INPUT_PANEL_ROWS * STEP_BLOCK];  // per-lane inputs, read at the point of use
     stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
@@ -203,8 +204,12 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     double xt[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
-    Inputs in;
-    load_inputs(a, i, in);
+    InputsLds<STEP_BLOCK> in;
+    {
+        Inputs in_r;
+        load_inputs(a, i, in_r);
+        in.store((lds_ptr)in_l + t, in_r);
+    }
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     int stage = 0, step = 0;
@@ -217,11 +222,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         // (~150 knots/values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
-        const Tables T = {lds + lds_off, a.egm96, rk + lds_off};
-        // same for the per-lane inputs: keep the 11 raw values, not the dozens of products derived from them
-        Inputs inl = in;
-        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
-        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
+        // the per-lane inputs are read from their LDS panel at the point of use (same opaque offset: no hoisting)
+        InputsLds<STEP_BLOCK> inl = in;
+        inl.p = in.p + lds_off;
         const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
         auto emit = [&](int j, double kj) {
             const int idx = j * STEP_BLOCK + t;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {lds, a.egm96, rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
     const int64_t n = a.n;
     TrimP p;
     p.n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
