@@ -176,6 +176,8 @@ def main():
         gather_ms = None
 
     status_bad = int((w.status != 0).sum())
+    if status_bad > n // 1000:
+        raise SystemExit(f"INVALID RUN: {status_bad} of {n} aircraft terminated (status != 0) — they do no work; refusing to report a throughput")
     total_units = float(n) * world * args.inner * args.steps
     value = total_units / elapsed
 

@@ -194,22 +194,29 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[FB_NX * STEP_BLOCK];   // x_n
     __shared__ double acc_l[FB_NX * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
+#ifndef FB_INPUTS_IN_REGS
     __shared__ double in_l[INPUT_PANEL_ROWS * STEP_BLOCK];  // per-lane inputs, read at the point of use
+#endif
     stage_tables(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    int32_t st = a.status[i];
-    if (st != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
+    if (a.status[i] != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
+    bool dead = false;             // a status bit was raised during this launch (bits go straight to memory: rare)
     const int t = threadIdx.x;
     double xt[FB_NX];
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
+#ifdef FB_INPUTS_IN_REGS
+    Inputs in;
+    load_inputs(a, i, in);
+#else
     InputsLds<STEP_BLOCK> in;
     {
         Inputs in_r;
         load_inputs(a, i, in_r);
         in.store((lds_ptr)in_l + t, in_r);
     }
+#endif
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     int stage = 0, step = 0;
@@ -224,8 +231,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         asm volatile("" : "+s"(lds_off));
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
         // the per-lane inputs are read from their LDS panel at the point of use (same opaque offset: no hoisting)
+#ifdef FB_INPUTS_IN_REGS
+        Inputs inl = in;
+        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
+        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+#else
         InputsLds<STEP_BLOCK> inl = in;
         inl.p = in.p + lds_off;
+#endif
         const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
         auto emit = [&](int j, double kj) {
             const int idx = j * STEP_BLOCK + t;
@@ -244,18 +257,20 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         };
         // NB: a stage-3 emit overwrites x_n in LDS component by component; the RHS itself reads its state
         // from the registers xt[], never from the panel, so this is safe.
-        st |= rhs<false>(xt, stall, eng, inl, a.env, T, emit, aux, nullptr, 0);
+        int32_t bits = rhs<false>(xt, stall, eng, inl, a.env, T, emit, aux, nullptr, 0);
         if (stage == 0 && pending_cb) {  // this evaluation sits at x_{n+1} (= xt): run the discrete callbacks on it
             pending_cb = false;
-            const bool mod = f_step(xt, stall, eng, in, aux, st);
+            const bool mod = f_step(xt, stall, eng, in, aux, bits);
             step++;
+            if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
             if (mod) {
 #pragma unroll
                 for (int j = 0; j < FB_NX; j++) xs_l[j * STEP_BLOCK + t] = xt[j];
             }
-            if (st != 0 || step == nsteps) break;
+            if (dead || step == nsteps) break;
             if (mod) continue;  // re-evaluate k1 on the modified state (this pass's stage-0 emits are simply redone)
         }
+        if (bits != 0) { a.status[i] |= bits; dead = true; }
 #pragma unroll
         for (int j = 0; j < FB_NX; j++) xt[j] = xn[j];
         stage = (stage + 1) & 3;
@@ -264,12 +279,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xt[j]);
-    if (bad) st |= FB_ST_NAN;
+    if (bad) a.status[i] |= FB_ST_NAN;
 #pragma unroll
     for (int j = 0; j < FB_NX; j++) a.x[(int64_t)j * a.n + i] = xt[j];
     a.s[i] = stall;
     a.s[a.n + i] = eng;
-    a.status[i] = st;
 }
 
 // ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------

@@ -236,3 +236,20 @@ def test_ground_contact_matches_oracle(fb, oracle):
     print("ground roll-out max scaled error", e2.max())
     assert e2.max() < 1e-6
     w.close()
+
+
+def test_status_stays_clean_from_trim_to_step(fb):
+    """Regression: stepping straight from the device trim (no host set_state in between) must leave every status word 0
+    and every aircraft advancing (an earlier build returned garbage status words here, freezing the whole batch)."""
+    n = 65536
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, fb.TrimParameters(EAS=np.linspace(40, 48, n), ψ_nb=np.linspace(-3, 3, n)))
+    assert w.trim_success.all() and (w.status == 0).all()
+    x0 = w.x
+    for k in (1, 50):
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=k)
+        fb.step(sim, 0.5); w.sync()
+        assert (w.status == 0).all()
+    x1 = w.x
+    assert np.all(x1[8] < x0[8]), "fuel must have burnt on every aircraft: nobody is frozen"
+    w.close()
