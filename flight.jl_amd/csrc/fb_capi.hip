@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "c172_kernels.hpp"
+#include "robot2d_kernels.hpp"
 
 using namespace fbd;
 
@@ -50,6 +51,7 @@ struct fb_handle_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
     int64_t launches = 0;
+    struct R2State* r2 = nullptr;  // Robot2D handles only
 };
 
 static KArgs make_args(fb_handle h) {
@@ -71,6 +73,8 @@ static int32_t check_ready(fb_handle h) {
 }
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
+#include "fb_robot2d.inc"
+
 extern "C" {
 
 const char* fb_last_error(void) { return g_err.c_str(); }
@@ -79,9 +83,10 @@ const char* fb_version(void) { return "flightbatch 0.1 (gfx950)"; }
 int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out) {
     if (!out) return fail("out is null");
     *out = nullptr;
-    if (model_id != FB_MODEL_C172S0) return fail("model not implemented (only FB_MODEL_C172S0)");
-    if (kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
-    if (dtype != FB_F64) return fail("dtype not implemented (only FB_F64)");
+    if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_ROBOT2D) return fail("model not implemented (FB_MODEL_C172S0, FB_MODEL_ROBOT2D)");
+    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
+    if (model_id == FB_MODEL_C172S0 && dtype != FB_F64) return fail("dtype not implemented for Cessna172Sv0 (only FB_F64)");
+    if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
     if (n <= 0) return fail("n must be positive");
     if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");
     int ndev = 0;
@@ -96,6 +101,13 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     h->params.h_terrain = 0.0;
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    if (model_id == FB_MODEL_ROBOT2D) {
+        if (int32_t rc = r2_create(h, dtype)) { return rc; }
+        *out = h;
+        return 0;
+    }
     HIPCHK(hipMalloc(&h->x_own, sizeof(double) * FB_NX * n));
     HIPCHK(hipMalloc(&h->s_own, sizeof(int32_t) * FB_NS * n));
     HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
@@ -113,8 +125,6 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
         HIPCHK(hipMemcpyAsync(h->ui, ui.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    HIPCHK(hipEventCreate(&h->ev0));
-    HIPCHK(hipEventCreate(&h->ev1));
     *out = h;
     return 0;
 }
@@ -122,6 +132,7 @@ int32_t fb_destroy(fb_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
@@ -130,6 +141,15 @@ int32_t fb_destroy(fb_handle h) {
     return 0;
 }
 int64_t fb_size(fb_handle h) { return h ? h->n : -1; }
+int32_t fb_dims(fb_handle h, int32_t* nx, int32_t* ns, int32_t* nu, int32_t* ny) {
+    if (!h) return fail("null handle");
+    const bool r2 = h->model == FB_MODEL_ROBOT2D;
+    if (nx) *nx = r2 ? FB_R2_NX : FB_NX;
+    if (ns) *ns = r2 ? 0 : FB_NS;
+    if (nu) *nu = r2 ? FB_R2_NU : FB_NU;
+    if (ny) *ny = r2 ? FB_R2_NY : FB_NY;
+    return 0;
+}
 
 int32_t fb_set_stream(fb_handle h, void* hip_stream) {
     if (!h) return fail("null handle");
@@ -140,6 +160,7 @@ int32_t fb_set_stream(fb_handle h, void* hip_stream) {
 }
 int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev) {
     if (!h) return fail("null handle");
+    if (h->model == FB_MODEL_ROBOT2D) return fail("fb_attach_state: not supported for Robot2D");
     if ((x_dev == nullptr) != (s_dev == nullptr)) return fail("x_dev and s_dev must both be given or both be NULL");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -153,6 +174,13 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
     HIPCHK(hipSetDevice(h->device));
     int64_t count = 1;
     for (int k = 0; k < ndims; k++) count *= dims[k];
+    if ((kind == FB_TABLE_ROBOT2D) != (h->model == FB_MODEL_ROBOT2D)) return fail("table kind does not belong to this model");
+    if (kind == FB_TABLE_ROBOT2D) {
+        if (count != FB_R2_TABLE_SIZE) return fail("Robot2D blob must hold FB_R2_TABLE_SIZE doubles");
+        std::memcpy(h->r2->table, data, sizeof(double) * FB_R2_TABLE_SIZE);
+        h->r2->have_table = true;
+        return 0;
+    }
     switch (kind) {
         case FB_TABLE_EGM96:
             if (ndims != 2 || dims[0] != 721 || dims[1] != 1441) return fail("EGM96 table must be float32 [721 x 1441]");
@@ -196,6 +224,14 @@ int32_t fb_get_params(fb_handle h, fb_params* p) {
 int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
+    if (h->model == FB_MODEL_ROBOT2D) {
+        if (x) { if (int32_t rc = r2_upload(h, h->r2, h->r2->r, x, FB_R2_NX)) return rc; }
+        HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->r2->steps_done = 0;
+        h->t = 0.0;
+        return 0;
+    }
     if (x) HIPCHK(hipMemcpyAsync(h->x, x, sizeof(double) * FB_NX * h->n, hipMemcpyHostToDevice, h->stream));
     if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
@@ -206,6 +242,7 @@ int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
 int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
+    if (h->model == FB_MODEL_ROBOT2D) return x ? r2_download(h, h->r2, x, h->r2->r, FB_R2_NX) : 0;
     if (x) HIPCHK(hipMemcpyAsync(x, h->x, sizeof(double) * FB_NX * h->n, hipMemcpyDeviceToHost, h->stream));
     if (s) HIPCHK(hipMemcpyAsync(s, h->s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -214,6 +251,7 @@ int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
 int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
+    if (h->model == FB_MODEL_ROBOT2D) return u ? r2_upload(h, h->r2, h->r2->u, u, FB_R2_NU) : 0;
     if (u) HIPCHK(hipMemcpyAsync(h->u, u, sizeof(double) * FB_NU * h->n, hipMemcpyHostToDevice, h->stream));
     if (ui) HIPCHK(hipMemcpyAsync(h->ui, ui, sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -222,13 +260,21 @@ int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui) {
 int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
+    if (h->model == FB_MODEL_ROBOT2D) return u ? r2_download(h, h->r2, u, h->r2->u, FB_R2_NU) : 0;
     if (u) HIPCHK(hipMemcpyAsync(u, h->u, sizeof(double) * FB_NU * h->n, hipMemcpyDeviceToHost, h->stream));
     if (ui) HIPCHK(hipMemcpyAsync(ui, h->ui, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 
+int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit) {
+    if (!h || !init) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->model == FB_MODEL_ROBOT2D) return r2_f_init(h, init, ninit);
+    return fail("fb_f_init: Cessna172Sv0 initialises through fb_trim (TrimParameters) or fb_set_state");
+}
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost) {
+    if (h && h->model == FB_MODEL_ROBOT2D) return fail("fb_trim: Robot2D has no trim (use fb_f_init)");
     if (int32_t rc = check_ready(h)) return rc;
     if (!trim_params || !trim_state) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
@@ -254,6 +300,7 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
 }
 
 int32_t fb_f_ode(fb_handle h, double* xdot) {
+    if (h && h->model == FB_MODEL_ROBOT2D) { HIPCHK(hipSetDevice(h->device)); return r2_f_ode(h, xdot); }
     if (int32_t rc = check_ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = h->n;
@@ -268,6 +315,13 @@ int32_t fb_f_ode(fb_handle h, double* xdot) {
     return 0;
 }
 int32_t fb_f_step(fb_handle h) {
+    if (h && h->model == FB_MODEL_ROBOT2D) {
+        if (int32_t rc = r2_ready(h)) return rc;
+        HIPCHK(hipSetDevice(h->device));
+        R2State* R = h->r2;
+        R2_DISPATCH(k_r2_f_step);
+        return 0;
+    }
     if (int32_t rc = check_ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_f_step, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
@@ -276,10 +330,18 @@ int32_t fb_f_step(fb_handle h) {
 }
 int32_t fb_f_periodic(fb_handle h) {
     if (!h) return fail("null handle");
+    if (h->model == FB_MODEL_ROBOT2D) {
+        if (int32_t rc = r2_ready(h)) return rc;
+        HIPCHK(hipSetDevice(h->device));
+        R2State* R = h->r2;
+        R2_DISPATCH(k_r2_f_periodic);
+        return 0;
+    }
     return 0;  // Cessna172Sv0: NoAvionics and @no_periodic systems — nothing to do (c172.jl:695; aircraftbase.jl:131)
 }
 int32_t fb_get_outputs(fb_handle h, double* y) {
     if (!h || !y) return fail("null argument");
+    if (h->model == FB_MODEL_ROBOT2D) { HIPCHK(hipSetDevice(h->device)); return r2_download(h, h->r2, y, h->r2->y, FB_R2_NY); }
     if (!h->y) return fail("no outputs yet: call fb_f_ode first");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(y, h->y, sizeof(double) * FB_NY * h->n, hipMemcpyDeviceToHost, h->stream));
@@ -294,6 +356,11 @@ int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
     return 0;
 }
 int32_t fb_step(fb_handle h, int64_t nsteps) {
+    if (h && h->model == FB_MODEL_ROBOT2D) {
+        if (nsteps < 0) return fail("nsteps must be >= 0");
+        HIPCHK(hipSetDevice(h->device));
+        return r2_step(h, nsteps);
+    }
     if (int32_t rc = check_ready(h)) return rc;
     if (nsteps < 0) return fail("nsteps must be >= 0");
     HIPCHK(hipSetDevice(h->device));

@@ -9,3 +9,4 @@ from .modeling import (BatchedWorld, Simulation, SimulationTermination, TimeSeri
                        f_init, f_ode, f_periodic, f_step, init, run, step)
 from . import tables  # noqa: F401
 from . import sharding  # noqa: F401
+from .robot2d import Robot2DWorld, InitParameters  # noqa: F401

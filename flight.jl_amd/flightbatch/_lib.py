@@ -31,6 +31,8 @@ def _load():
         "fb_create": ([C.c_int32, C.c_int32, C.c_int32, I64, C.c_int32, C.POINTER(H)], C.c_int32),
         "fb_destroy": ([H], C.c_int32),
         "fb_size": ([H], I64),
+        "fb_dims": ([H, I32, I32, I32, I32], C.c_int32),
+        "fb_f_init": ([H, D, C.c_int32], C.c_int32),
         "fb_set_stream": ([H, VP], C.c_int32),
         "fb_attach_state": ([H, VP, VP], C.c_int32),
         "fb_set_table": ([H, C.c_int32, VP, C.POINTER(I64), C.c_int32], C.c_int32),

@@ -206,6 +206,11 @@ class BatchedWorld:
 # ---- the verbs (all return None) ---------------------------------------------------------------------
 def f_init(world: BatchedWorld, init, trim_state: np.ndarray | None = None) -> None:
     """f_init!(world, trim_params): FP/world.jl:49-57 -> FA/c172/c172.jl:883-942."""
+    if hasattr(init, "pack") and not isinstance(init, TrimParameters):   # plain per-instance initializer (Robot2D.InitParameters)
+        ip = init.pack(world.n)
+        check(lib.fb_f_init(world._h, _pd(ip), ip.shape[0]))
+        world.t = 0.0
+        return None
     if not isinstance(init, TrimParameters):
         raise TypeError(f"no f_init method for {type(init).__name__}")  # MethodError, FC/modeling.jl:205-207
     tp = init.pack(world.n)
@@ -221,7 +226,7 @@ def f_init(world: BatchedWorld, init, trim_state: np.ndarray | None = None) -> N
 def f_ode(world: BatchedWorld, xdot: np.ndarray | None = None) -> None:
     """f_ode!(world): FP/world.jl:26-32. Fills ẋ (into `xdot` if given, [FB_NX, n]) and world.y."""
     if xdot is not None:
-        assert xdot.dtype == np.float64 and xdot.shape == (K["FB_NX"], world.n) and xdot.flags.c_contiguous
+        assert xdot.dtype == np.float64 and xdot.shape[1] == world.n and xdot.flags.c_contiguous
     check(lib.fb_f_ode(world._h, _pd(xdot) if xdot is not None else None))
     return None
 

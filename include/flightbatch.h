@@ -73,7 +73,8 @@ enum {
     FB_ST_ISA_RANGE = 2,      /* ArgumentError, FP/atmosphere.jl:133  */
     FB_ST_GROUND_CRASH = 4,   /* GroundCrash,   FP/landinggear.jl:331-347 */
     FB_ST_NAN = 8,
-    FB_ST_CONTACT_ASSERT = 16 /* @assert, FP/landinggear.jl:321 */
+    FB_ST_CONTACT_ASSERT = 16, /* @assert, FP/landinggear.jl:321 */
+    FB_ST_LOST_BALANCE = 32    /* LostBalance, FA/robot2d/robot2d.jl:531-561 (Robot2D only) */
 };
 /* ---- output record y[FB_NY] (what cb_save logs of `mdl.y`, FC/sim.jl:345-347) ---- */
 enum {
@@ -91,6 +92,15 @@ enum {
                             a_eb_b[3] a_ib_b[3] f_c_c[3] alpha_ib_b[3] g_c_c[3]; dynamics.jl:416-434 */
     FB_NY = 174
 };
+/* ---- Robot2D (FB_MODEL_ROBOT2D; FA/robot2d/robot2d.jl) ------------------------------------------------
+ * state record x[FB_R2_NX]: the 4 continuous states (robot2d.jl:43) followed by the discrete state the reference
+ * keeps in vehicle.u / controller.s: [w, v, theta, eta | u_m, lqr_int_out, lqr_out_sat, pid_x_i, pid_x_d, pid_sat_out]
+ * inputs u[FB_R2_NU] = ControllerU (robot2d.jl:359-364): [mode (0 motor, 1 velocity, 2 position), m_ref, v_ref, eta_ref]
+ * outputs y[FB_R2_NY] = VehicleY (robot2d.jl:32-41): [w, v, theta, eta, u_m, tau_m, w_dot, v_dot]; no int state (ns = 0).
+ * FB_TABLE_ROBOT2D blob (23 doubles): vehicle L R m_b m_r J_b J_r k_m b_m J_m (robot2d.jl:20-30), then the
+ * LQRDataPoint of robot2d.h5 K_fbk[3] K_fwd K_int x_trim[3] u_trim z_trim, then PID k_p k_i k_d tau_f (robot2d.jl:419-436). */
+enum { FB_R2_NXC = 4, FB_R2_NX = 10, FB_R2_NU = 4, FB_R2_NY = 8, FB_R2_NINIT = 3, FB_R2_TABLE_SIZE = 23 };
+
 /* ---- trim (FA/c172/c172.jl:796-818) ---- */
 enum {
     FB_TP_N_E = 0, /* n_e[3] */ FB_TP_H_E = 3, FB_TP_PSI_NB = 4, FB_TP_EAS = 5, FB_TP_GAMMA_WB_N = 6,
@@ -108,7 +118,8 @@ enum {
     FB_TABLE_EGM96 = 0,     /* float32 [721 x 1441], column-major [lat, lon]; FP/geodesy.jl:186-198 */
     FB_TABLE_PROPELLER = 1, /* [21 x 21 x 6]: (J, Mt, {C_Fx,C_Mx,C_Fz_a,C_Mz_a,C_P,eta_p}); FP/propellers.jl:235-276 */
     FB_TABLE_PISTON = 2,    /* packed blob, layout in csrc/tables.h; FP/piston.jl:70-195 */
-    FB_TABLE_AERO = 3       /* packed blob, layout in csrc/tables.h; FA/c172/c172.jl:51-199 */
+    FB_TABLE_AERO = 3,      /* packed blob, layout in csrc/tables.h; FA/c172/c172.jl:51-199 */
+    FB_TABLE_ROBOT2D = 4    /* FB_R2_TABLE_SIZE doubles, see above; FA/robot2d/robot2d.jl:20-30,419-436 */
 };
 
 /* World-level parameters shared by the whole batch (one SimpleWorld each in the reference, identical here) */
@@ -127,6 +138,8 @@ typedef struct fb_params {
 int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out);
 int32_t fb_destroy(fb_handle h);
 int64_t fb_size(fb_handle h);
+/* per-model array sizes: continuous+discrete real state, int state, real inputs, output record (0 where absent) */
+int32_t fb_dims(fb_handle h, int32_t* nx, int32_t* ns, int32_t* nu, int32_t* ny);
 
 /* Run on an externally created HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
 int32_t fb_set_stream(fb_handle h, void* hip_stream);
@@ -151,6 +164,10 @@ int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui);
  * success[i] = 1 when cost <= 1e-16 (the reference's STOPVAL_REACHED criterion, c172.jl:926,934).
  * On return x, s, u hold the trimmed initial condition (assign!, FA/c172/c172s/c172s.jl:227-263). */
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost);
+
+/* f_init!(mdl, init) with a plain per-instance initializer: Robot2D InitParameters [N x 3] = (u_m, w, eta),
+ * FA/robot2d/robot2d.jl:208-228,563-570. (C172 initialises through fb_trim or fb_set_state.) */
+int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit);
 
 /* f_ode!(world) : FP/world.jl:26-32. Uses current x, u, s; writes xdot [N x FB_NX] (may be NULL)
  * and refreshes the output record y. */

@@ -8,6 +8,7 @@
 // This restatement is pinned by the reference's own known-answer / tolerance tests (tests/test_oracle_*.py
 // cite each one); the 1e-6 trajectory figure against a real Julia run remains "parity unpinned".
 #include "fo_c172.hpp"
+#include "fo_robot2d.hpp"
 #include "../include/flightbatch.h"
 #include "../flight.jl_amd/csrc/tables.h"  // blob layout constants only (to cross-check the product host's table packer)
 #include <cstdio>
@@ -271,6 +272,58 @@ int32_t fo_get_aero_blob(double* b) {
                                  t.C_m_zero, t.C_m_de, t.C_m_alpha, t.C_m_q, t.C_m_alpha_dot, t.C_n_dr, t.C_n_da, t.C_n_beta, t.C_n_p, t.C_n_r};
     for (int i = 0; i < AS_COUNT; i++) b[AT_SCALARS + i] = sc[i];
     return AT_SIZE;
+}
+
+// ---- Robot2D (lib/FlightApps/src/robot2d/robot2d.jl) ------------------------------------------------------
+// vp[9] = L R m_b m_r J_b J_r k_m b_m J_m (J_b, J_r < 0: derive from the others as the reference's defaults do)
+// gp[14] = K_fbk[3] K_fwd K_int x_trim[3] u_trim z_trim pid_kp pid_ki pid_kd pid_tau_f
+static R2Vehicle r2_vehicle(const double* vp) {
+    R2Vehicle v;
+    v.L = vp[0]; v.R = vp[1]; v.m_b = vp[2]; v.m_r = vp[3]; v.J_b = vp[4]; v.J_r = vp[5]; v.k_m = vp[6]; v.b_m = vp[7]; v.J_m = vp[8];
+    v.finish();
+    return v;
+}
+static R2Gains r2_gains(const double* gp) {
+    R2Gains g;
+    for (int k = 0; k < 3; k++) { g.K_fbk[k] = gp[k]; g.x_trim[k] = gp[5 + k]; }
+    g.K_fwd = gp[3]; g.K_int = gp[4]; g.u_trim = gp[8]; g.z_trim = gp[9];
+    g.pid_kp = gp[10]; g.pid_ki = gp[11]; g.pid_kd = gp[12]; g.pid_tau_f = gp[13];
+    return g;
+}
+int32_t fo_robot2d_init(int64_t n, const double* vp, const double* ip /*[3 x n]: u_m, ω, η*/, double* r /*[10 x n]*/) {
+    const R2Vehicle v = r2_vehicle(vp);
+    for (int64_t i = 0; i < n; i++) {
+        double ri[10];
+        r2_init(v, ip[0 * n + i], ip[1 * n + i], ip[2 * n + i], ri);
+        for (int k = 0; k < 10; k++) r[k * n + i] = ri[k];
+    }
+    return 0;
+}
+int32_t fo_robot2d_f_ode(int64_t n, const double* vp, const double* r, double* xd /*[4 x n]*/) {
+    const R2Vehicle v = r2_vehicle(vp);
+    for (int64_t i = 0; i < n; i++) {
+        double x[4] = {r[0 * n + i], r[1 * n + i], r[2 * n + i], r[3 * n + i]}, d[4];
+        r2_f_ode(v, x, r[4 * n + i], d);
+        for (int k = 0; k < 4; k++) xd[k * n + i] = d[k];
+    }
+    return 0;
+}
+int32_t fo_robot2d_step(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
+                        const double* u /*[4 x n]*/, double* r /*[10 x n]*/, int64_t step0, int64_t nsteps, int32_t* status) {
+    const R2Vehicle v = r2_vehicle(vp);
+    const R2Gains g = r2_gains(gp);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        double ri[10], ui[4];
+        for (int k = 0; k < 10; k++) ri[k] = r[k * n + i];
+        for (int k = 0; k < 4; k++) ui[k] = u[k * n + i];
+        const int32_t st = (status && status[i]) ? status[i] : r2_step(v, g, dt, ratio, with_controller != 0, ui, ri, step0, nsteps);
+        for (int k = 0; k < 10; k++) r[k * n + i] = ri[k];
+        if (status) status[i] |= st;
+    }
+    return 0;
 }
 
 // ============================ known-answer test helpers ======================================

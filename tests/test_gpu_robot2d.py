@@ -1,0 +1,78 @@
+"""Robot2D on the GPU (through the C ABI) against the CPU oracle and against the reference's closed-loop tests."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from test_oracle_robot2d import DEFAULT_VP, gains_from_h5, run
+
+pytestmark = pytest.mark.gpu
+_D = C.POINTER(C.c_double)
+
+
+def oracle_init(L, vp, ip):
+    r = np.zeros((10, ip.shape[1]))
+    L.fo_robot2d_init(C.c_int64(ip.shape[1]), vp.ctypes.data_as(_D), np.ascontiguousarray(ip).ctypes.data_as(_D), r.ctypes.data_as(_D))
+    return r
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-11), ("f32", 2e-3)])
+def test_robot2d_closed_loop_matches_oracle(fb, oracle, dtype, tol):
+    """README example 1 configuration (dt = 0.01, Δt = 0.02), mixed modes and references across the batch."""
+    n = 4096
+    rng = np.random.default_rng(5)
+    w = fb.Robot2DWorld(n, dtype=dtype)
+    ipar = fb.InitParameters(u_m=rng.uniform(-0.2, 0.2, n), ω=rng.uniform(-0.05, 0.05, n), η=rng.uniform(-1, 1, n))
+    fb.f_init(w, ipar)
+    u = np.zeros((4, n))
+    u[0] = rng.integers(0, 3, n); u[1] = rng.uniform(-0.3, 0.3, n); u[2] = rng.uniform(-0.5, 0.5, n); u[3] = rng.uniform(-2, 2, n)
+    w.u = u
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=37)   # launch size not a multiple of Δt/dt on purpose
+    fb.step(sim, 5.0); w.sync()
+    vp = DEFAULT_VP.copy(); gp = gains_from_h5()
+    r = oracle_init(oracle.lib, vp, ipar.pack(n))
+    st = run(oracle.lib, vp, gp, r, u, 0.01, 2, 1, 0, 500)
+    if dtype == "f64":
+        assert np.array_equal(w.status != 0, st != 0)
+    ok = (st == 0) & (w.status == 0)
+    assert ok.mean() > 0.5
+    err = np.max(np.abs(w.x[:, ok] - r[:, ok]) / np.maximum(np.abs(r[:, ok]), 1.0))
+    print(dtype, "max scaled error after 500 steps:", err, "terminated:", int((st != 0).sum()))
+    assert err < tol
+    xd = np.zeros((4, n)); fb.f_ode(w, xd)
+    xdo = np.zeros((4, n))
+    oracle.lib.fo_robot2d_f_ode(C.c_int64(n), vp.ctypes.data_as(_D), np.ascontiguousarray(w.x).ctypes.data_as(_D), xdo.ctypes.data_as(_D))
+    assert np.max(np.abs(xd - xdo)[:, ok] / np.maximum(np.abs(xdo[:, ok]), 1.0)) < (1e-12 if dtype == "f64" else 1e-4)
+    y = w.y
+    assert np.allclose(y[:4], w.x[:4]) and np.allclose(y[6:8], xd[:2])
+    w.close()
+
+
+def test_robot2d_reference_closed_loop_scenario(fb):
+    """lib/FlightApps/test/robot2d/test_robot2d.jl:70-97 on the GPU: Vehicle(L = 0.1, R = 0.08, m_b = 0.5), dt = Δt = 0.01."""
+    w = fb.Robot2DWorld(256, vehicle=dict(L=0.1, R=0.08, m_b=0.5))
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=100)
+    fb.init(sim, fb.InitParameters())
+    u = np.zeros((4, 256)); u[0] = 0; u[1] = 0.1
+    w.u = u; fb.step(sim, 0.1); w.sync()
+    x = w.x
+    assert np.all(x[4] == 0.1) and np.all(x[2] < 0)
+    u[0] = 1; u[2] = 0.3; w.u = u; fb.step(sim, 10.0); w.sync()
+    assert np.all(np.abs(w.x[1] - 0.3) < 1e-3)
+    u[2] = -np.inf; w.u = u; fb.step(sim, 10.0); w.sync()
+    assert np.all(np.abs(w.x[1] + 0.4 * 0.32 * 0.08 / 0.0189) < 1e-3)
+    u[0] = 2; u[3] = 1.0; w.u = u; fb.step(sim, 20.0); w.sync()
+    assert np.all(np.abs(w.x[3] - 1.0) < 1e-3) and (w.status == 0).all()
+    w.close()
+
+
+def test_robot2d_lost_balance_freezes(fb):
+    w = fb.Robot2DWorld(128)
+    fb.f_init(w, fb.InitParameters())
+    x = w.x; x[2] = 0.7; w.x = x
+    u = np.zeros((4, 128)); w.u = u     # mode_m with zero command: falls over
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    fb.step(sim, 5.0); w.sync()
+    assert (w.status == fb.K["FB_ST_LOST_BALANCE"]).all() and np.all(np.abs(w.x[2]) > np.pi / 4)
+    xa = w.x; fb.step(sim, 1.0); w.sync()
+    assert np.array_equal(xa, w.x)   # terminated robots stay frozen
+    w.close()
