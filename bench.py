@@ -33,6 +33,7 @@ DT = 0.01
 BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flags, C172Sv0 fp64
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+PROFILE_COUNTERS = "r01d_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
 
 
 def lattice(rank: int):
@@ -186,7 +187,7 @@ def main():
         achieved_gbs = BYTES_PER_AIRCRAFT_STEP * units_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         valu = None
-        prof = os.path.join(ROOT, "profiles", "r01_counters.json")
+        prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
         if os.path.exists(prof):
             pj = json.load(open(prof))
             if pj.get("n") == n and pj.get("inner") == args.inner:
@@ -195,7 +196,7 @@ def main():
                     tf = pj["fp64_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
                     valu = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_aircraft_step": pj["fp64_flops_per_launch"] / units_per_launch,
-                            "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/r01_counters.json"}
+                            "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS}
         line = {
             "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

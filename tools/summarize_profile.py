@@ -37,7 +37,7 @@ if ks.get("SQ_INSTS_VALU_FMA_F64"):
     flops = 64 * (ks["SQ_INSTS_VALU_ADD_F64"] + ks["SQ_INSTS_VALU_MUL_F64"] + 2 * ks["SQ_INSTS_VALU_FMA_F64"] + ks["SQ_INSTS_VALU_TRANS_F64"])
     res["fp64_flops_per_launch"] = flops
     res["fp64_flops_per_aircraft_step"] = flops / (N * INNER)
-    res["valu_insts_per_aircraft_step"] = ks["SQ_INSTS_VALU"] * 64 / (N * INNER) / 64 * 64 / 64
+    res["valu_insts_per_aircraft_step"] = ks["SQ_INSTS_VALU"] * 64 / (N * INNER)   # SQ_INSTS_VALU counts per wave; one lane = one aircraft
 res["k_step_mean_ns_under_pmc"] = mean(dur["k_step"])
 json.dump(res, open(os.path.join(summ, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: res.get(k) for k in ("hbm_bytes_per_launch", "fp64_flops_per_aircraft_step", "calibration", "k_step_mean_ns_under_pmc")}, indent=1))
