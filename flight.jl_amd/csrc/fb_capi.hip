@@ -12,9 +12,11 @@
 using namespace fbd;
 
 static thread_local std::string g_err;
-static int32_t fail(const char* fmt, const char* what = "") {
+template <class... A>
+static int32_t fail(const char* fmt, A... args) {
     char buf[512];
-    std::snprintf(buf, sizeof buf, fmt, what);
+    if constexpr (sizeof...(A) == 0) std::snprintf(buf, sizeof buf, "%s", fmt);
+    else std::snprintf(buf, sizeof buf, fmt, args...);
     g_err = buf;
     return -1;
 }
@@ -52,6 +54,7 @@ struct fb_handle_s {
     bool timing = false;
     int64_t launches = 0;
     struct R2State* r2 = nullptr;  // Robot2D handles only
+    struct LogState* log = nullptr;  // on-device TimeSeries log (fb_log_*)
 };
 
 static KArgs make_args(fb_handle h) {
@@ -74,6 +77,7 @@ static int32_t check_ready(fb_handle h) {
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 #include "fb_robot2d.inc"
+#include "fb_log.inc"
 
 extern "C" {
 
@@ -132,6 +136,7 @@ int32_t fb_destroy(fb_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    log_free(h);
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
@@ -355,15 +360,9 @@ int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
     h->steps_per_launch = k;
     return 0;
 }
-int32_t fb_step(fb_handle h, int64_t nsteps) {
-    if (h && h->model == FB_MODEL_ROBOT2D) {
-        if (nsteps < 0) return fail("nsteps must be >= 0");
-        HIPCHK(hipSetDevice(h->device));
-        return r2_step(h, nsteps);
-    }
-    if (int32_t rc = check_ready(h)) return rc;
-    if (nsteps < 0) return fail("nsteps must be >= 0");
-    HIPCHK(hipSetDevice(h->device));
+// nsteps of the stepping kernel, no logging
+static int32_t step_raw(fb_handle h, int64_t nsteps) {
+    if (h->model == FB_MODEL_ROBOT2D) return r2_step(h, nsteps);
     const KArgs a = make_args(h);
     int64_t left = nsteps;
     while (left > 0) {
@@ -374,6 +373,94 @@ int32_t fb_step(fb_handle h, int64_t nsteps) {
     }
     HIPCHK(hipGetLastError());
     h->t += (double)nsteps * h->params.dt;
+    return 0;
+}
+int32_t fb_step(fb_handle h, int64_t nsteps) {
+    if (h && h->model == FB_MODEL_ROBOT2D) {
+        if (int32_t rc = r2_ready(h)) return rc;
+    } else if (int32_t rc = check_ready(h)) return rc;
+    if (nsteps < 0) return fail("nsteps must be >= 0");
+    HIPCHK(hipSetDevice(h->device));
+    LogState* L = h->log;
+    if (!L || L->every <= 0) return step_raw(h, nsteps);
+    // launches are cut at the save instants; a sample is taken after the step's callbacks (cb_save comes last, FC/sim.jl:217)
+    int64_t left = nsteps;
+    while (left > 0) {
+        const int64_t to_save = L->every - (L->step_index % L->every);
+        const int64_t k = left < to_save ? left : to_save;
+        if (k == to_save && L->count >= L->capacity) return fail("log capacity (%lld samples) exhausted", (long long)L->capacity);
+        if (int32_t rc = step_raw(h, k)) return rc;
+        L->step_index += k;
+        left -= k;
+        if (L->step_index % L->every == 0)
+            if (int32_t rc = log_record(h)) return rc;
+    }
+    return 0;
+}
+/* ---- on-device TimeSeries log ---- */
+int32_t fb_log_configure(fb_handle h, int64_t every, int64_t capacity, const int32_t* rows, int32_t nrows) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    log_free(h);
+    if (every <= 0) return 0;  // logging off
+    if (capacity <= 0 || nrows <= 0 || !rows) return fail("fb_log_configure: capacity and the row list must be non-empty");
+    const int ny = h->model == FB_MODEL_ROBOT2D ? FB_R2_NY : FB_NY, nx = h->model == FB_MODEL_ROBOT2D ? FB_R2_NX : FB_NX;
+    LogState* L = new LogState();
+    for (int j = 0; j < nrows; j++) {
+        const int r = rows[j];
+        const bool ok = (r >= 0 && r < ny) || (r >= FB_LOG_X0 && r < FB_LOG_X0 + nx);
+        if (!ok) { delete L; return fail("fb_log_configure: row %d is neither an output row [0,%d) nor FB_LOG_X0 + state row [0,%d)", r, ny, nx); }
+        if (r < FB_LOG_X0) L->need_y = true;
+    }
+    h->log = L;
+    L->every = every; L->capacity = capacity; L->nrows = nrows;
+    HIPCHK(hipMalloc(&L->rows_dev, sizeof(int32_t) * nrows));
+    HIPCHK(hipMemcpy(L->rows_dev, rows, sizeof(int32_t) * nrows, hipMemcpyHostToDevice));
+    const size_t bytes = (size_t)capacity * nrows * h->n * log_esize(h);
+    if (hipMalloc(&L->data, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        log_free(h);
+        return fail("fb_log_configure: cannot allocate %zu bytes of device memory for the log", bytes);
+    }
+    L->t.reserve((size_t)capacity);
+    return 0;
+}
+int32_t fb_log_clear(fb_handle h) {
+    if (!h) return fail("null handle");
+    if (h->log) { h->log->count = 0; h->log->step_index = 0; h->log->t.clear(); }
+    return 0;
+}
+int32_t fb_log_record(fb_handle h) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return log_record(h);
+}
+int32_t fb_log_count(fb_handle h, int64_t* count) {
+    if (!h || !count) return fail("null argument");
+    *count = h->log ? h->log->count : 0;
+    return 0;
+}
+int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double* data) {
+    if (!h) return fail("null handle");
+    LogState* L = h->log;
+    if (!L) return fail("the log is not configured (fb_log_configure)");
+    if (first < 0 || count < 0 || first + count > L->count) return fail("fb_log_read: samples [%lld, %lld) requested, %lld recorded", (long long)first, (long long)(first + count), (long long)L->count);
+    HIPCHK(hipSetDevice(h->device));
+    if (t) for (int64_t k = 0; k < count; k++) t[k] = L->t[(size_t)(first + k)];
+    if (data && count > 0) {
+        const size_t e = log_esize(h), per = (size_t)L->nrows * h->n;
+        const char* src = (const char*)L->data + (size_t)first * per * e;
+        if (e == 8) {
+            HIPCHK(hipMemcpyAsync(data, src, (size_t)count * per * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        } else {
+            std::vector<float> f((size_t)count * per);
+            HIPCHK(hipMemcpyAsync(f.data(), src, f.size() * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (size_t k = 0; k < f.size(); k++) data[k] = (double)f[k];
+        }
+    }
     return 0;
 }
 int32_t fb_sync(fb_handle h) {

@@ -52,6 +52,11 @@ def _load():
         "fb_sync": ([H], C.c_int32),
         "fb_time": ([H], C.c_double),
         "fb_status": ([H, I32], C.c_int32),
+        "fb_log_configure": ([H, I64, I64, I32, C.c_int32], C.c_int32),
+        "fb_log_clear": ([H], C.c_int32),
+        "fb_log_record": ([H], C.c_int32),
+        "fb_log_count": ([H, C.POINTER(I64)], C.c_int32),
+        "fb_log_read": ([H, I64, I64, D, D], C.c_int32),
         "fb_timing_begin": ([H], C.c_int32),
         "fb_timing_end": ([H, C.POINTER(C.c_float), C.POINTER(I64)], C.c_int32),
         "fb_last_error": ([], C.c_char_p),

@@ -247,11 +247,15 @@ def f_periodic(world: BatchedWorld) -> None:
 class Simulation:
     """Simulation(mdl; algorithm = RK4(), adaptive = false, dt = 0.02, Δt = dt, t_start = 0, t_end = 10000,
     save_on = true, saveat = []) — FC/sim.jl:183-196. Only the fixed-step RK4 path exists here.
-    `saveat` (seconds) thins the log; saving is a device->host copy of x (and y) at those instants."""
+
+    Saving (cb_save, FC/sim.jl:210-217) is an ON-DEVICE log: every `saveat` seconds (default: every step) the rows
+    `save_rows` of the output record y (names or indices of include/flightbatch.h FB_Y_*; default: none) and, with
+    `save_x`, the whole state x are appended to a device buffer sized for `t_end` (capped by `log_capacity` samples);
+    nothing crosses PCIe until TimeSeries(sim) is built."""
 
     def __init__(self, mdl: BatchedWorld, dt: float = 0.02, Δt: float | None = None, t_start: float = 0.0,
                  t_end: float = 10000.0, save_on: bool = True, saveat: float | None = None, steps_per_launch: int | None = None,
-                 save_outputs: bool = False):
+                 save_outputs: bool = False, save_rows=None, save_x: bool = True, log_capacity: int | None = None):
         self.mdl = mdl
         self.dt = float(dt)
         self.Δt = float(Δt if Δt is not None else dt)
@@ -261,15 +265,28 @@ class Simulation:
         self.t_start, self.t_end = float(t_start), float(t_end)
         self.save_on = save_on
         self.save_every = max(1, int(round((saveat if saveat else self.dt) / self.dt)))
-        self.save_outputs = save_outputs
         mdl._Δt_root = self.Δt  # FC/sim.jl:198
         mdl.set_params(dt=self.dt, periodic_n=int(round(ratio)))
         self._nstep = 0
-        self.log_t: list = []
-        self.log_x: list = []
-        self.log_y: list = []
+        nx, ny = _dims(mdl)
+        rows: list = []
+        if save_outputs:
+            rows += list(range(ny))
+        for r in (save_rows or []):
+            rows.append(K[r] if isinstance(r, str) else int(r))
+        self.y_rows = rows
+        self.save_x = bool(save_x)
+        self._rows = np.array(rows + ([K["FB_LOG_X0"] + k for k in range(nx)] if save_x else []), dtype=np.int32)
         k = steps_per_launch or (self.save_every if save_on else 50)
         check(lib.fb_set_steps_per_launch(mdl._h, int(k)))
+        if save_on and self._rows.size:
+            want = int(np.ceil((self.t_end - self.t_start) / (self.save_every * self.dt))) + 2
+            budget = int(log_capacity) if log_capacity else max(2, int(8e9 // (8 * self._rows.size * mdl.n)))   # <= 8 GB by default
+            self.capacity = min(want, budget)
+            check(lib.fb_log_configure(mdl._h, self.save_every, self.capacity, _pi(self._rows), int(self._rows.size)))
+        else:
+            self.save_on = False
+            check(lib.fb_log_configure(mdl._h, 0, 0, None, 0))
 
     # property forwarding, FC/sim.jl:261-275
     @property
@@ -292,37 +309,31 @@ class Simulation:
     def s(self):
         return self.mdl.s
 
-    def _save(self):
-        self.log_t.append(self.t)
-        self.log_x.append(self.mdl.x)
-        if self.save_outputs:
-            f_ode(self.mdl)
-            self.log_y.append(self.mdl.y)
+
+def _dims(mdl):
+    nx, ny = C.c_int32(), C.c_int32()
+    check(lib.fb_dims(mdl._h, C.byref(nx), None, None, C.byref(ny)))
+    return nx.value, ny.value
 
 
 def init(sim: Simulation, *init_args, **init_kwargs) -> None:
     """init!(sim, init_args...): FC/sim.jl:390-414 — clears the log, f_init!s the model, saves y(t0)."""
-    sim.log_t.clear(); sim.log_x.clear(); sim.log_y.clear()
+    check(lib.fb_log_clear(sim.mdl._h))
     if init_args:
         f_init(sim.mdl, *init_args, **init_kwargs)
     sim._nstep = 0
     sim.mdl._n = 0  # cb_periodic_init!, FC/sim.jl:358-362
     if sim.save_on:
-        sim._save()
+        check(lib.fb_log_record(sim.mdl._h))
     return None
 
 
 def step(sim: Simulation, Δt_total: float | None = None, stop_at_tdt: bool = True) -> None:
-    """step!(sim) / step!(sim, Δt_total, true): FC/sim.jl:386 (OrdinaryDiffEq step!)."""
+    """step!(sim) / step!(sim, Δt_total, true): FC/sim.jl:386 (OrdinaryDiffEq step!). Asynchronous: the launches (and the
+    device-side saves between them) are queued on the world's stream."""
     n = 1 if Δt_total is None else int(round(Δt_total / sim.dt))
-    done = 0
-    while done < n:
-        k = min(n - done, sim.save_every - (sim._nstep % sim.save_every)) if sim.save_on else n - done
-        check(lib.fb_step(sim.mdl._h, k))
-        done += k
-        sim._nstep += k
-        if sim.save_on and sim._nstep % sim.save_every == 0:
-            sim._save()
+    check(lib.fb_step(sim.mdl._h, n))
+    sim._nstep += n
     sim.mdl.t = sim.t
     return None
 
@@ -335,12 +346,25 @@ def run(sim: Simulation) -> None:
 
 
 class TimeSeries:
-    """TimeSeries(sim): FC/sim.jl:644-704 — logged samples as arrays: t [m], x [m, FB_NX, n], y [m, FB_NY, n]."""
+    """TimeSeries(sim): FC/sim.jl:644-704 — the logged samples, read back from the device log:
+    t [m] (seconds from the last init), x [m, Nx, n] (when save_x), y [m, len(y_rows), n] (rows sim.y_rows of the output
+    record; all of it with save_outputs=True). ts[i] indexes samples like the reference's getindex."""
 
-    def __init__(self, sim: Simulation):
-        self.t = np.array(sim.log_t)
-        self.x = np.stack(sim.log_x) if sim.log_x else np.zeros((0, K["FB_NX"], sim.mdl.n))
-        self.y = np.stack(sim.log_y) if sim.log_y else None
+    def __init__(self, sim: Simulation, first: int = 0, count: int | None = None):
+        cnt = C.c_int64()
+        check(lib.fb_log_count(sim.mdl._h, C.byref(cnt)))
+        m = cnt.value - first if count is None else int(count)
+        nrows = int(sim._rows.size)
+        nx, _ = _dims(sim.mdl)
+        self.t = np.zeros(m)
+        data = np.zeros((m, nrows, sim.mdl.n))
+        if m > 0 and nrows > 0:
+            check(lib.fb_log_read(sim.mdl._h, int(first), m, _pd(self.t), _pd(data)))
+        self.t = self.t + sim.t_start
+        ny = len(sim.y_rows)
+        self.y_rows = list(sim.y_rows)
+        self.y = data[:, :ny] if ny else None
+        self.x = data[:, ny:] if sim.save_x else np.zeros((m, nx, sim.mdl.n))
 
     def __len__(self):
         return len(self.t)

@@ -129,4 +129,22 @@ function step!(sim::BatchedSimulation, Δt_total::Real = sim.dt, stop_at_tdt::Bo
 end
 Base.getproperty(sim::BatchedSimulation, s::Symbol) = s === :t ? getfield(sim, :nstep) * getfield(sim, :dt) : getfield(sim, s)
 
+# ---- saving: the SavingCallback / TimeSeries(sim) of FC/sim.jl:210-217,644-704, kept on the device -------------------
+const LOG_X0 = Cint(1000)   # FB_LOG_X0: rows >= LOG_X0 select state rows, rows < LOG_X0 rows of the output record y
+"Log `rows` (0-based, see include/flightbatch.h FB_Y_*) every `saveat` seconds into a device buffer of `capacity` samples."
+function save_on!(sim::BatchedSimulation, rows::Vector{Cint}; saveat::Real = sim.dt, capacity::Integer = 1024)
+    check(ccall((:fb_log_configure, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cint}, Cint),
+                sim.mdl.handle, round(Int64, saveat / sim.dt), capacity, rows, length(rows)))
+    check(ccall((:fb_log_record, lib), Cint, (Ptr{Cvoid},), sim.mdl.handle))   # y(t0), like reinit! does
+end
+"TimeSeries(sim) for the batch: (t, data) with data[aircraft, row, sample]."
+function timeseries(sim::BatchedSimulation, nrows::Integer)
+    cnt = Ref{Int64}(0)
+    check(ccall((:fb_log_count, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), sim.mdl.handle, cnt))
+    t = Vector{Float64}(undef, cnt[])
+    data = Array{Float64, 3}(undef, sim.mdl.n, nrows, cnt[])
+    check(ccall((:fb_log_read, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}), sim.mdl.handle, 0, cnt[], t, data))
+    return t, data
+end
+
 end # module

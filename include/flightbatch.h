@@ -188,6 +188,22 @@ int32_t fb_sync(fb_handle h);
 /* sim.t : FC/sim.jl:261-275 */
 double fb_time(fb_handle h);
 
+/* On-device TimeSeries log: the SavingCallback of Simulation (FC/sim.jl:210-212: log = SavedValues(Float64, Y),
+ * cb_save_function = deepcopy(mdl.y), :345-347) and TimeSeries(sim) (:644-704).
+ * A sample = `nrows` rows for all N aircraft, taken every `every` steps after the step's callbacks (cb_save is the last
+ * callback of the set, :217) into a device buffer of `capacity` samples; rows[j] in [0, Ny) selects output row y[rows[j]]
+ * (an f_ode! at the saved instant refreshes y first), FB_LOG_X0 + k selects state row x[k]. every = 0 turns logging off.
+ * fb_log_clear drops the samples and restarts the save phase (init!, :395-397); fb_log_record saves the current instant
+ * (init! saves y(t0) through reinit!, :405-410). fb_log_read copies samples [first, first+count) to the host:
+ * t [count], data [count x nrows x N] (sample slowest, aircraft fastest). fb_step fails when a sample is due and the
+ * buffer is full. */
+enum { FB_LOG_X0 = 1000 };
+int32_t fb_log_configure(fb_handle h, int64_t every, int64_t capacity, const int32_t* rows, int32_t nrows);
+int32_t fb_log_clear(fb_handle h);
+int32_t fb_log_record(fb_handle h);
+int32_t fb_log_count(fb_handle h, int64_t* count);
+int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double* data);
+
 /* SimulationTermination / ArgumentError mapping: per-aircraft sticky status bits (FB_ST_*). */
 int32_t fb_status(fb_handle h, int32_t* status);
 

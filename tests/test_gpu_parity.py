@@ -253,3 +253,38 @@ def test_status_stays_clean_from_trim_to_step(fb):
     x1 = w.x
     assert np.all(x1[8] < x0[8]), "fuel must have burnt on every aircraft: nobody is frozen"
     w.close()
+
+
+def test_device_log_matches_host_snapshots(fb):
+    """The on-device TimeSeries log (cb_save, FC/sim.jl:210-217,345-347): decimated y rows + x saved on the GPU must
+    equal what f_ode!/mdl.y give when the same run is stopped at the same instants; t0 sample from init!."""
+    n = 2048
+    tp = lattice_trim_params(fb, n, seed=4)
+    rows = ["FB_Y_KIN", fb.K["FB_Y_KIN"] + 7, fb.K["FB_Y_AIR"] + 3, fb.K["FB_Y_DYN"] + 20, fb.K["FB_Y_PWP"] + 4]
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, tp)
+    x0, s0 = w.x, w.s
+    sim = fb.Simulation(w, dt=0.01, t_end=3.0, saveat=0.25, save_rows=rows, steps_per_launch=40)   # 40 does not divide 25
+    fb.init(sim)
+    fb.run(sim)
+    ts = fb.TimeSeries(sim)
+    assert len(ts) == 13 and np.allclose(ts.t, np.arange(13) * 0.25)
+    assert ts.x.shape == (13, 27, n) and ts.y.shape == (13, 5, n)
+    assert np.array_equal(ts.x[-1], w.x)
+    # the same run, stopped by hand
+    w2 = fb.BatchedWorld(n)
+    fb.f_init(w2, tp); w2.set_state(x0, s0)
+    sim2 = fb.Simulation(w2, dt=0.01, save_on=False, steps_per_launch=25)
+    ridx = [fb.K[r] if isinstance(r, str) else r for r in rows]
+    for k in range(13):
+        if k:
+            fb.step(sim2, 0.25)
+        fb.f_ode(w2)
+        assert np.array_equal(ts.x[k], w2.x), k
+        assert np.array_equal(ts.y[k], w2.y[ridx]), k
+    # capacity is enforced loudly, and init! restarts the log
+    with pytest.raises(fb.FlightBatchError, match="capacity"):
+        fb.step(sim, 10.0)
+    fb.init(sim)
+    assert len(fb.TimeSeries(sim)) == 1
+    w.close(); w2.close()

@@ -76,3 +76,18 @@ def test_robot2d_lost_balance_freezes(fb):
     xa = w.x; fb.step(sim, 1.0); w.sync()
     assert np.array_equal(xa, w.x)   # terminated robots stay frozen
     w.close()
+
+
+def test_robot2d_device_log_f32(fb):
+    """The device log of an fp32 batch: samples are stored in fp32 on the GPU and widened on read."""
+    n = 512
+    w = fb.Robot2DWorld(n, dtype="f32")
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, t_end=1.0, saveat=0.1, save_rows=[0, 1, 6])
+    fb.init(sim, fb.InitParameters(u_m=0.05))
+    fb.run(sim)
+    ts = fb.TimeSeries(sim)
+    assert len(ts) == 11 and ts.x.shape == (11, 10, n) and ts.y.shape == (11, 3, n)
+    assert np.array_equal(ts.x[-1], w.x)
+    assert np.array_equal(ts.y[:, 0], ts.x[:, 0]) and np.array_equal(ts.y[:, 1], ts.x[:, 1])   # y.ω, y.v are the states
+    assert np.all(np.abs(np.diff(ts.x[:, 1, 0])) > 0)   # it moves
+    w.close()
