@@ -119,12 +119,41 @@ class File:
                 continue  # soft / external links: not used by the reference's files
             out[name] = struct.unpack_from("<Q", b, p)[0] + self.base
 
+    def _children(self, header: int) -> dict:
+        """name -> object header address of the members of the group whose object header is at `header`."""
+        out: dict = {}
+        for mtype, data, _ in self._messages(header):
+            if mtype == 0x0011:  # old-style group: B-tree + local heap
+                btree, heap = struct.unpack_from("<QQ", self.b, data)
+                if btree != UNDEF and heap != UNDEF:
+                    self._walk_btree(btree + self.base, self._heap_data(heap + self.base), out)
+        self._link_messages(header, out)
+        return out
+
+    def _is_group(self, header: int) -> bool:
+        types = {m[0] for m in self._messages(header)}
+        return 0x0001 not in types   # no dataspace message: not a dataset
+
     def names(self) -> dict:
+        """Flat map 'group/sub/dataset' -> object header address of every dataset in the file."""
         if self._names is None:
             out: dict = {}
+
+            def walk(header, prefix):
+                for name, addr in self._children(header).items():
+                    if self._is_group(addr):
+                        walk(addr, prefix + name + "/")
+                    else:
+                        out[prefix + name] = addr
+            root: dict = {}
             if self.root_btree != UNDEF and self.root_heap != UNDEF:
-                self._walk_btree(self.root_btree + self.base, self._heap_data(self.root_heap + self.base), out)
-            self._link_messages(self.root_header + self.base, out)
+                self._walk_btree(self.root_btree + self.base, self._heap_data(self.root_heap + self.base), root)
+            self._link_messages(self.root_header + self.base, root)
+            for name, addr in root.items():
+                if self._is_group(addr):
+                    walk(addr, name + "/")
+                else:
+                    out[name] = addr
             self._names = out
         return self._names
 

@@ -92,6 +92,62 @@ enum {
                             a_eb_b[3] a_ib_b[3] f_c_c[3] alpha_ib_b[3] g_c_c[3]; dynamics.jl:416-434 */
     FB_NY = 174
 };
+/* ---- Cessna172Xv2 (FB_MODEL_C172X2): fly-by-wire actuators + gain-scheduled autopilot ----------------------
+ * FA/c172/c172x/c172x.jl:19-52,112-143 (Actuator1 x 7, FlyByWireActuation), c172x2.jl:18-60 (Avionics{ctl, gdc}),
+ * control/c172x_ctl.jl (ControlLawsLon/Lat), FP/control.jl:123-185 (Integrator), :370-471 (PID), :620-743 (LQR),
+ * :950-994 (gain lookups).
+ * Continuous state x [N x FB_X2_NX], in the order of the reference's ComponentVector (`act` is the last Systems
+ * field, c172.jl:678-686): rows 0-11 as Cessna172Sv0 (aero, ldg, fuel, pwp), rows FB_X2_ACT + {THROTTLE..BRAKE_RIGHT}
+ * the seven actuator positions, rows 19-27 kinematics (q_wb, q_ew, h_e), rows 28-33 dynamics (w_eb_b, v_eb_b).
+ * Discrete state s and inputs u/ui as Cessna172Sv0, except that u's throttle/aileron/elevator/rudder (+offset) rows
+ * are ignored: those four actuators are commanded by the control laws; FB_U_FLAPS / FB_U_BRAKE_* are the commands of
+ * the remaining three actuators (act.flaps.u etc.). Output record y as Cessna172Sv0. */
+enum {
+    FB_X2_NX = 34, FB_X2_ACT = 12, FB_X2_KIN = 19, FB_X2_DYN = 28,
+    FB_ACT_THROTTLE = 0, FB_ACT_AILERON = 1, FB_ACT_ELEVATOR = 2, FB_ACT_RUDDER = 3, FB_ACT_FLAPS = 4,
+    FB_ACT_BRAKE_LEFT = 5, FB_ACT_BRAKE_RIGHT = 6, FB_NACT = 7
+};
+/* control-law inputs cu [N x FB_NCU] (avionics.ctl.u; ControlLawsLonU c172x_ctl.jl:242-253, ControlLawsLatU :826-836);
+ * the two mode requests are stored as doubles holding the enum value */
+enum {
+    FB_CU_LON_MODE_REQ = 0, FB_CU_THROTTLE_AXIS = 1, FB_CU_THROTTLE_OFFSET = 2, FB_CU_ELEVATOR_AXIS = 3,
+    FB_CU_ELEVATOR_OFFSET = 4, FB_CU_Q_REF = 5, FB_CU_THETA_REF = 6, FB_CU_EAS_REF = 7, FB_CU_CLM_REF = 8, FB_CU_H_REF = 9,
+    FB_CU_LAT_MODE_REQ = 10, FB_CU_AILERON_AXIS = 11, FB_CU_AILERON_OFFSET = 12, FB_CU_RUDDER_AXIS = 13,
+    FB_CU_RUDDER_OFFSET = 14, FB_CU_P_REF = 15, FB_CU_BETA_REF = 16, FB_CU_PHI_REF = 17, FB_CU_CHI_REF = 18,
+    FB_NCU = 19
+};
+enum { /* ModeControlLon, c172x_ctl.jl:29-39 */
+    FB_LON_DIRECT = 0, FB_LON_SAS = 1, FB_LON_THR_Q = 2, FB_LON_THR_THETA = 3, FB_LON_THR_EAS = 4, FB_LON_EAS_Q = 5,
+    FB_LON_EAS_THETA = 6, FB_LON_EAS_CLM = 7, FB_LON_EAS_ALT = 8
+};
+enum { FB_LAT_DIRECT = 0, FB_LAT_SAS = 1, FB_LAT_P_BETA = 2, FB_LAT_PHI_BETA = 3, FB_LAT_CHI_BETA = 4 }; /* :727-733 */
+enum { FB_ALT_ACQUIRE = 0, FB_ALT_HOLD = 1 };                                                           /* :41-44 */
+/* control-law record cs [N x FB_NCS]: the discrete state (s) of every compensator plus the outputs (y) other code
+ * reads (modes, references, actuator commands). LQR blocks: integrator state[2], output saturation[2] (+ the last
+ * z_ref[2] where a later mode change reads it); Integrator: x0, sat_out_0; PID: x_i0, x_d0, sat_out_0. */
+enum {
+    FB_CS_LON_MODE = 0, FB_CS_H_STATE = 1, FB_CS_THROTTLE_CMD = 2, FB_CS_ELEVATOR_CMD = 3, FB_CS_THROTTLE_REF = 4,
+    FB_CS_ELEVATOR_REF = 5, FB_CS_Q_REF = 6, FB_CS_THETA_REF = 7,
+    FB_CS_TE2TE = 8,    /* int[2] sat[2] z_ref[2] */
+    FB_CS_TV2TE = 14,   /* int[2] sat[2] */
+    FB_CS_VH2TE = 18,   /* int[2] sat[2] */
+    FB_CS_Q2E_INT = 22, /* x0 sat */
+    FB_CS_Q2E_PID = 24, FB_CS_C2THETA_PID = 27, FB_CS_V2T_PID = 30,
+    FB_CS_LAT_MODE = 33, FB_CS_AILERON_CMD = 34, FB_CS_RUDDER_CMD = 35, FB_CS_AILERON_REF = 36, FB_CS_RUDDER_REF = 37,
+    FB_CS_PHI_REF = 38,
+    FB_CS_AR2AR = 39,    /* int[2] sat[2] */
+    FB_CS_PHIBETA2AR = 43, /* int[2] sat[2] z_ref[2] */
+    FB_CS_P2PHI_INT = 49, FB_CS_P2PHI_PID = 51, FB_CS_CHI2PHI_PID = 54,
+    FB_NCS = 57
+};
+/* FB_TABLE_CTL_GAINS blob: ten lookups in the order te2te, tv2te, vh2te (LQR, NX = 8, 8, 9), q2e, c2theta, v2t (PID),
+ * ar2ar, phibeta2ar (LQR, NX = 8), p2phi, chi2phi (PID)  [files FA/c172/c172x/control/data/{te2te,tv2te,vh2te,q2e,c2θ,v2t,
+ * ar2ar,φβ2ar,p2φ,χ2φ}.h5, loaded by c172x_ctl.jl:208-213,816-819]. Each lookup = 6 doubles (n_EAS, n_h, EAS_lo, EAS_hi,
+ * h_lo, h_hi: the `bounds` dataset and the grid size) followed by n_EAS*n_h records, EAS index fastest. LQR record:
+ * K_fbk [2 x NX] column-major, K_fwd [2 x 2], K_int [2 x 2], x_trim [NX], u_trim [2], z_trim [2]; PID record: k_p k_i k_d tau_f.
+ * Interpolation: linear in (EAS, h_e), Flat extrapolation (FP/control.jl:950-966). */
+enum { FB_CTL_GRID_HDR = 6, FB_CTL_LQR8_REC = 36, FB_CTL_LQR9_REC = 39, FB_CTL_PID_REC = 4 };
+
 /* ---- Robot2D (FB_MODEL_ROBOT2D; FA/robot2d/robot2d.jl) ------------------------------------------------
  * state record x[FB_R2_NX]: the 4 continuous states (robot2d.jl:43) followed by the discrete state the reference
  * keeps in vehicle.u / controller.s: [w, v, theta, eta | u_m, lqr_int_out, lqr_out_sat, pid_x_i, pid_x_d, pid_sat_out]
@@ -119,7 +175,8 @@ enum {
     FB_TABLE_PROPELLER = 1, /* [21 x 21 x 6]: (J, Mt, {C_Fx,C_Mx,C_Fz_a,C_Mz_a,C_P,eta_p}); FP/propellers.jl:235-276 */
     FB_TABLE_PISTON = 2,    /* packed blob, layout in csrc/tables.h; FP/piston.jl:70-195 */
     FB_TABLE_AERO = 3,      /* packed blob, layout in csrc/tables.h; FA/c172/c172.jl:51-199 */
-    FB_TABLE_ROBOT2D = 4    /* FB_R2_TABLE_SIZE doubles, see above; FA/robot2d/robot2d.jl:20-30,419-436 */
+    FB_TABLE_ROBOT2D = 4,   /* FB_R2_TABLE_SIZE doubles, see above; FA/robot2d/robot2d.jl:20-30,419-436 */
+    FB_TABLE_CTL_GAINS = 5  /* Cessna172Xv2 autopilot gain lookups, layout above; FP/control.jl:879-994 */
 };
 
 /* World-level parameters shared by the whole batch (one SimpleWorld each in the reference, identical here) */

@@ -9,6 +9,7 @@
 // cite each one); the 1e-6 trajectory figure against a real Julia run remains "parity unpinned".
 #include "fo_c172.hpp"
 #include "fo_robot2d.hpp"
+#include "fo_c172x.hpp"
 #include "../include/flightbatch.h"
 #include "../flight.jl_amd/csrc/tables.h"  // blob layout constants only (to cross-check the product host's table packer)
 #include <cstdio>
@@ -555,4 +556,126 @@ void fo_ldg_unit_f_ode(double h_orth, const double* kin10, double steering_input
     for (int i = 0; i < 23; i++) out[i] = o[i];
 }
 
+
+// ---- Cessna172Xv2 (fo_c172x.hpp). x [34 x n] in ORACLE order (27 Sv0 rows, then the 7 actuator positions). ----
+void fo_ctl_lookup(const double* blob, int32_t which, double EAS, double h, double* out) {
+    CtlGains G; G.bind(blob);
+    const int rec[10] = {FB_CTL_LQR8_REC, FB_CTL_LQR8_REC, FB_CTL_LQR9_REC, FB_CTL_PID_REC, FB_CTL_PID_REC, FB_CTL_PID_REC,
+                         FB_CTL_LQR8_REC, FB_CTL_LQR8_REC, FB_CTL_PID_REC, FB_CTL_PID_REC};
+    ctl_lookup(G.lk[which], rec[which], EAS, h, out);
+}
+static TrimParams trim_params_from(const double* tp, int64_t n, int64_t i) {
+    auto TP = [&](int k) { return tp[k * n + i]; };
+    TrimParams p;
+    p.n_e = {TP(FB_TP_N_E), TP(FB_TP_N_E + 1), TP(FB_TP_N_E + 2)};
+    p.h_e = TP(FB_TP_H_E); p.psi_nb = TP(FB_TP_PSI_NB); p.EAS = TP(FB_TP_EAS); p.gamma_wb_n = TP(FB_TP_GAMMA_WB_N);
+    p.psi_wb_dot = TP(FB_TP_PSI_WB_DOT); p.theta_wb_dot = TP(FB_TP_THETA_WB_DOT); p.beta_a = TP(FB_TP_BETA_A);
+    p.fuel_load = TP(FB_TP_FUEL_LOAD); p.mixture = TP(FB_TP_MIXTURE); p.flaps = TP(FB_TP_FLAPS);
+    for (int k = 0; k < 5; k++) p.payload[k] = TP(FB_TP_PAYLOAD + k);
+    return p;
+}
+// f_init!(aircraft, TrimParameters): trim, actuator states, control-law initialisation. dT = controller sample period.
+int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double* env, const double* blob, double dT, double* x,
+                           double* u, int32_t* ui, int32_t* s, double* cu, double* cs, int32_t* success, double* cost, int32_t threads) {
+    const Env e = env_from(env);
+    CtlGains G; G.bind(blob);
+#ifdef _OPENMP
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        const TrimParams p = trim_params_from(tp, n, i);
+        TrimState t{ts[0 * n + i], ts[1 * n + i], ts[2 * n + i], ts[3 * n + i], ts[4 * n + i], ts[5 * n + i], ts[6 * n + i]};
+        double xi[NXX], cui[FB_NCU] = {}, csi[FB_NCS] = {}, c = 0;
+        C172Inputs in; C172Disc d;
+        const bool ok = c172x_trim_init(*g_model, G, e, p, t, dT, xi, in, d, cui, csi, &c);
+        const double tv[7] = {t.alpha_a, t.phi_nb, t.n_eng, t.throttle, t.aileron, t.elevator, t.rudder};
+        for (int k = 0; k < 7; k++) ts[k * n + i] = tv[k];
+        for (int k = 0; k < NXX; k++) x[k * n + i] = xi[k];
+        inputs_to(in, u, ui, n, i);
+        s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
+        for (int k = 0; k < FB_NCU; k++) cu[k * n + i] = cui[k];
+        for (int k = 0; k < FB_NCS; k++) cs[k * n + i] = csi[k];
+        if (success) success[i] = ok;
+        if (cost) cost[i] = c;
+    }
+    return 0;
+}
+// nsteps x step!(sim) with the control laws every `ratio` steps (step0 = steps already taken since init).
+int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* cu, double* cs,
+                      const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
+                      int32_t threads, double* traj, int64_t save_every) {
+    const Env e = env_from(env);
+    CtlGains G; G.bind(blob);
+#ifdef _OPENMP
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NXX], cui[FB_NCU], csi[FB_NCS];
+        for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
+        for (int k = 0; k < FB_NCU; k++) cui[k] = cu[k * n + i];
+        for (int k = 0; k < FB_NCS; k++) csi[k] = cs[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        const C172Inputs in = inputs_from(u, ui, n, i);
+        C172Y Y;
+        int32_t st = status ? status[i] : 0;
+        int64_t slot = 0;
+        if (traj && save_every > 0) { for (int k = 0; k < NXX; k++) traj[(slot * NXX + k) * n + i] = xi[k]; slot++; }
+        for (int64_t t = 0; t < nsteps; t++) {
+            if (st == 0) st |= c172x_step(*g_model, G, e, in, cui, csi, d, xi, dt, dt * ratio, ((step0 + t + 1) % ratio) == 0, Y);
+            if (traj && save_every > 0 && ((t + 1) % save_every == 0)) {
+                for (int k = 0; k < NXX; k++) traj[(slot * NXX + k) * n + i] = xi[k];
+                slot++;
+            }
+        }
+        for (int k = 0; k < NXX; k++) x[k * n + i] = xi[k];
+        for (int k = 0; k < FB_NCS; k++) cs[k * n + i] = csi[k];
+        s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
+        if (status) status[i] = st;
+    }
+    return 0;
+}
+// f_ode!(world) of the X model: xdot [34 x n], y as Cessna172Sv0
+int32_t fo_c172x_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* cs, const double* env,
+                       double* xdot, double* y, int32_t* status) {
+    const Env e = env_from(env);
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NXX], xd[NXX], csi[FB_NCS], cmd7[7];
+        for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
+        for (int k = 0; k < FB_NCS; k++) csi[k] = cs[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        const C172Inputs in = inputs_from(u, ui, n, i);
+        x2_commands(in, csi, cmd7);
+        C172Y Y;
+        const int32_t st = c172x_f_ode(*g_model, e, in, cmd7, d, xi, xd, Y);
+        if (xdot) for (int k = 0; k < NXX; k++) xdot[k * n + i] = xd[k];
+        if (y) pack_y(Y, y, n, i);
+        if (status) status[i] |= st;
+    }
+    return 0;
+}
+// f_periodic!(Unconditional(), world): the control laws on the y of an f_ode! at the current x
+int32_t fo_c172x_f_periodic(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* cu, double* cs,
+                            const double* env, const double* blob, double dT) {
+    const Env e = env_from(env);
+    CtlGains G; G.bind(blob);
+    for (int64_t i = 0; i < n; i++) {
+        double xi[NXX], xd[NXX], cui[FB_NCU], csi[FB_NCS], cmd7[7];
+        for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
+        for (int k = 0; k < FB_NCU; k++) cui[k] = cu[k * n + i];
+        for (int k = 0; k < FB_NCS; k++) csi[k] = cs[k * n + i];
+        C172Disc d;
+        d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
+        const C172Inputs in = inputs_from(u, ui, n, i);
+        x2_commands(in, csi, cmd7);
+        C172Y Y;
+        c172x_f_ode(*g_model, e, in, cmd7, d, xi, xd, Y);
+        ctl_periodic(G, dT, ctl_in_from(*g_model, Y, xi, cmd7), cui, csi);
+        for (int k = 0; k < FB_NCS; k++) cs[k * n + i] = csi[k];
+    }
+    return 0;
+}
 }  // extern "C"

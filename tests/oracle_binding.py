@@ -18,6 +18,28 @@ def _p(a):
     return a.ctypes.data_as(_D if a.dtype == np.float64 else _I)
 
 
+def header_enums() -> dict:
+    """enum constants of include/flightbatch.h (the layouts the oracle's C API shares with the product)."""
+    import re
+    text = open(os.path.join(ROOT, "include", "flightbatch.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out: dict = {}
+    for body in re.findall(r"enum\s*\{(.*?)\}", text, flags=re.S):
+        val = -1
+        for item in body.split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, expr = [t.strip() for t in item.split("=", 1)]
+                val = int(eval(expr, {}, out))
+            else:
+                name = item
+                val += 1
+            out[name] = val
+    return out
+
+
 class Oracle:
     _lib = None
 
@@ -77,3 +99,48 @@ class Oracle:
         ok = np.zeros(n, np.int32); cost = np.zeros(n)
         self.lib.fo_c172_trim(C.c_int64(n), _p(tp), _p(ts), _p(env), _p(x), _p(u), _p(ui), _p(s), _p(ok), _p(cost), C.c_int32(threads))
         return dict(ts=ts, x=x, u=u, ui=ui, s=s, ok=ok.astype(bool), cost=cost)
+
+
+class OracleX:
+    """Cessna172Xv2 through the oracle (oracle/fo_c172x.hpp). Arrays in ORACLE row order (27 Sv0 rows + 7 actuators)."""
+
+    def __init__(self, oracle: Oracle, blob: np.ndarray):
+        self.o = oracle
+        self.lib = oracle.lib
+        self.blob = np.ascontiguousarray(blob, dtype=np.float64)
+
+    def trim_init(self, tp, ts, env, dT, threads=0):
+        n = tp.shape[1]
+        tp = np.ascontiguousarray(tp); ts = np.array(ts, dtype=np.float64, order="C")
+        x = np.zeros((34, n)); u = np.zeros((16, n)); ui = np.zeros(n, np.int32); s = np.zeros((2, n), np.int32)
+        cu = np.zeros((19, n)); cs = np.zeros((57, n)); ok = np.zeros(n, np.int32); cost = np.zeros(n)
+        self.lib.fo_c172x_trim_init(C.c_int64(n), _p(tp), _p(ts), _p(env), _p(self.blob), C.c_double(dT), _p(x), _p(u), _p(ui), _p(s),
+                                    _p(cu), _p(cs), _p(ok), _p(cost), C.c_int32(threads))
+        return dict(ts=ts, x=x, u=u, ui=ui, s=s, cu=cu, cs=cs, ok=ok.astype(bool), cost=cost)
+
+    def step(self, st, env, dt, ratio, nsteps, threads=0, save_every=0):
+        """Advances the dict `st` (x, u, ui, s, cu, cs, status, nstep) in place."""
+        n = st["x"].shape[1]
+        for k in ("x", "u", "cu", "cs"):
+            st[k] = np.ascontiguousarray(st[k], dtype=np.float64)
+        st["ui"] = np.ascontiguousarray(st["ui"], dtype=np.int32); st["s"] = np.ascontiguousarray(st["s"], dtype=np.int32)
+        st.setdefault("status", np.zeros(n, np.int32)); st.setdefault("nstep", 0)
+        traj = np.zeros((nsteps // save_every + 1, 34, n)) if save_every > 0 else None
+        self.lib.fo_c172x_step(C.c_int64(n), _p(st["x"]), _p(st["u"]), _p(st["ui"]), _p(st["s"]), _p(st["cu"]), _p(st["cs"]), _p(env),
+                               _p(self.blob), C.c_double(dt), C.c_int32(ratio), C.c_int64(st["nstep"]), C.c_int64(nsteps), _p(st["status"]),
+                               C.c_int32(threads), _p(traj), C.c_int64(save_every))
+        st["nstep"] += nsteps
+        return traj
+
+    def f_ode(self, st, env):
+        n = st["x"].shape[1]
+        xd = np.zeros((34, n)); y = np.zeros((174, n)); status = np.zeros(n, np.int32)
+        self.lib.fo_c172x_f_ode(C.c_int64(n), _p(np.ascontiguousarray(st["x"])), _p(np.ascontiguousarray(st["u"])), _p(st["ui"]), _p(st["s"]),
+                                _p(np.ascontiguousarray(st["cs"])), _p(env), _p(xd), _p(y), _p(status))
+        return xd, y, status
+
+    def f_periodic(self, st, env, dT):
+        n = st["x"].shape[1]
+        st["cs"] = np.ascontiguousarray(st["cs"], dtype=np.float64)
+        self.lib.fo_c172x_f_periodic(C.c_int64(n), _p(np.ascontiguousarray(st["x"])), _p(np.ascontiguousarray(st["u"])), _p(st["ui"]), _p(st["s"]),
+                                     _p(np.ascontiguousarray(st["cu"])), _p(st["cs"]), _p(env), _p(self.blob), C.c_double(dT))
