@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "tables.h"
 #include "../../include/flightbatch.h"
 
@@ -270,6 +271,7 @@ constexpr double fuel_r[2][3] = {{0.325, -2.845, 0.0}, {0.325, 2.845, 0.0}};
 constexpr double m_full = 114.4, m_res = 1.0;
 }  // namespace c172
 
+FBD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 struct Env {  // fb_params subset, wave-uniform (SGPRs)
     double T_sl, p_sl, wind_n, wind_e, wind_d, h_trn;
     int surface;
@@ -291,6 +293,10 @@ struct Inputs {
     FBD double get_throttle() const { return throttle; }
     FBD double get_mixture() const { return mixture; }
     FBD double get_m_pld(int k) const { return m_pld[k]; }
+    FBD double get_steering() const {
+        return u_glob ? clampd(clampd(u_glob[FB_U_RUDDER * n], -1, 1) + clampd(u_glob[FB_U_RUDDER_OFFSET * n], -1, 1), -1, 1) : 0.0;
+    }
+    FBD double get_brake(int g) const { return u_glob ? clampd(u_glob[(g == 0 ? FB_U_BRAKE_LEFT : FB_U_BRAKE_RIGHT) * n], 0, 1) : 0.0; }
 };
 // The same eleven values parked in an LDS panel [11][STRIDE] (row = quantity, column = lane) and read at the
 // point of use: the stepping kernel cannot afford 22 VGPRs for values that are touched once per RHS.
@@ -307,6 +313,10 @@ struct InputsLds {
     FBD double get_throttle() const { return p[4 * STRIDE]; }
     FBD double get_mixture() const { return p[5 * STRIDE]; }
     FBD double get_m_pld(int k) const { return p[(6 + k) * STRIDE]; }
+    FBD double get_steering() const {
+        return u_glob ? clampd(clampd(u_glob[FB_U_RUDDER * n], -1, 1) + clampd(u_glob[FB_U_RUDDER_OFFSET * n], -1, 1), -1, 1) : 0.0;
+    }
+    FBD double get_brake(int g) const { return u_glob ? clampd(u_glob[(g == 0 ? FB_U_BRAKE_LEFT : FB_U_BRAKE_RIGHT) * n], 0, 1) : 0.0; }
     FBD void store(lds_ptr q, const Inputs& in) {
         q[0 * STRIDE] = in.de; q[1 * STRIDE] = in.da; q[2 * STRIDE] = in.dr; q[3 * STRIDE] = in.df;
         q[4 * STRIDE] = in.throttle; q[5 * STRIDE] = in.mixture;
@@ -316,7 +326,29 @@ struct InputsLds {
     }
 };
 constexpr int INPUT_PANEL_ROWS = 11;
-FBD double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+// Cessna172X (fly-by-wire): surfaces, throttle, nose-wheel steering and brakes follow the actuator POSITIONS, which are
+// states (device rows 27..33: throttle, aileron, elevator, rudder, flaps, brake_left, brake_right), saturated to their
+// Ranged type on the way out (Actuator1.f_ode!: pos = R(x.p), c172x.jl:45; assign!, c172x.jl:127-143: aero.u.e = -elevator.pos,
+// aero.u.a = aileron.pos, aero.u.r = -rudder.pos, aero.u.f = flaps.pos, throttle, steering = rudder.pos, brakes).
+// Mixture and payload are launch constants read from global memory at the point of use (L1/L2 resident).
+constexpr int X2_ACT = FB_NX;  // device row of the first actuator position
+struct InputsX {
+    const double* xa;      // the seven actuator positions of the state being evaluated (caller's registers)
+    const double* u_glob;  // &u[0 * n + i]
+    int64_t n;
+    int ui;
+    FBD double pos(int k) const { return clampd(xa[k], (k == FB_ACT_THROTTLE || k >= FB_ACT_FLAPS) ? 0.0 : -1.0, 1.0); }
+    FBD double get_de() const { return c172::de_lo + (c172::de_hi - c172::de_lo) / 2 * (clampd(-pos(FB_ACT_ELEVATOR), -1, 1) + 1); }
+    FBD double get_da() const { return c172::da_lo + (c172::da_hi - c172::da_lo) / 2 * (clampd(pos(FB_ACT_AILERON), -1, 1) + 1); }
+    FBD double get_dr() const { return c172::dr_lo + (c172::dr_hi - c172::dr_lo) / 2 * (clampd(-pos(FB_ACT_RUDDER), -1, 1) + 1); }
+    FBD double get_df() const { return c172::df_lo + (c172::df_hi - c172::df_lo) / 1 * (clampd(pos(FB_ACT_FLAPS), 0, 1) - 0); }
+    FBD double get_throttle() const { return pos(FB_ACT_THROTTLE); }
+    FBD double get_mixture() const { return clampd(u_glob[FB_U_MIXTURE * n], 0, 1); }
+    FBD double get_m_pld(int k) const { return clampd(u_glob[(FB_U_M_PILOT + k) * n], 0, 100); }
+    FBD double get_steering() const { return pos(FB_ACT_RUDDER); }
+    FBD double get_brake(int g) const { return pos(g == 0 ? FB_ACT_BRAKE_LEFT : FB_ACT_BRAKE_RIGHT); }
+};
+constexpr double ACT_TAU = 1.0 / 20;  // Actuator1 time constant, c172x.jl:21
 // mechanical actuation + Ranged saturation + linear_scaling, from the raw FB_U_* inputs
 FBD void make_inputs(Inputs& in, const double* u, int64_t stride, int ui) {
     using namespace c172;
@@ -379,14 +411,32 @@ __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& 
 // Every derivative component is handed to `emit(index, value)` the moment it is known, so that the
 // caller can consume it at once (the stepping kernel folds it into the RK stage sums in LDS) instead of
 // keeping a 27-double array alive across the whole evaluation.
-template <bool WITH_Y, class Emit, class In>
-FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in, const Env& env, const Tables& T,
-                Emit&& emit, StepAux& aux, double* Y, int64_t n) {
+// Output sinks: where the components of the output record y go.
+//   NoSink    — nowhere (the stepping kernel): everything that only feeds y is dead code;
+//   PanelSink — the full record into a global [FB_NY x n] panel (f_ode!, logging);
+//   a partial sink (enabled, !full) picks a few components — the control laws' inputs — and still allows the
+//   shortcuts that a full record forbids.
+struct NoSink {
+    static constexpr bool enabled = false, full = false;
+    FBD void put(int, double) const {}
+};
+struct PanelSink {
+    static constexpr bool enabled = true, full = true;
+    double* Y;   // &y[0 * n + i]
+    int64_t n;
+    FBD void put(int k, double v) const { Y[(int64_t)k * n] = v; }
+};
+template <class Sink, class Emit, class In, int NXT>
+FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, const Env& env, const Tables& T,
+                Emit&& emit, StepAux& aux, Sink&& sink) {
     using namespace c172;
+    using SinkT = typename std::remove_reference<Sink>::type;
+    constexpr bool WITH_Y = SinkT::enabled;
+    constexpr int NC = SinkT::full ? PR_NC : PR_NC_STEP;   // propeller table stride in LDS (see stage_tables)
     int32_t st = 0;
-    auto YP = [&](int k, double v) { if (WITH_Y) Y[(int64_t)k * n] = v; };
-    auto YP3 = [&](int k, v3 v) { if (WITH_Y) { Y[(int64_t)k * n] = v.x; Y[(int64_t)(k + 1) * n] = v.y; Y[(int64_t)(k + 2) * n] = v.z; } };
-    auto YP4 = [&](int k, quat q) { if (WITH_Y) { Y[(int64_t)k * n] = q.w; Y[(int64_t)(k + 1) * n] = q.x; Y[(int64_t)(k + 2) * n] = q.y; Y[(int64_t)(k + 3) * n] = q.z; } };
+    auto YP = [&](int k, double v) { if (WITH_Y) sink.put(k, v); };
+    auto YP3 = [&](int k, v3 v) { if (WITH_Y) { sink.put(k, v.x); sink.put(k + 1, v.y); sink.put(k + 2, v.z); } };
+    auto YP4 = [&](int k, quat q) { if (WITH_Y) { sink.put(k, q.w); sink.put(k + 1, q.x); sink.put(k + 2, q.y); sink.put(k + 3, q.z); } };
 
     // ===== kinematics: wander-azimuth mechanisation (FlightPhysics/src/kinematics.jl:181-223) =====
     const quat q_wb = {x[FB_X_Q_WB], x[FB_X_Q_WB + 1], x[FB_X_Q_WB + 2], x[FB_X_Q_WB + 3]};
@@ -546,8 +596,8 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in
     // High-clearance shortcut (exact for the state): every strut attachment is within 2.3 m of Ob and the geoid
     // moves by < 1 mm over that distance, so when Ob is more than 10 m above the terrain no wheel can touch it:
     // wow = false, zero wrench, regulator input 0 (landinggear.jl:255-258, 418-424) without evaluating the three
-    // ECEF->geodetic conversions and geoid gathers. Not taken when the output record (which logs Δh) is requested.
-    const bool high_clearance = !WITH_Y && (h_o - env.h_trn > 10.0);
+    // ECEF->geodetic conversions and geoid gathers. Not taken when the FULL output record (which logs Δh) is requested.
+    const bool high_clearance = !SinkT::full && (h_o - env.h_trn > 10.0);
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         FB_PHASE_FENCE();
@@ -576,14 +626,9 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in
             gi.w_eb_b = w_eb_b; gi.v_eb_b = v_eb_b; gi.loc_Ot = loc_Ot; gi.he_Ot = he_Ot;
             gi.g = g; gi.surface = env.surface;
             gi.steer_engaged = (in.ui & FB_UI_STEERING_ENGAGED) ? 1 : 0;
-            // ground-only inputs, fetched on demand (c172s.jl:107-110)
-            gi.steer_in = 0.0;
-            gi.brake_in = 0.0;
-            if (in.u_glob) {
-                const double* ug = in.u_glob;
-                if (g == 2) gi.steer_in = clampd(clampd(ug[FB_U_RUDDER * in.n], -1, 1) + clampd(ug[FB_U_RUDDER_OFFSET * in.n], -1, 1), -1, 1);
-                else gi.brake_in = clampd(ug[(g == 0 ? FB_U_BRAKE_LEFT : FB_U_BRAKE_RIGHT) * in.n], 0, 1);
-            }
+            // ground-only inputs, fetched on demand (c172s.jl:107-110; c172x.jl:139-141)
+            gi.steer_in = (g == 2) ? in.get_steering() : 0.0;
+            gi.brake_in = (g == 2) ? 0.0 : in.get_brake(g);
             gear_ground_kinematics(gi, go);
             v_xy0 = go.v_xy0; v_xy1 = go.v_xy1;
             st |= go.st;
@@ -625,10 +670,10 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in
         const double Mt = fabs(w_prop) * (prop_d / 2) / a_snd;
         const loc lj = range_locate(0.0, 1.5, PR_NJ, J_adv, true);
         const loc lm = range_locate(0.0, 1.5, PR_NM, Mt, true);
-        lds_cptr c00 = PR + (lj.i + PR_NJ * lm.i) * PR_NC;
-        lds_cptr c10 = c00 + PR_NC;
-        lds_cptr c01 = c00 + PR_NJ * PR_NC;
-        lds_cptr c11 = c01 + PR_NC;
+        lds_cptr c00 = PR + (lj.i + PR_NJ * lm.i) * NC;
+        lds_cptr c10 = c00 + NC;
+        lds_cptr c01 = c00 + PR_NJ * NC;
+        lds_cptr c11 = c01 + NC;
         const double w00 = (1 - lj.w) * (1 - lm.w), w01 = (1 - lj.w) * lm.w, w10 = lj.w * (1 - lm.w), w11 = lj.w * lm.w;
         auto coef = [&](int cidx) { return (w00 * c00[cidx] + w01 * c01[cidx]) + (w10 * c10[cidx] + w11 * c11[cidx]); };
         const double C_Fx = coef(0), C_Mx = coef(1), C_Fz_a = coef(2), C_Mz_a = coef(3);
@@ -697,7 +742,7 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in
             YP(k, MAP); YP(k + 1, f_ar); YP(k + 2, mdot); YP(k + 3, w_eng); YP(k + 4, tau_shaft); YP(k + 5, P_shaft); YP(k + 6, SFC);
             YP(k + 7, out_idle); YP(k + 8, out_frc);
             YP(k + 9, J_adv); YP(k + 10, Mt); YP3(k + 11, F_p); YP3(k + 14, tau_pb); YP3(k + 17, h_rot);
-            YP(k + 20, rho * fabs(fr * fr2) * d5 * coef(4)); YP(k + 21, coef(5));
+            if constexpr (SinkT::full) { YP(k + 20, rho * fabs(fr * fr2) * d5 * coef(4)); YP(k + 21, coef(5)); }
         }
     }
 
@@ -788,8 +833,8 @@ FBD int32_t rhs(const double (&x)[FB_NX], int stall, int eng_state, const In& in
 // f_step!(world): kinematics renormalisation, stall hysteresis, contact-regulator reset, crash checks,
 // engine state machine (aircraftbase.jl:172-181; kinematics.jl:226-229,114-118; c172.jl:375-384,715-724;
 // landinggear.jl:331-347,479-483; piston.jl:428-453). Returns true when x or s changed.
-template <class In>
-FBD bool f_step(double (&x)[FB_NX], int& stall, int& eng_state, const In& in, const StepAux& aux, int32_t& st) {
+template <class In, int NXT>
+FBD bool f_step(double (&x)[NXT], int& stall, int& eng_state, const In& in, const StepAux& aux, int32_t& st) {
     bool mod = false;
     {
         const double n2 = x[FB_X_Q_WB] * x[FB_X_Q_WB] + x[FB_X_Q_WB + 1] * x[FB_X_Q_WB + 1] + x[FB_X_Q_WB + 2] * x[FB_X_Q_WB + 2] + x[FB_X_Q_WB + 3] * x[FB_X_Q_WB + 3];

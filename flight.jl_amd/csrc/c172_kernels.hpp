@@ -103,7 +103,7 @@ __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& 
 
 // ---- kernel arguments -----------------------------------------------------------------------
 struct KArgs {
-    double* x;          // [FB_NX x n]
+    double* x;          // [NX x n]  (NX = 27, or 34 for Cessna172X: rows 27..33 = actuator positions)
     int32_t* s;         // [FB_NS x n]
     const double* u;    // [FB_NU x n]
     const int32_t* ui;  // [n]
@@ -113,12 +113,20 @@ struct KArgs {
     int64_t n;
     Env env;
     double dt;
+    // Cessna172X only
+    double* cs;         // [FB_NCS x n] control-law record (actuator commands live here)
+    const double* cu;   // [FB_NCU x n] control-law inputs
+    double* q_pre;      // [8 x n] q_wb, q_ew of the last evaluation before f_step! (what the periodic update must see)
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
 
+// Stage the [aero | piston | propeller] blob into LDS. NC = propeller coefficients kept per grid point: all six when the
+// full output record is produced, the first four (C_Fx, C_Mx, C_Fz_α, C_Mz_α) otherwise — 7 KB of LDS less.
+template <int NC>
 FBD void stage_tables(double* lds, double* rk, const double* tables) {
-    for (int k = threadIdx.x; k < LDS_TABLE_DOUBLES; k += blockDim.x) lds[k] = tables[k];
+    for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = tables[k];
+    for (int k = threadIdx.x; k < PR_NJ * PR_NM * NC; k += blockDim.x) lds[LDS_PROP + k] = tables[LDS_PROP + (k / NC) * PR_NC + (k % NC)];
     __syncthreads();
     // reciprocal knot spacings for every position of the aero|piston blob (only knot positions are ever read)
     for (int k = threadIdx.x; k < LDS_RK_DOUBLES; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
@@ -129,47 +137,83 @@ FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
     in.u_glob = a.u + i;
     in.n = a.n;
 }
+// Cessna172X: the seven actuator commands in force — the four control-law outputs (assign!, c172x_ctl.jl:449-458, 986-995)
+// and the flaps / brake commands of u — saturated to the actuators' Ranged input types (c172x.jl:113-119)
+FBD double x2_command(const KArgs& a, int64_t i, int k) {
+    const int64_t n = a.n;
+    switch (k) {
+        case FB_ACT_THROTTLE: return clampd(a.cs[(int64_t)FB_CS_THROTTLE_CMD * n + i], 0, 1);
+        case FB_ACT_AILERON: return clampd(a.cs[(int64_t)FB_CS_AILERON_CMD * n + i], -1, 1);
+        case FB_ACT_ELEVATOR: return clampd(a.cs[(int64_t)FB_CS_ELEVATOR_CMD * n + i], -1, 1);
+        case FB_ACT_RUDDER: return clampd(a.cs[(int64_t)FB_CS_RUDDER_CMD * n + i], -1, 1);
+        case FB_ACT_FLAPS: return clampd(a.u[(int64_t)FB_U_FLAPS * n + i], 0, 1);
+        case FB_ACT_BRAKE_LEFT: return clampd(a.u[(int64_t)FB_U_BRAKE_LEFT * n + i], 0, 1);
+        default: return clampd(a.u[(int64_t)FB_U_BRAKE_RIGHT * n + i], 0, 1);
+    }
+}
+template <bool X> struct Dims { static constexpr int NXT = X ? (int)FB_X2_NX : (int)FB_NX; };
 
 // f_ode!(world): xdot (optional) and the output record y
+template <bool X>
 __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y) {
+    constexpr int NXT = Dims<X>::NXT;
     __shared__ double lds[LDS_TABLE_DOUBLES];
     __shared__ double rk[LDS_RK_DOUBLES];
-    stage_tables(lds, rk, a.tables);
+    stage_tables<PR_NC>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
-    double x[FB_NX], xd[FB_NX];
+    double x[NXT], xd[NXT];
 #pragma unroll
-    for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
-    Inputs in;
-    load_inputs(a, i, in);
+    for (int k = 0; k < NXT; k++) x[k] = a.x[(int64_t)k * a.n + i];
     StepAux aux;
-    const int32_t st = rhs<true>(x, a.s[i], a.s[a.n + i], in, a.env, T, [&](int j, double v) { xd[j] = v; }, aux, y + i, a.n);
+    auto emit = [&](int j, double v) { xd[j] = v; };
+    int32_t st;
+    if constexpr (X) {
+        const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
+        st = rhs(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+#pragma unroll
+        for (int k = 0; k < FB_NACT; k++) xd[X2_ACT + k] = 1 / ACT_TAU * (x2_command(a, i, k) - x[X2_ACT + k]);   // Actuator1.f_ode!, c172x.jl:39-52
+    } else {
+        Inputs in;
+        load_inputs(a, i, in);
+        st = rhs(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+    }
     if (xdot) {
 #pragma unroll
-        for (int k = 0; k < FB_NX; k++) xdot[(int64_t)k * a.n + i] = xd[k];
+        for (int k = 0; k < NXT; k++) xdot[(int64_t)k * a.n + i] = xd[k];
     }
     a.status[i] |= st;
 }
 
 // f_step!(world). The reference acts on the y left behind by the last f_ode!; f_ode! is a pure
 // function of (x,u,s), so it is recomputed here from the current x.
+template <bool X>
 __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
-    __shared__ double lds[LDS_TABLE_DOUBLES];
+    constexpr int NXT = Dims<X>::NXT;
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
-    stage_tables(lds, rk, a.tables);
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
-    double x[FB_NX], xd[FB_NX];
+    double x[NXT], xd[NXT];
 #pragma unroll
-    for (int k = 0; k < FB_NX; k++) x[k] = a.x[(int64_t)k * a.n + i];
-    Inputs in;
-    load_inputs(a, i, in);
+    for (int k = 0; k < NXT; k++) x[k] = a.x[(int64_t)k * a.n + i];
     int stall = a.s[i], eng = a.s[a.n + i];
     StepAux aux;
-    int32_t st = rhs<false>(x, stall, eng, in, a.env, T, [&](int j, double v) { xd[j] = v; }, aux, nullptr, 0);
-    f_step(x, stall, eng, in, aux, st);
+    auto emit = [&](int j, double v) { xd[j] = v; };
+    int32_t st;
+    if constexpr (X) {
+        const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
+        st = rhs(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        f_step(x, stall, eng, in, aux, st);
+    } else {
+        Inputs in;
+        load_inputs(a, i, in);
+        st = rhs(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        f_step(x, stall, eng, in, aux, st);
+    }
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * a.n + i] = x[k];
     a.s[i] = stall;
@@ -182,63 +226,53 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 // Registers are the limiter of this kernel: VALU instructions address 256 VGPRs (the AGPR half of the
 // file is only a spill cache), one fp64 value takes two, and a single RHS keeps ~200 fp64 values alive.
 // So the RK4 bookkeeping does not live in registers at all:
-//   * per lane, x_n (27 doubles) and the running stage sum (27 doubles) sit in two [27][256] LDS panels
-//     (lane-contiguous rows: conflict-free ds_read_b64/ds_write_b64). LDS per workgroup: 25 KB of tables
-//     + 108 KB of panels = one 256-lane workgroup per CU, one wave per SIMD;
+//   * per lane, x_n (NX doubles) and the running stage sum (NX doubles) sit in two [NX][256] LDS panels
+//     (lane-contiguous rows: conflict-free ds_read_b64/ds_write_b64). LDS per workgroup: 22 KB of tables
+//     + 108 KB (NX = 27) or 136 KB (NX = 34) of panels = one 256-lane workgroup per CU, one wave per SIMD;
 //   * the stage update is fused INTO the RHS: each derivative k_j is consumed the moment it is produced
-//     (acc_j += w k_j in LDS, x_next_j = x_n,j + c dt k_j), so no k[27] array is ever alive.
+//     (acc_j += w k_j in LDS, x_next_j = x_n,j + c dt k_j), so no k[NX] array is ever alive.
 // Stage sum: acc = k1 + 2 k2 + 2 k3, x_{n+1} = x_n + dt/6 (acc + k4) — the classic RK4 combination
 // (OrdinaryDiffEq writes it as dt/6 (2 (k2 + k3) + (k1 + k4)); same value up to the last bit).
+// X = Cessna172X: seven more states (first-order actuators driven by the commands in cs / u, constant during a
+// launch: the control laws run between launches), inputs derived from the actuator positions; with 34 rows per panel
+// there is no LDS left for an input panel, so mixture / payload / commands are read from global memory (L1/L2 hits).
+template <bool X>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
-    __shared__ double lds[LDS_TABLE_DOUBLES];
+    constexpr int NXT = Dims<X>::NXT;
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
-    __shared__ double xs_l[FB_NX * STEP_BLOCK];   // x_n
-    __shared__ double acc_l[FB_NX * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
-#ifndef FB_INPUTS_IN_REGS
-    __shared__ double in_l[INPUT_PANEL_ROWS * STEP_BLOCK];  // per-lane inputs, read at the point of use
-#endif
-    stage_tables(lds, rk, a.tables);
+    __shared__ double xs_l[NXT * STEP_BLOCK];   // x_n
+    __shared__ double acc_l[NXT * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
+    __shared__ double in_l[X ? 8 : INPUT_PANEL_ROWS * STEP_BLOCK];  // Sv0: per-lane inputs, read at the point of use
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (a.status[i] != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
     bool dead = false;             // a status bit was raised during this launch (bits go straight to memory: rare)
     const int t = threadIdx.x;
-    double xt[FB_NX];
+    double xt[NXT];
 #pragma unroll
-    for (int k = 0; k < FB_NX; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
-#ifdef FB_INPUTS_IN_REGS
-    Inputs in;
-    load_inputs(a, i, in);
-#else
+    for (int k = 0; k < NXT; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
     InputsLds<STEP_BLOCK> in;
-    {
+    if constexpr (!X) {
         Inputs in_r;
         load_inputs(a, i, in_r);
         in.store((lds_ptr)in_l + t, in_r);
     }
-#endif
+    const int ui = a.ui[i];
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     int stage = 0, step = 0;
     bool pending_cb = false;
 #pragma unroll 1
     while (true) {
-        double xn[FB_NX];
+        double xn[NXT];
         StepAux aux;
-        // Opaque (always zero) LDS offset: without it LICM hoists every loop-invariant table load
-        // (~150 knots/values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
+        // Opaque (always zero) offsets: without them LICM hoists every loop-invariant table / input load
+        // (~150 knots and values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
-        // the per-lane inputs are read from their LDS panel at the point of use (same opaque offset: no hoisting)
-#ifdef FB_INPUTS_IN_REGS
-        Inputs inl = in;
-        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
-        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
-#else
-        InputsLds<STEP_BLOCK> inl = in;
-        inl.p = in.p + lds_off;
-#endif
         const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
         auto emit = [&](int j, double kj) {
             const int idx = j * STEP_BLOCK + t;
@@ -257,10 +291,30 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         };
         // NB: a stage-3 emit overwrites x_n in LDS component by component; the RHS itself reads its state
         // from the registers xt[], never from the panel, so this is safe.
-        int32_t bits = rhs<false>(xt, stall, eng, inl, a.env, T, emit, aux, nullptr, 0);
-        if (stage == 0 && pending_cb) {  // this evaluation sits at x_{n+1} (= xt): run the discrete callbacks on it
+        int32_t bits;
+        bool mod = false;
+        if constexpr (X) {
+            const InputsX inl = {&xt[X2_ACT], a.u + i + lds_off, a.n, ui};
+            bits = rhs(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            KArgs ao = a;
+            ao.cs = a.cs + lds_off; ao.u = a.u + lds_off;
+#pragma unroll
+            for (int k = 0; k < FB_NACT; k++) emit(X2_ACT + k, 1 / ACT_TAU * (x2_command(ao, i, k) - xt[X2_ACT + k]));
+            if (stage == 0 && pending_cb) {
+                if (step + 1 == nsteps && a.q_pre) {   // what the control laws will see: the state of THIS evaluation
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a.q_pre[(int64_t)k * a.n + i] = xt[FB_X_Q_WB + k];
+                }
+                mod = f_step(xt, stall, eng, inl, aux, bits);
+            }
+        } else {
+            InputsLds<STEP_BLOCK> inl = in;
+            inl.p = in.p + lds_off;
+            bits = rhs(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (stage == 0 && pending_cb) mod = f_step(xt, stall, eng, in, aux, bits);
+        }
+        if (stage == 0 && pending_cb) {  // this evaluation sat at x_{n+1} (= xt): the discrete callbacks have run on it
             pending_cb = false;
-            const bool mod = f_step(xt, stall, eng, in, aux, bits);
             step++;
             if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
             if (mod) {
@@ -272,16 +326,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         }
         if (bits != 0) { a.status[i] |= bits; dead = true; }
 #pragma unroll
-        for (int j = 0; j < FB_NX; j++) xt[j] = xn[j];
+        for (int j = 0; j < NXT; j++) xt[j] = xn[j];
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xt[j]);
+    for (int j = 0; j < NXT; j++) bad = bad || !isfinite(xt[j]);
     if (bad) a.status[i] |= FB_ST_NAN;
 #pragma unroll
-    for (int j = 0; j < FB_NX; j++) a.x[(int64_t)j * a.n + i] = xt[j];
+    for (int j = 0; j < NXT; j++) a.x[(int64_t)j * a.n + i] = xt[j];
     a.s[i] = stall;
     a.s[a.n + i] = eng;
 }
@@ -361,7 +415,7 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
     double uraw[FB_NU];
     trim_assign(p, z, env, T, x, in, uraw);
     StepAux aux;
-    rhs<false>(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, nullptr, 0);
+    rhs(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, NoSink{});
     const double nv = sqrt(x[FB_X_V_EB_B] * x[FB_X_V_EB_B] + x[FB_X_V_EB_B + 1] * x[FB_X_V_EB_B + 1] + x[FB_X_V_EB_B + 2] * x[FB_X_V_EB_B + 2]);
     r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
@@ -372,9 +426,9 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
 // bounded, damped Newton iteration on the 7 residuals with a central-difference Jacobian — a batched,
 // branch-light solver that maps onto one lane per aircraft.
 __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out) {
-    __shared__ double lds[LDS_TABLE_DOUBLES];
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
-    stage_tables(lds, rk, a.tables);
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};

@@ -1,0 +1,284 @@
+// c172x_ctl_device.hpp — the Cessna172X gain-scheduled control laws, one aircraft per lane, run every Δt.
+//
+// Reference (relative to lib/): FlightApps/src/c172/c172x/control/c172x_ctl.jl:203-447 (ControlLawsLon), :463-519 (its
+// f_init!), :814-979 (ControlLawsLat), :1000-1032 (its f_init!), :46-77, :735-741 (which compensators a mode enables);
+// FlightPhysics/src/control.jl:161-183 (Integrator), :431-471 (PID), :708-743 (LQR), :950-994 (gain lookups: linear in
+// (EAS, h_e), Flat extrapolation); c172x2.jl:27-50 (Avionics: guidance in `direct` mode is a no-op).
+// Per-aircraft data lives in global memory, structure-of-arrays: inputs cu [FB_NCU x n], record cs [FB_NCS x n]
+// (include/flightbatch.h). The update runs ~1-2 k flops once per Δt, against ~12 k flops per RK4 step: it is kept in its
+// own small kernel (k_x2_ctl) so that the stepping kernel's register budget is untouched; lanes of one wave may sit in
+// different modes — the branches below are the price, paid once per Δt.
+#pragma once
+#include "c172_device.hpp"
+
+namespace fbd {
+
+struct CtlTab {
+    const double* lk[10];  // te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ lookups inside the FB_TABLE_CTL_GAINS blob (global memory)
+};
+struct CtlMem {
+    const double* cu;  // &cu[0 * n + i]
+    double* cs;        // &cs[0 * n + i]
+    int64_t n;
+    FBD double U(int k) const { return cu[(int64_t)k * n]; }
+    FBD double& S(int k) const { return cs[(int64_t)k * n]; }
+};
+// what the control laws read from vehicle.y (XLonRed/XLonFull/XLatRed, Zte/Ztv/Zvh/Zφβ/Zar: c172x_ctl.jl:84-199, 745-810)
+struct CtlIn {
+    double EAS, h_e, theta, phi, clm, chi;
+    v3 w_wb_b, w_eb_b;
+    double alpha, beta, alpha_filt, beta_filt, n_eng;
+    double pos[4];  // throttle, aileron, elevator, rudder positions (Ranged)
+    double cmd[4];  // idem, the commands the last f_ode! saw
+    bool on_gnd;
+};
+// the few output-record components the control laws need, tapped from rhs()
+struct CtlSink {
+    static constexpr bool enabled = true, full = false;
+    double theta, phi, wx, wy, wz, vd, chi, EAS, alpha, beta;
+    FBD void put(int k, double v) {
+        if (k == FB_Y_KIN + 1) theta = v;
+        else if (k == FB_Y_KIN + 2) phi = v;
+        else if (k == FB_Y_KIN + 25) wx = v;
+        else if (k == FB_Y_KIN + 26) wy = v;
+        else if (k == FB_Y_KIN + 27) wz = v;
+        else if (k == FB_Y_KIN + 36) vd = v;
+        else if (k == FB_Y_KIN + 38) chi = v;
+        else if (k == FB_Y_AIR + 20) EAS = v;
+        else if (k == FB_Y_AERO) alpha = v;
+        else if (k == FB_Y_AERO + 1) beta = v;
+    }
+};
+
+FBD double sgnd(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
+constexpr double CTL_INF = __builtin_huge_val();
+
+// ---- gain lookup: bilinear over the (EAS, h) grid, record by record -------------------------------------------
+template <int REC>
+FBD void ctl_lookup(const double* lk, double EAS, double h, double (&out)[REC]) {
+    const int nE = (int)lk[0], nH = (int)lk[1];
+    int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
+    double wE = 0, wH = 0;
+    if (nE > 1) {
+        const double xi = (fmin(fmax(EAS, lk[2]), lk[3]) - lk[2]) / ((lk[3] - lk[2]) / (nE - 1));
+        i0 = min(max((int)floor(xi), 0), nE - 2); i1 = i0 + 1; wE = xi - i0;
+    }
+    if (nH > 1) {
+        const double xj = (fmin(fmax(h, lk[4]), lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
+        j0 = min(max((int)floor(xj), 0), nH - 2); j1 = j0 + 1; wH = xj - j0;
+    }
+    const double* d = lk + FB_CTL_GRID_HDR;
+    const double* a00 = d + (size_t)(i0 + nE * j0) * REC;
+    const double* a10 = d + (size_t)(i1 + nE * j0) * REC;
+    const double* a01 = d + (size_t)(i0 + nE * j1) * REC;
+    const double* a11 = d + (size_t)(i1 + nE * j1) * REC;
+#pragma unroll
+    for (int c = 0; c < REC; c++) out[c] = (1 - wE) * ((1 - wH) * a00[c] + wH * a01[c]) + wE * ((1 - wH) * a10[c] + wH * a11[c]);
+}
+
+// ---- compensators; their states are rows of the cs record ------------------------------------------------------
+struct PidGains { double k_p, k_i, k_d, tau_f; };
+FBD PidGains pid_gains(const double* lk, double EAS, double h) {
+    double g[FB_CTL_PID_REC];
+    ctl_lookup<FB_CTL_PID_REC>(lk, EAS, h, g);
+    return {g[0], g[1], g[2], g[3]};
+}
+// PID f_periodic! (β_p = β_d = 1); rows s0 .. s0+2 = x_i0, x_d0, sat_out_0
+FBD double pid_run(const CtlMem& M, int s0, const PidGains& P, double lo, double hi, double dT, double input, double sat_ext) {
+    const double x_i0 = M.S(s0), x_d0 = M.S(s0 + 1), sat0 = M.S(s0 + 2);
+    const double a = 1 / (P.tau_f + dT);
+    const bool halted = (sgnd(input * sat0) > 0) || (sgnd(input * sat_ext) > 0);
+    const double x_i = x_i0 + dT * P.k_i * input * (halted ? 0.0 : 1.0);
+    const double x_d = a * P.tau_f * x_d0 + dT * a * P.k_d * input;
+    const double out_free = P.k_p * input + x_i + a * (-x_d0 + P.k_d * input);
+    M.S(s0) = x_i; M.S(s0 + 1) = x_d;
+    M.S(s0 + 2) = (out_free >= hi ? 1.0 : 0.0) - (out_free <= lo ? 1.0 : 0.0);
+    return fmin(fmax(out_free, lo), hi);
+}
+FBD void pid_init(const CtlMem& M, int s0, const PidGains& P, double lo, double hi, double dT) {
+    M.S(s0) = 0; M.S(s0 + 1) = 0; M.S(s0 + 2) = 0;
+    pid_run(M, s0, P, lo, hi, dT, 0.0, 0.0);
+}
+// Integrator f_periodic!, unbounded; rows s0, s0+1 = x0, sat_out_0
+FBD double integ_run(const CtlMem& M, int s0, double dT, double input, double sat_ext) {
+    const bool halted = (sgnd(input * M.S(s0 + 1)) > 0) || (sgnd(input * sat_ext) > 0);
+    const double x1 = M.S(s0) + dT * input * (halted ? 0.0 : 1.0);
+    M.S(s0) = x1;
+    M.S(s0 + 1) = (x1 >= CTL_INF ? 1.0 : 0.0) - (x1 <= -CTL_INF ? 1.0 : 0.0);
+    return x1;
+}
+FBD void integ_init(const CtlMem& M, int s0, double dT) { M.S(s0) = 0; M.S(s0 + 1) = 0; integ_run(M, s0, dT, 0.0, 0.0); }
+// LQR{NX,2,2} f_periodic!; g = [K_fbk 2xNX column-major | K_fwd 2x2 | K_int 2x2 | x_trim | u_trim | z_trim];
+// rows s0 .. s0+3 = int_out_0[2], out_sat_0[2]; sat_ext is never set by the control laws
+template <int NX>
+FBD void lqr_run(const CtlMem& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT, const double (&x)[NX],
+                 const double (&z)[2], const double (&z_ref)[2], double (&out)[2]) {
+    const double* K_fbk = g; const double* K_fwd = g + 2 * NX; const double* K_int = K_fwd + 4;
+    const double* x_trim = K_int + 4; const double* u_trim = x_trim + NX; const double* z_trim = u_trim + 2;
+    const double dz0 = z_ref[0] - z[0], dz1 = z_ref[1] - z[1], dt0 = z_ref[0] - z_trim[0], dt1 = z_ref[1] - z_trim[1];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double int_in = K_int[i] * dz0 + K_int[i + 2] * dz1;
+        const bool halted = sgnd(int_in * M.S(s0 + 2 + i)) > 0;
+        const double int_out = M.S(s0 + i) + dT * int_in * (halted ? 0.0 : 1.0);
+        const double fwd = K_fwd[i] * dt0 + K_fwd[i + 2] * dt1;
+        double fbk = K_fbk[i] * (x[0] - x_trim[0]);
+#pragma unroll
+        for (int k = 1; k < NX; k++) fbk += K_fbk[i + 2 * k] * (x[k] - x_trim[k]);
+        const double out_free = u_trim[i] + int_out + fwd - fbk;
+        M.S(s0 + i) = int_out;
+        M.S(s0 + 2 + i) = (out_free >= hi[i] ? 1.0 : 0.0) - (out_free <= lo[i] ? 1.0 : 0.0);
+        out[i] = fmin(fmax(out_free, lo[i]), hi[i]);
+    }
+}
+template <int NX>
+FBD void lqr_init(const CtlMem& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT) {
+    double x[NX], out[2];
+#pragma unroll
+    for (int k = 0; k < NX; k++) x[k] = 0;
+    const double z[2] = {0, 0};
+    M.S(s0) = 0; M.S(s0 + 1) = 0; M.S(s0 + 2) = 0; M.S(s0 + 3) = 0;
+    lqr_run<NX>(M, s0, g, lo, hi, dT, x, z, z, out);
+}
+
+// ---- longitudinal channel ------------------------------------------------------------------------------------------
+FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+    double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
+    const double EAS_ref = M.U(FB_CU_EAS_REF), clm_ref = M.U(FB_CU_CLM_REF), h_ref = M.U(FB_CU_H_REF);
+    const double EAS = v.EAS, h_e = v.h_e, q = v.w_wb_b.y, r = v.w_wb_b.z, theta = v.theta;
+    const double h_err = h_ref - h_e;
+    const int h_state = (int)M.S(FB_CS_H_STATE), mode_prev = (int)M.S(FB_CS_LON_MODE);
+    double throttle_ref = clampd(clampd(M.U(FB_CU_THROTTLE_AXIS), 0, 1) + clampd(M.U(FB_CU_THROTTLE_OFFSET), 0, 1), 0, 1);
+    double elevator_ref = clampd(clampd(M.U(FB_CU_ELEVATOR_AXIS), -1, 1) + clampd(M.U(FB_CU_ELEVATOR_OFFSET), -1, 1), -1, 1);
+    double throttle_cmd = throttle_ref, elevator_cmd = elevator_ref;
+    constexpr double h_thr = 10.0, h_hys = 1.0, k_p_theta = 1.0;   // c172x_ctl.jl:233-235
+    int mode;
+    if (v.on_gnd) mode = FB_LON_DIRECT;
+    else if (mode_req == FB_LON_EAS_ALT) {
+        if (h_state == FB_ALT_ACQUIRE) {
+            mode = FB_LON_THR_EAS;
+            throttle_ref = h_err > 0 ? 1.0 : 0.0;   // full throttle to climb, idle to descend
+            if (fabs(h_err) < h_thr - h_hys) M.S(FB_CS_H_STATE) = FB_ALT_HOLD;
+        } else {
+            mode = FB_LON_EAS_ALT;
+            if (fabs(h_err) > h_thr + h_hys) M.S(FB_CS_H_STATE) = FB_ALT_ACQUIRE;
+        }
+    } else mode = mode_req;
+    const bool changed = mode != mode_prev;
+    const bool te2te = mode == FB_LON_SAS || mode == FB_LON_THR_Q || mode == FB_LON_THR_THETA || mode == FB_LON_EAS_Q ||
+                       mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    const bool q2e = te2te && mode != FB_LON_SAS;
+    const bool th2q = mode == FB_LON_THR_THETA || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    const bool v2t = mode == FB_LON_EAS_Q || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    const double lo[2] = {0, -1}, hi[2] = {1, 1};
+    const double x_red[8] = {v.w_eb_b.y, theta, EAS, v.alpha, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
+    double out[2];
+    if (te2te) {
+        const double sat_thr = M.S(FB_CS_TE2TE + 2), sat_ele = M.S(FB_CS_TE2TE + 3);   // te2te_lqr.y.out_sat of the previous update
+        if (v2t) {
+            const PidGains P = pid_gains(T.lk[5], EAS, h_e);
+            if (changed) { pid_init(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT); if (P.k_i != 0) M.S(FB_CS_V2T_PID) = M.S(FB_CS_THROTTLE_CMD); }
+            throttle_ref = pid_run(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT, EAS_ref - EAS, sat_thr);
+        }
+        if (q2e) {
+            const PidGains P = pid_gains(T.lk[3], EAS, h_e);
+            if (changed) {
+                integ_init(M, FB_CS_Q2E_INT, dT);
+                pid_init(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT);
+                if (P.k_i != 0) M.S(FB_CS_Q2E_PID) = M.S(FB_CS_TE2TE + 5);
+            }
+            if (th2q) {
+                if (mode == FB_LON_EAS_CLM) {
+                    const PidGains Pc = pid_gains(T.lk[4], EAS, h_e);
+                    if (changed) { pid_init(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT); if (Pc.k_i != 0) M.S(FB_CS_C2THETA_PID) = theta; }
+                    theta_ref = pid_run(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT, clm_ref - v.clm, sat_ele);
+                }
+                const double theta_dot_ref = k_p_theta * (theta_ref - theta);
+                const double phi_bnd = clampd(v.phi, -PI / 3, PI / 3);
+                q_ref = 1 / cos(phi_bnd) * theta_dot_ref + r * tan(phi_bnd);
+            }
+            const double io = integ_run(M, FB_CS_Q2E_INT, dT, q_ref - q, sat_ele);
+            elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
+        }
+        double g[FB_CTL_LQR8_REC];
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[0], EAS, h_e, g);
+        const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
+        M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
+        lqr_run<8>(M, FB_CS_TE2TE, g, lo, hi, dT, x_red, z, z_ref, out);
+        throttle_cmd = out[0]; elevator_cmd = out[1];
+    }
+    if (mode == FB_LON_THR_EAS) {
+        double g[FB_CTL_LQR8_REC];
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[1], EAS, h_e, g);
+        if (changed) lqr_init<8>(M, FB_CS_TV2TE, g, lo, hi, dT);
+        const double z[2] = {v.cmd[0], EAS}, z_ref[2] = {throttle_ref, EAS_ref};
+        lqr_run<8>(M, FB_CS_TV2TE, g, lo, hi, dT, x_red, z, z_ref, out);
+        throttle_cmd = out[0]; elevator_cmd = out[1];
+    }
+    if (mode == FB_LON_EAS_ALT) {
+        double g[FB_CTL_LQR9_REC];
+        ctl_lookup<FB_CTL_LQR9_REC>(T.lk[2], EAS, h_e, g);
+        if (changed) lqr_init<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
+        const double x_full[9] = {v.w_eb_b.y, theta, EAS, v.alpha, h_e, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
+        const double z[2] = {EAS, h_e}, z_ref[2] = {EAS_ref, h_ref};
+        lqr_run<9>(M, FB_CS_VH2TE, g, lo, hi, dT, x_full, z, z_ref, out);
+        throttle_cmd = out[0]; elevator_cmd = out[1];
+    }
+    M.S(FB_CS_LON_MODE) = mode;
+    M.S(FB_CS_THROTTLE_REF) = clampd(throttle_ref, 0, 1); M.S(FB_CS_ELEVATOR_REF) = clampd(elevator_ref, -1, 1);
+    M.S(FB_CS_Q_REF) = q_ref; M.S(FB_CS_THETA_REF) = theta_ref;
+    M.S(FB_CS_THROTTLE_CMD) = clampd(throttle_cmd, 0, 1); M.S(FB_CS_ELEVATOR_CMD) = clampd(elevator_cmd, -1, 1);
+}
+
+// ---- lateral channel -----------------------------------------------------------------------------------------------
+FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
+FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+    const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
+    double phi_ref = M.U(FB_CU_PHI_REF);
+    const double EAS = v.EAS, h_e = v.h_e;
+    const int mode_prev = (int)M.S(FB_CS_LAT_MODE);
+    const int mode = v.on_gnd ? (int)FB_LAT_DIRECT : mode_req;
+    const bool changed = mode != mode_prev;
+    const double aileron_ref = clampd(clampd(M.U(FB_CU_AILERON_AXIS), -1, 1) + clampd(M.U(FB_CU_AILERON_OFFSET), -1, 1), -1, 1);
+    const double rudder_ref = clampd(clampd(M.U(FB_CU_RUDDER_AXIS), -1, 1) + clampd(M.U(FB_CU_RUDDER_OFFSET), -1, 1), -1, 1);
+    double aileron_cmd = aileron_ref, rudder_cmd = rudder_ref;
+    const double lo[2] = {-1, -1}, hi[2] = {1, 1};
+    const double x_lat[8] = {v.w_eb_b.x, v.w_eb_b.z, v.phi, EAS, v.beta, v.beta_filt, v.pos[1], v.pos[3]};
+    double out[2];
+    if (mode == FB_LAT_SAS) {
+        double g[FB_CTL_LQR8_REC];
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[6], EAS, h_e, g);
+        const double z[2] = {v.cmd[1], v.cmd[3]}, z_ref[2] = {aileron_ref, rudder_ref};
+        lqr_run<8>(M, FB_CS_AR2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
+        aileron_cmd = out[0]; rudder_cmd = out[1];
+    }
+    if (mode == FB_LAT_P_BETA || mode == FB_LAT_PHI_BETA || mode == FB_LAT_CHI_BETA) {
+        const double sat_ail = M.S(FB_CS_PHIBETA2AR + 2);
+        if (mode == FB_LAT_P_BETA) {
+            const PidGains P = pid_gains(T.lk[8], EAS, h_e);
+            if (changed) {
+                integ_init(M, FB_CS_P2PHI_INT, dT);
+                pid_init(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT);
+                if (P.k_i != 0) M.S(FB_CS_P2PHI_PID) = M.S(FB_CS_PHIBETA2AR + 4);
+            }
+            const double io = integ_run(M, FB_CS_P2PHI_INT, dT, p_ref - v.w_wb_b.x, sat_ail);
+            phi_ref = pid_run(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ail);
+        } else if (mode == FB_LAT_CHI_BETA) {
+            const PidGains P = pid_gains(T.lk[9], EAS, h_e);
+            if (changed) { pid_init(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT); if (P.k_i != 0) M.S(FB_CS_CHI2PHI_PID) = M.S(FB_CS_PHIBETA2AR + 4); }
+            phi_ref = pid_run(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT, wrap_to_pi(chi_ref - v.chi), sat_ail);
+        }
+        double g[FB_CTL_LQR8_REC];
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[7], EAS, h_e, g);
+        if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT);
+        const double z[2] = {v.phi, v.beta}, z_ref[2] = {phi_ref, beta_ref};
+        M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];
+        lqr_run<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
+        aileron_cmd = out[0]; rudder_cmd = out[1];
+    }
+    M.S(FB_CS_LAT_MODE) = mode;
+    M.S(FB_CS_AILERON_REF) = aileron_ref; M.S(FB_CS_RUDDER_REF) = rudder_ref; M.S(FB_CS_PHI_REF) = phi_ref;
+    M.S(FB_CS_AILERON_CMD) = clampd(aileron_cmd, -1, 1); M.S(FB_CS_RUDDER_CMD) = clampd(rudder_cmd, -1, 1);
+}
+
+}  // namespace fbd

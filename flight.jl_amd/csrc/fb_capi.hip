@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "c172_kernels.hpp"
+#include "c172x_kernels.hpp"
 #include "robot2d_kernels.hpp"
 
 using namespace fbd;
@@ -54,6 +55,14 @@ struct fb_handle_s {
     bool timing = false;
     int64_t launches = 0;
     struct R2State* r2 = nullptr;  // Robot2D handles only
+    // Cessna172Xv2 handles only
+    double* cs = nullptr;      // [FB_NCS x n] control-law record
+    double* cu = nullptr;      // [FB_NCU x n] control-law inputs
+    double* q_pre = nullptr;   // [8 x n]
+    double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
+    int64_t gains_off[10] = {0};
+    bool have_gains = false;
+    int64_t steps_done = 0;    // steps since the last init (phase of the periodic update)
     struct LogState* log = nullptr;  // on-device TimeSeries log (fb_log_*)
 };
 
@@ -63,6 +72,7 @@ static KArgs make_args(fb_handle h) {
     a.n = h->n;
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface};
     a.dt = h->params.dt;
+    a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre;
     return a;
 }
 static int32_t check_ready(fb_handle h) {
@@ -75,6 +85,32 @@ static int32_t check_ready(fb_handle h) {
     return 0;
 }
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+static bool is_x2(fb_handle h) { return h->model == FB_MODEL_C172X2; }
+static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (int)FB_NX; }
+// Cessna172X: row of the C ABI state layout (reference order: act after pwp) -> device row (actuators last)
+static int x2_dev_row(int k) { return k < FB_X2_ACT ? k : (k < FB_X2_KIN ? FB_NX + (k - FB_X2_ACT) : k - FB_NACT); }
+static int32_t check_ready_x2(fb_handle h) {
+    if (int32_t rc = check_ready(h)) return rc;
+    if (is_x2(h) && !h->have_gains) return fail("table CTL_GAINS has not been uploaded (fb_set_table)");
+    return 0;
+}
+static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
+    CtlArgs c;
+    for (int k = 0; k < 10; k++) c.tab.lk[k] = h->gains + h->gains_off[k];
+    c.dT = h->params.dt * (h->params.periodic_n > 0 ? h->params.periodic_n : 1);
+    c.use_q_pre = use_q_pre;
+    return c;
+}
+// host [nrows x n] <-> device rows through a row map (identity when map == nullptr)
+static int32_t copy_rows(fb_handle h, double* dev, const double* host_in, double* host_out, int nrows, int (*map)(int)) {
+    const int64_t n = h->n;
+    for (int k = 0; k < nrows; k++) {
+        double* d = dev + (int64_t)(map ? map(k) : k) * n;
+        if (host_in) HIPCHK(hipMemcpyAsync(d, host_in + (int64_t)k * n, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+        if (host_out) HIPCHK(hipMemcpyAsync(host_out + (int64_t)k * n, d, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    }
+    return 0;
+}
 
 #include "fb_robot2d.inc"
 #include "fb_log.inc"
@@ -87,9 +123,9 @@ const char* fb_version(void) { return "flightbatch 0.1 (gfx950)"; }
 int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out) {
     if (!out) return fail("out is null");
     *out = nullptr;
-    if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_ROBOT2D) return fail("model not implemented (FB_MODEL_C172S0, FB_MODEL_ROBOT2D)");
-    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
-    if (model_id == FB_MODEL_C172S0 && dtype != FB_F64) return fail("dtype not implemented for Cessna172Sv0 (only FB_F64)");
+    if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
+    if (model_id != FB_MODEL_ROBOT2D && kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
+    if (model_id != FB_MODEL_ROBOT2D && dtype != FB_F64) return fail("dtype not implemented for the Cessna 172 models (only FB_F64)");
     if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
     if (n <= 0) return fail("n must be positive");
     if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");
@@ -112,15 +148,24 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
         *out = h;
         return 0;
     }
-    HIPCHK(hipMalloc(&h->x_own, sizeof(double) * FB_NX * n));
+    const int nx = nx_of(h);
+    HIPCHK(hipMalloc(&h->x_own, sizeof(double) * nx * n));
     HIPCHK(hipMalloc(&h->s_own, sizeof(int32_t) * FB_NS * n));
+    if (is_x2(h)) {
+        HIPCHK(hipMalloc(&h->cs, sizeof(double) * FB_NCS * n));
+        HIPCHK(hipMalloc(&h->cu, sizeof(double) * FB_NCU * n));
+        HIPCHK(hipMalloc(&h->q_pre, sizeof(double) * 8 * n));
+        HIPCHK(hipMemsetAsync(h->cs, 0, sizeof(double) * FB_NCS * n, h->stream));
+        HIPCHK(hipMemsetAsync(h->cu, 0, sizeof(double) * FB_NCU * n, h->stream));
+        HIPCHK(hipMemsetAsync(h->q_pre, 0, sizeof(double) * 8 * n, h->stream));
+    }
     HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
     HIPCHK(hipMalloc(&h->ui, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->status, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->tables, sizeof(double) * LDS_TABLE_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
     h->x = h->x_own; h->s = h->s_own;
-    HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * FB_NX * n, h->stream));
+    HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * nx * n, h->stream));
     HIPCHK(hipMemsetAsync(h->s, 0, sizeof(int32_t) * FB_NS * n, h->stream));
     HIPCHK(hipMemsetAsync(h->u, 0, sizeof(double) * FB_NU * n, h->stream));
     HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * n, h->stream));
@@ -140,6 +185,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
@@ -149,7 +195,7 @@ int64_t fb_size(fb_handle h) { return h ? h->n : -1; }
 int32_t fb_dims(fb_handle h, int32_t* nx, int32_t* ns, int32_t* nu, int32_t* ny) {
     if (!h) return fail("null handle");
     const bool r2 = h->model == FB_MODEL_ROBOT2D;
-    if (nx) *nx = r2 ? FB_R2_NX : FB_NX;
+    if (nx) *nx = r2 ? (int)FB_R2_NX : nx_of(h);
     if (ns) *ns = r2 ? 0 : FB_NS;
     if (nu) *nu = r2 ? FB_R2_NU : FB_NU;
     if (ny) *ny = r2 ? FB_R2_NY : FB_NY;
@@ -184,6 +230,26 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
         if (count != FB_R2_TABLE_SIZE) return fail("Robot2D blob must hold FB_R2_TABLE_SIZE doubles");
         std::memcpy(h->r2->table, data, sizeof(double) * FB_R2_TABLE_SIZE);
         h->r2->have_table = true;
+        return 0;
+    }
+    if (kind == FB_TABLE_CTL_GAINS) {
+        if (!is_x2(h)) return fail("table kind does not belong to this model");
+        const double* b = (const double*)data;
+        static const int rec[10] = {FB_CTL_LQR8_REC, FB_CTL_LQR8_REC, FB_CTL_LQR9_REC, FB_CTL_PID_REC, FB_CTL_PID_REC, FB_CTL_PID_REC,
+                                    FB_CTL_LQR8_REC, FB_CTL_LQR8_REC, FB_CTL_PID_REC, FB_CTL_PID_REC};
+        int64_t off = 0;
+        for (int k = 0; k < 10; k++) {
+            if (off + FB_CTL_GRID_HDR > count) return fail("control-law gains blob is truncated");
+            const int64_t nE = (int64_t)b[off], nH = (int64_t)b[off + 1];
+            if (nE < 1 || nH < 1 || nE > 64 || nH > 64) return fail("control-law gains blob: implausible grid size in lookup %d", k);
+            h->gains_off[k] = off;
+            off += FB_CTL_GRID_HDR + nE * nH * rec[k];
+        }
+        if (off != count) return fail("control-law gains blob: %lld doubles given, layout needs %lld", (long long)count, (long long)off);
+        if (h->gains) { (void)hipFree(h->gains); h->gains = nullptr; }
+        HIPCHK(hipMalloc(&h->gains, sizeof(double) * count));
+        HIPCHK(hipMemcpy(h->gains, data, sizeof(double) * count, hipMemcpyHostToDevice));
+        h->have_gains = true;
         return 0;
     }
     switch (kind) {
@@ -237,18 +303,19 @@ int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
         h->t = 0.0;
         return 0;
     }
-    if (x) HIPCHK(hipMemcpyAsync(h->x, x, sizeof(double) * FB_NX * h->n, hipMemcpyHostToDevice, h->stream));
+    if (x) { if (int32_t rc = copy_rows(h, h->x, x, nullptr, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->t = 0.0;
+    h->steps_done = 0;
     return 0;
 }
 int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) return x ? r2_download(h, h->r2, x, h->r2->r, FB_R2_NX) : 0;
-    if (x) HIPCHK(hipMemcpyAsync(x, h->x, sizeof(double) * FB_NX * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (x) { if (int32_t rc = copy_rows(h, h->x, nullptr, x, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(s, h->s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -280,7 +347,7 @@ int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit) {
 }
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost) {
     if (h && h->model == FB_MODEL_ROBOT2D) return fail("fb_trim: Robot2D has no trim (use fb_f_init)");
-    if (int32_t rc = check_ready(h)) return rc;
+    if (int32_t rc = check_ready_x2(h)) return rc;
     if (!trim_params || !trim_state) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = h->n;
@@ -295,6 +362,11 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     HIPCHK(hipMemcpyAsync(d_ts, trim_state, sizeof(double) * FB_NTS * n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_trim, grid_for(n, 64), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost);
     HIPCHK(hipGetLastError());
+    if (is_x2(h)) {  // f_init!(aircraft, trim): actuator states, then f_init!(avionics, vehicle) (aircraftbase.jl:255-265)
+        hipLaunchKernelGGL(k_x2_init, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        HIPCHK(hipGetLastError());
+    }
+    h->steps_done = 0;
     HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMemcpyAsync(trim_state, d_ts, sizeof(double) * FB_NTS * n, hipMemcpyDeviceToHost, h->stream));
     if (success) HIPCHK(hipMemcpyAsync(success, h->trim_ok, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
@@ -310,11 +382,12 @@ int32_t fb_f_ode(fb_handle h, double* xdot) {
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = h->n;
     if (!h->y) HIPCHK(hipMalloc(&h->y, sizeof(double) * FB_NY * n));
-    if (xdot && !h->xdot) HIPCHK(hipMalloc(&h->xdot, sizeof(double) * FB_NX * n));
-    hipLaunchKernelGGL(k_f_ode, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
+    if (xdot && !h->xdot) HIPCHK(hipMalloc(&h->xdot, sizeof(double) * nx_of(h) * n));
+    if (is_x2(h)) hipLaunchKernelGGL(k_f_ode<true>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
+    else hipLaunchKernelGGL(k_f_ode<false>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
     HIPCHK(hipGetLastError());
     if (xdot) {
-        HIPCHK(hipMemcpyAsync(xdot, h->xdot, sizeof(double) * FB_NX * n, hipMemcpyDeviceToHost, h->stream));
+        if (int32_t rc = copy_rows(h, h->xdot, nullptr, xdot, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;
@@ -329,7 +402,8 @@ int32_t fb_f_step(fb_handle h) {
     }
     if (int32_t rc = check_ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_f_step, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
+    if (is_x2(h)) hipLaunchKernelGGL(k_f_step<true>, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
+    else hipLaunchKernelGGL(k_f_step<false>, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -342,7 +416,47 @@ int32_t fb_f_periodic(fb_handle h) {
         R2_DISPATCH(k_r2_f_periodic);
         return 0;
     }
+    if (is_x2(h)) {  // f_periodic!(Unconditional(), world): the control laws on the outputs of an f_ode! at the current x
+        if (int32_t rc = check_ready_x2(h)) return rc;
+        HIPCHK(hipSetDevice(h->device));
+        hipLaunchKernelGGL(k_x2_ctl, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     return 0;  // Cessna172Sv0: NoAvionics and @no_periodic systems — nothing to do (c172.jl:695; aircraftbase.jl:131)
+}
+/* avionics.ctl.u / avionics.ctl.{s,y} of Cessna172Xv2 */
+int32_t fb_set_ctl_inputs(fb_handle h, const double* cu) {
+    if (!h || !cu) return fail("null argument");
+    if (!is_x2(h)) return fail("fb_set_ctl_inputs: only Cessna172Xv2 has control laws");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->cu, cu, sizeof(double) * FB_NCU * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_get_ctl_inputs(fb_handle h, double* cu) {
+    if (!h || !cu) return fail("null argument");
+    if (!is_x2(h)) return fail("fb_get_ctl_inputs: only Cessna172Xv2 has control laws");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(cu, h->cu, sizeof(double) * FB_NCU * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_set_ctl_state(fb_handle h, const double* cs) {
+    if (!h || !cs) return fail("null argument");
+    if (!is_x2(h)) return fail("fb_set_ctl_state: only Cessna172Xv2 has control laws");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->cs, cs, sizeof(double) * FB_NCS * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_get_ctl_state(fb_handle h, double* cs) {
+    if (!h || !cs) return fail("null argument");
+    if (!is_x2(h)) return fail("fb_get_ctl_state: only Cessna172Xv2 has control laws");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(cs, h->cs, sizeof(double) * FB_NCS * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
 }
 int32_t fb_get_outputs(fb_handle h, double* y) {
     if (!h || !y) return fail("null argument");
@@ -365,11 +479,28 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
     if (h->model == FB_MODEL_ROBOT2D) return r2_step(h, nsteps);
     const KArgs a = make_args(h);
     int64_t left = nsteps;
-    while (left > 0) {
-        const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
-        hipLaunchKernelGGL(k_step, grid_for(h->n, 256), dim3(256), 0, h->stream, a, k);
-        left -= k;
-        h->launches++;
+    if (is_x2(h)) {
+        // launches are cut at the multiples of Δt/dt; the control laws run between them on the outputs of the step's
+        // last f_ode! (cb_periodic after cb_step, FC/sim.jl:204-218, 366-381)
+        const int64_t ratio = h->params.periodic_n > 0 ? h->params.periodic_n : 1;
+        const CtlArgs c = ctl_args(h, 1);
+        while (left > 0) {
+            const int64_t to_periodic = ratio - (h->steps_done % ratio);
+            int64_t k = left < to_periodic ? left : to_periodic;
+            if (k > h->steps_per_launch) k = h->steps_per_launch;
+            hipLaunchKernelGGL(k_step<true>, grid_for(h->n, 256), dim3(256), 0, h->stream, a, (int)k);
+            h->launches++;
+            h->steps_done += k;
+            left -= k;
+            if (h->steps_done % ratio == 0) hipLaunchKernelGGL(k_x2_ctl, grid_for(h->n, 256), dim3(256), 0, h->stream, a, c);
+        }
+    } else {
+        while (left > 0) {
+            const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
+            hipLaunchKernelGGL(k_step<false>, grid_for(h->n, 256), dim3(256), 0, h->stream, a, k);
+            left -= k;
+            h->launches++;
+        }
     }
     HIPCHK(hipGetLastError());
     h->t += (double)nsteps * h->params.dt;
@@ -378,7 +509,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
 int32_t fb_step(fb_handle h, int64_t nsteps) {
     if (h && h->model == FB_MODEL_ROBOT2D) {
         if (int32_t rc = r2_ready(h)) return rc;
-    } else if (int32_t rc = check_ready(h)) return rc;
+    } else if (int32_t rc = check_ready_x2(h)) return rc;
     if (nsteps < 0) return fail("nsteps must be >= 0");
     HIPCHK(hipSetDevice(h->device));
     LogState* L = h->log;

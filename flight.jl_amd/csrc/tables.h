@@ -68,8 +68,11 @@ enum {
  * host side: [21 x 21 x 6] column-major (J, Mt, coefficient) as the reference's Coefficients{Array}
  * device side: interleaved, element (iJ, iMt, c) at ((iJ + 21*iMt) * 6 + c)                      */
 enum { PR_NJ = 21, PR_NM = 21, PR_NC = 6, PR_SIZE = 21 * 21 * 6 };
+/* kernels that do not log C_P / eta_p keep only the first four coefficients in LDS (7 KB less per workgroup) */
+enum { PR_NC_STEP = 4, PR_SIZE_STEP = 21 * 21 * 4 };
 
 /* LDS blob = [aero | piston | propeller] */
-enum { LDS_AERO = 0, LDS_PISTON = AT_SIZE, LDS_PROP = AT_SIZE + PT_SIZE, LDS_TABLE_DOUBLES = AT_SIZE + PT_SIZE + PR_SIZE };
+enum { LDS_AERO = 0, LDS_PISTON = AT_SIZE, LDS_PROP = AT_SIZE + PT_SIZE, LDS_TABLE_DOUBLES = AT_SIZE + PT_SIZE + PR_SIZE,
+       LDS_TABLE_DOUBLES_STEP = AT_SIZE + PT_SIZE + PR_SIZE_STEP };
 
 #endif

@@ -47,6 +47,10 @@ def _load():
         "fb_f_step": ([H], C.c_int32),
         "fb_f_periodic": ([H], C.c_int32),
         "fb_get_outputs": ([H, D], C.c_int32),
+        "fb_set_ctl_inputs": ([H, D], C.c_int32),
+        "fb_get_ctl_inputs": ([H, D], C.c_int32),
+        "fb_set_ctl_state": ([H, D], C.c_int32),
+        "fb_get_ctl_state": ([H, D], C.c_int32),
         "fb_step": ([H, I64], C.c_int32),
         "fb_set_steps_per_launch": ([H, C.c_int32], C.c_int32),
         "fb_sync": ([H], C.c_int32),

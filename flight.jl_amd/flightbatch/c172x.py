@@ -1,0 +1,99 @@
+"""Host mirror of `Cessna172Xv2()` (lib/FlightApps/src/c172/c172x/c172x2.jl:52-58) for the batched path.
+
+    reference                                                     here
+    Model(SimpleWorld(Cessna172Xv2()))                            Cessna172Xv2World(n)
+    init!(sim, C172.TrimParameters())                             init(sim, TrimParameters(...))   (trim + avionics init)
+    ctl = world.aircraft.avionics.ctl
+    ctl.u.lon.mode_req = ModeControlLon.EAS_clm                   world.ctl.lon.mode_req = ModeControlLon.EAS_clm
+    ctl.u.lat.φ_ref = π/6                                         world.ctl.lat.φ_ref = np.pi / 6      (scalars broadcast; arrays per aircraft)
+    ctl.y.lon.mode, ctl.y.lon.throttle_cmd, ...                   world.ctl.y("LON_MODE"), world.ctl.y("THROTTLE_CMD")
+    act.flaps.u[] = 0.3                                           u = world.u; u[K["FB_U_FLAPS"]] = 0.3; world.u = u
+    Simulation(world; dt = 0.01, Δt = 0.02)                       Simulation(world, dt=0.01, Δt=0.02)
+
+State rows follow the reference's ComponentVector (include/flightbatch.h, FB_X2_*)."""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import numpy as np
+
+from . import ctl_gains
+from ._lib import K, check, lib
+from .modeling import BatchedWorld, _pd
+
+
+class ModeControlLon(enum.IntEnum):   # c172x_ctl.jl:29-39
+    direct = 0; sas = 1; thr_q = 2; thr_θ = 3; thr_EAS = 4; EAS_q = 5; EAS_θ = 6; EAS_clm = 7; EAS_alt = 8
+
+
+class ModeControlLat(enum.IntEnum):   # c172x_ctl.jl:727-733
+    direct = 0; sas = 1; p_β = 2; φ_β = 3; χ_β = 4
+
+
+_LON_FIELDS = {"mode_req": "LON_MODE_REQ", "throttle_axis": "THROTTLE_AXIS", "throttle_offset": "THROTTLE_OFFSET",
+               "elevator_axis": "ELEVATOR_AXIS", "elevator_offset": "ELEVATOR_OFFSET", "q_ref": "Q_REF", "θ_ref": "THETA_REF",
+               "EAS_ref": "EAS_REF", "clm_ref": "CLM_REF", "h_ref": "H_REF"}
+_LAT_FIELDS = {"mode_req": "LAT_MODE_REQ", "aileron_axis": "AILERON_AXIS", "aileron_offset": "AILERON_OFFSET",
+               "rudder_axis": "RUDDER_AXIS", "rudder_offset": "RUDDER_OFFSET", "p_ref": "P_REF", "β_ref": "BETA_REF", "φ_ref": "PHI_REF",
+               "χ_ref": "CHI_REF"}
+
+
+class _Channel:
+    """ctl.u.lon / ctl.u.lat: attribute access to rows of the cu array; assignments go to the device at once."""
+
+    def __init__(self, world, fields):
+        object.__setattr__(self, "_w", world)
+        object.__setattr__(self, "_f", fields)
+
+    def __getattr__(self, name):
+        return self._w.cu[K["FB_CU_" + self._f[name]]]
+
+    def __setattr__(self, name, value):
+        cu = self._w.cu
+        cu[K["FB_CU_" + self._f[name]]] = np.asarray(value, dtype=np.float64)
+        self._w.cu = cu
+
+
+class _ControlLaws:
+    def __init__(self, world):
+        self.lon = _Channel(world, _LON_FIELDS)
+        self.lat = _Channel(world, _LAT_FIELDS)
+        self._w = world
+
+    def y(self, name: str) -> np.ndarray:
+        """A row of the control-law record (FB_CS_* without the prefix): modes, references, commands, compensator states."""
+        return self._w.cs[K["FB_CS_" + name]]
+
+
+class Cessna172Xv2World(BatchedWorld):
+    """N independent `Model(SimpleWorld(Cessna172Xv2()))` on one GPU."""
+    MODEL = "FB_MODEL_C172X2"
+
+    def __init__(self, n: int, device: int = 0, tables: dict | None = None, gains: np.ndarray | None = None):
+        super().__init__(n, device, tables)
+        blob = np.ascontiguousarray(gains if gains is not None else ctl_gains.ctl_gains_blob(), dtype=np.float64)
+        dims = (C.c_int64 * 1)(blob.size)
+        check(lib.fb_set_table(self._h, K["FB_TABLE_CTL_GAINS"], blob.ctypes.data_as(C.c_void_p), dims, 1))
+        self.ctl = _ControlLaws(self)
+
+    @property
+    def cu(self) -> np.ndarray:
+        cu = np.empty((K["FB_NCU"], self.n))
+        check(lib.fb_get_ctl_inputs(self._h, _pd(cu)))
+        return cu
+
+    @cu.setter
+    def cu(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NCU"], self.n)
+        check(lib.fb_set_ctl_inputs(self._h, _pd(v)))
+
+    @property
+    def cs(self) -> np.ndarray:
+        cs = np.empty((K["FB_NCS"], self.n))
+        check(lib.fb_get_ctl_state(self._h, _pd(cs)))
+        return cs
+
+    @cs.setter
+    def cs(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NCS"], self.n)
+        check(lib.fb_set_ctl_state(self._h, _pd(v)))

@@ -87,10 +87,15 @@ class SimulationTermination(Exception):
 class BatchedWorld:
     """N independent ``Model(SimpleWorld(Cessna172Sv0()))`` instances resident on one MI355X."""
 
+    MODEL = "FB_MODEL_C172S0"
+
     def __init__(self, n: int, device: int = 0, tables: dict | None = None):
         self.n = int(n)
         self._h = C.c_void_p()
-        check(lib.fb_create(K["FB_MODEL_C172S0"], K["FB_KIN_WA"], K["FB_F64"], self.n, int(device), C.byref(self._h)))
+        check(lib.fb_create(K[self.MODEL], K["FB_KIN_WA"], K["FB_F64"], self.n, int(device), C.byref(self._h)))
+        nx = C.c_int32()
+        check(lib.fb_dims(self._h, C.byref(nx), None, None, None))
+        self.nx = nx.value
         tb = tables or _tables.default_tables()
         self._set_table("FB_TABLE_EGM96", np.asfortranarray(tb["egm96"], dtype=np.float32), (721, 1441))
         self._set_table("FB_TABLE_PROPELLER", np.asfortranarray(tb["propeller"], dtype=np.float64), (21, 21, 6))
@@ -139,13 +144,13 @@ class BatchedWorld:
     # -- mdl.x / mdl.s / mdl.u (FC/modeling.jl:89-101) --
     @property
     def x(self) -> np.ndarray:
-        x = np.empty((K["FB_NX"], self.n))
+        x = np.empty((self.nx, self.n))
         check(lib.fb_get_state(self._h, _pd(x), None))
         return x
 
     @x.setter
     def x(self, v):
-        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NX"], self.n)
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.nx, self.n)
         check(lib.fb_set_state(self._h, _pd(v), None))
 
     @property
@@ -160,7 +165,7 @@ class BatchedWorld:
         check(lib.fb_set_state(self._h, None, _pi(v)))
 
     def set_state(self, x, s):
-        x = np.ascontiguousarray(x, dtype=np.float64).reshape(K["FB_NX"], self.n)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.nx, self.n)
         s = np.ascontiguousarray(s, dtype=np.int32).reshape(K["FB_NS"], self.n)
         check(lib.fb_set_state(self._h, _pd(x), _pi(s)))
 

@@ -233,6 +233,13 @@ int32_t fb_f_ode(fb_handle h, double* xdot);
 int32_t fb_f_step(fb_handle h);
 /* f_periodic!(Unconditional(), world) : FP/world.jl:41-47 (no-op for C172Sv0: @no_periodic everywhere). */
 int32_t fb_f_periodic(fb_handle h);
+/* Cessna172Xv2: avionics.ctl.u (inputs cu [N x FB_NCU]) and the control laws' record (cs [N x FB_NCS]: s and the parts of
+ * y other code reads). fb_f_periodic runs the control laws once (f_periodic!(Unconditional(), world)); fb_step runs them
+ * every periodic_n steps, after the step's f_step!, on the outputs of the step's last f_ode! (FC/sim.jl:204-218). */
+int32_t fb_set_ctl_inputs(fb_handle h, const double* cu);
+int32_t fb_get_ctl_inputs(fb_handle h, double* cu);
+int32_t fb_set_ctl_state(fb_handle h, const double* cs);
+int32_t fb_get_ctl_state(fb_handle h, double* cs);
 /* mdl.y of the last fb_f_ode / fb_step : y [N x FB_NY] */
 int32_t fb_get_outputs(fb_handle h, double* y);
 

@@ -1,0 +1,141 @@
+"""Cessna172Xv2 (fly-by-wire actuators + gain-scheduled control laws) on the GPU, through the C ABI, against the CPU oracle
+and against the reference's closed-loop tolerances (lib/FlightApps/test/c172/test_c172x1.jl)."""
+import numpy as np
+import pytest
+
+from oracle_binding import OracleX
+from test_gpu_parity import lattice_trim_params, state_scale
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_to_dev_rows(K):
+    """row k of the C ABI state (reference order) -> row of the oracle / device order (27 Sv0 rows, then the actuators)"""
+    return np.array([k if k < K["FB_X2_ACT"] else (27 + k - K["FB_X2_ACT"] if k < K["FB_X2_KIN"] else k - K["FB_NACT"]) for k in range(34)])
+
+
+def x_scale(x):
+    sc = np.ones_like(x)
+    sc[:27] = state_scale(x[:27])
+    return sc
+
+
+@pytest.fixture(scope="module")
+def gains(fb):
+    return fb.ctl_gains.ctl_gains_blob()
+
+
+def make_pair(fb, oracle, gains, n, seed, dt=0.01, ratio=2):
+    """The same randomised-trim batch initialised on the GPU and on the oracle."""
+    tp = lattice_trim_params(fb, n, seed=seed)
+    w = fb.Cessna172Xv2World(n, gains=gains)
+    sim = fb.Simulation(w, dt=dt, Δt=dt * ratio, save_on=False, steps_per_launch=50)
+    fb.init(sim, tp)
+    X = OracleX(oracle, gains)
+    env = oracle.default_env()
+    o = X.trim_init(tp.pack(n), fb.TrimState(n), env, dt * ratio)
+    o["status"] = np.zeros(n, np.int32); o["nstep"] = 0
+    return w, sim, X, env, o
+
+
+def test_x2_init_matches_oracle(fb, oracle, gains):
+    K = fb.K
+    n = 1024
+    w, sim, X, env, o = make_pair(fb, oracle, gains, n, seed=21)
+    perm = ref_to_dev_rows(K)
+    ok = w.trim_success & o["ok"]
+    assert (w.trim_success == o["ok"]).all() and ok.mean() > 0.6
+    xo = o["x"][perm]                             # oracle rows re-ordered to the reference order (w.x is in that order)
+    assert np.max(np.abs(w.x - xo)[:, ok] / x_scale(o["x"])[perm][:, ok]) < 1e-7
+    # actuator states = commands = trim values; control-law inputs aligned with the vehicle; both channels in direct
+    assert np.array_equal(w.x[K["FB_X2_ACT"] + K["FB_ACT_THROTTLE"]], w.ctl.y("THROTTLE_CMD"))
+    assert np.max(np.abs(w.cu - o["cu"])[:, ok]) < 1e-6 and np.max(np.abs(w.cs - o["cs"])[:, ok]) < 1e-6
+    assert (w.ctl.y("LON_MODE") == 0).all() and (w.ctl.y("LAT_MODE") == 0).all() and (w.ctl.y("H_STATE") == K["FB_ALT_HOLD"]).all()
+    # f_ode!: ẋ (34 rows, reference order) and y against the oracle evaluated at the GPU's own state
+    xd = np.zeros((34, n)); fb.f_ode(w, xd)
+    od = dict(o); od["x"] = np.ascontiguousarray(np.empty((34, n))); od["x"][perm] = w.x; od["cs"] = w.cs; od["u"] = w.u; od["ui"] = w.ui; od["s"] = w.s
+    xdo, yo, _ = X.f_ode(od, env)
+    err = np.abs(xd - xdo[perm]) / np.maximum(np.abs(xdo[perm]), 1.0)
+    assert err.max() < 1e-9, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    sc_y = np.maximum(np.abs(yo), 1.0); sc_y[22:25] = 6.4e6
+    assert (np.abs(w.y - yo) / sc_y).max() < 1e-9
+    w.close()
+
+
+def test_x2_closed_loop_trajectory_matches_oracle(fb, oracle, gains):
+    """README example 2 configuration (dt = 0.01, Δt = 0.02): every aircraft in its own pair of control modes with its own
+    references, 10 s; state, control-law record and status against the oracle at the north-star tolerance."""
+    K = fb.K
+    n = 2048
+    w, sim, X, env, o = make_pair(fb, oracle, gains, n, seed=22)
+    rng = np.random.default_rng(7)
+    cu = w.cu
+    cu[K["FB_CU_LON_MODE_REQ"]] = rng.integers(0, 9, n)
+    cu[K["FB_CU_LAT_MODE_REQ"]] = rng.integers(0, 5, n)
+    cu[K["FB_CU_Q_REF"]] += rng.uniform(-0.005, 0.005, n); cu[K["FB_CU_THETA_REF"]] += rng.uniform(-0.03, 0.03, n)
+    cu[K["FB_CU_EAS_REF"]] += rng.uniform(-3, 3, n); cu[K["FB_CU_CLM_REF"]] += rng.uniform(-1.5, 1.5, n)
+    cu[K["FB_CU_H_REF"]] += rng.choice([-60.0, -5.0, 0.0, 5.0, 60.0], n)
+    cu[K["FB_CU_P_REF"]] += rng.uniform(-0.01, 0.01, n); cu[K["FB_CU_BETA_REF"]] += rng.uniform(-0.03, 0.03, n)
+    cu[K["FB_CU_PHI_REF"]] += rng.uniform(-0.3, 0.3, n); cu[K["FB_CU_CHI_REF"]] += rng.uniform(-0.5, 0.5, n)
+    w.cu = cu
+    o["cu"] = np.ascontiguousarray(o["cu"]); o["cu"][:] = cu
+    # start both from the GPU's initial condition so that only the stepping is compared
+    perm = ref_to_dev_rows(K)
+    o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
+    fb.step(sim, 10.0); w.sync()
+    X.step(o, env, 0.01, 2, 1000)
+    st, sto = w.status, o["status"]
+    assert np.array_equal(st != 0, sto != 0)
+    ok = (st == 0)
+    assert ok.mean() > 0.9
+    xo = o["x"][perm]
+    sc = x_scale(o["x"])[perm]
+    err = (np.abs(w.x - xo) / sc)[:, ok]
+    print("X2 closed loop, max scaled state error after 1000 steps:", err.max(), "terminated:", int((~ok).sum()))
+    assert err.max() < 1e-6
+    cerr = np.abs(w.cs - o["cs"])[:, ok] / np.maximum(np.abs(o["cs"][:, ok]), 1.0)
+    print("max control-law record error:", cerr.max())
+    assert cerr.max() < 1e-6
+    assert np.array_equal(w.ctl.y("LON_MODE")[ok], o["cs"][K["FB_CS_LON_MODE"], ok]) and np.array_equal(w.s[:, ok], o["s"][:, ok])
+    w.close()
+
+
+def test_x2_reference_mode_tracking(fb, gains):
+    """test_c172x1.jl:300-470 on the GPU, one scenario per lane, dt = Δt = 0.01 like the reference's test:
+    thr_θ (θ_ref = 5°, atol 1e-4), thr_EAS (45 m/s, 1e-1), EAS_clm (2 m/s & 45 m/s), φ_β (φ = π/12, β = 3°, 1e-3)."""
+    K = fb.K
+    n = 256
+    w = fb.Cessna172Xv2World(n, gains=gains)
+    sim = fb.Simulation(w, dt=0.01, Δt=0.01, save_on=False, steps_per_launch=1)
+    fb.init(sim, fb.TrimParameters())
+    assert w.trim_success.all()
+    lane = np.arange(n) % 4
+    w.ctl.lon.mode_req = np.choose(lane, [ModeLon(fb).thr_θ, ModeLon(fb).thr_EAS, ModeLon(fb).EAS_clm, ModeLon(fb).sas]).astype(float)
+    w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β)
+    fb.step(sim, 1.0)
+    y = _y(fb, w)
+    assert np.array_equal(w.ctl.y("LON_MODE"), w.ctl.lon.mode_req) and (w.ctl.y("LAT_MODE") == fb.ModeControlLat.φ_β).all()
+    w.ctl.lat.φ_ref = np.where(lane == 3, np.pi / 12, np.pi / 6)
+    w.ctl.lat.β_ref = np.where(lane == 3, np.deg2rad(3), 0.0)
+    w.ctl.lon.θ_ref = np.where(lane == 0, np.deg2rad(5), w.ctl.lon.θ_ref)
+    w.ctl.lon.EAS_ref = np.where((lane == 1) | (lane == 2), 45.0, w.ctl.lon.EAS_ref)
+    w.ctl.lon.clm_ref = np.where(lane == 2, 2.0, w.ctl.lon.clm_ref)
+    fb.step(sim, 10.0); w.sync()
+    y = _y(fb, w)
+    assert np.all(np.abs(y[1, lane == 0] - np.deg2rad(5)) < 1e-4)                    # thr_θ after 10 s
+    assert np.all(np.abs(y[2, lane == 3] - np.pi / 12) < 1e-3) and np.all(np.abs(y[K["FB_Y_AERO"] + 1, lane == 3] - np.deg2rad(3)) < 1e-3)
+    fb.step(sim, 20.0); w.sync()
+    y = _y(fb, w)
+    assert np.all(np.abs(y[K["FB_Y_AIR"] + 20, lane == 1] - 45) < 1e-1)               # thr_EAS after 30 s
+    assert np.all(np.abs(y[K["FB_Y_KIN"] + 36, lane == 2] + 2) < 1e-1) and np.all(np.abs(y[K["FB_Y_AIR"] + 20, lane == 2] - 45) < 2e-1)
+    assert (w.status == 0).all()
+    w.close()
+
+
+def ModeLon(fb):
+    return fb.ModeControlLon
+
+
+def _y(fb, w):
+    fb.f_ode(w)
+    return w.y
