@@ -11,3 +11,4 @@ from . import tables  # noqa: F401
 from . import sharding  # noqa: F401
 from .robot2d import Robot2DWorld, InitParameters  # noqa: F401
 from .c172x import Cessna172Xv2World, ModeControlLon, ModeControlLat  # noqa: F401
+from .fleet import MixedFleet  # noqa: F401

@@ -40,3 +40,34 @@ def all_gather_state(x_local, n_total: int | None = None):
     if n_total is not None and res.shape[1] != n_total:
         raise RuntimeError(f"gathered {res.shape[1]} aircraft, expected {n_total}")
     return res
+
+
+# ---- mixed fleets (BASELINE.json configs[4]; SURVEY.md §8e: "assigned after the model-type sort so each GPU gets the same
+# type mix") ------------------------------------------------------------------------------------------------
+def pack_fleet(types, rank: int = 0, world: int = 1) -> dict:
+    """Packs a fleet whose vehicle types are interleaved in the caller's order into homogeneous batches.
+
+    `types`: integer model id per vehicle (any integers), in the caller's order. Returns, per type present,
+    {type: indices} — the caller-order indices this rank owns, ascending — such that every rank gets a contiguous slice
+    of EACH type's sorted index list (same mix on every rank, sizes differ by at most one per type). A stable
+    counting sort: vehicles of one type keep their relative order, so results scatter back with one indexed store."""
+    import numpy as np
+    types = np.asarray(types)
+    out = {}
+    for t in np.unique(types):
+        idx = np.flatnonzero(types == t)
+        lo, hi = shard_range(idx.size, rank, world)
+        out[int(t)] = idx[lo:hi]
+    return out
+
+
+def unpack_fleet(parts: dict, values: dict, n_total: int, fill=0):
+    """Inverse of pack_fleet on one rank: scatter per-type arrays `values[type]` ([..., n_type]) back to caller order
+    ([..., n_total], rows padded to the widest type with `fill`)."""
+    import numpy as np
+    rows = max(np.atleast_2d(v).shape[0] for v in values.values())
+    out = np.full((rows, n_total), fill, dtype=np.float64)
+    for t, idx in parts.items():
+        v = np.atleast_2d(values[t])
+        out[:v.shape[0], idx] = v
+    return out

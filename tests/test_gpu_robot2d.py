@@ -91,3 +91,31 @@ def test_robot2d_device_log_f32(fb):
     assert np.array_equal(ts.y[:, 0], ts.x[:, 0]) and np.array_equal(ts.y[:, 1], ts.x[:, 1])   # y.ω, y.v are the states
     assert np.all(np.abs(np.diff(ts.x[:, 1, 0])) > 0)   # it moves
     w.close()
+
+
+def test_mixed_fleet_c172_and_robot2d(fb, oracle):
+    """Config 5 (BASELINE.json configs[4]) at test size: 50 % Cessna172Sv0 / 50 % Robot2D interleaved in the input order,
+    dt = 0.01, Δt = 0.02; the packed run must equal the two homogeneous runs, vehicle by vehicle."""
+    n = 4096
+    types = np.where(np.arange(n) % 2 == 0, fb.K["FB_MODEL_C172S0"], fb.K["FB_MODEL_ROBOT2D"])
+    types[:64] = fb.K["FB_MODEL_ROBOT2D"]     # not a pure alternation
+    fleet = fb.MixedFleet(types, {fb.K["FB_MODEL_C172S0"]: lambda m: fb.BatchedWorld(m), fb.K["FB_MODEL_ROBOT2D"]: lambda m: fb.Robot2DWorld(m, dtype="f32")})
+    fleet.simulate(dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    nc, nr = fleet.index[fb.K["FB_MODEL_C172S0"]].size, fleet.index[fb.K["FB_MODEL_ROBOT2D"]].size
+    assert nc + nr == n and nr == n // 2 + 32
+    EAS = 40 + 10 * (fleet.index[fb.K["FB_MODEL_C172S0"]] / n)            # a property of the vehicle, not of its slot
+    fleet.init({fb.K["FB_MODEL_C172S0"]: fb.TrimParameters(EAS=EAS, h_e=1000.0), fb.K["FB_MODEL_ROBOT2D"]: fb.InitParameters(u_m=0.0)})
+    rw = fleet.worlds[fb.K["FB_MODEL_ROBOT2D"]]
+    u = rw.u; u[0] = 1; u[2] = 0.3; rw.u = u                               # mode_v, v_ref = 0.3 (SURVEY §8d config 5)
+    fleet.step(2.0); fleet.sync()
+    x = fleet.gather("x")
+    st = fleet.gather("status", fill=-1)
+    assert x.shape == (27, n) and (st == 0).all()
+    is_r = types == fb.K["FB_MODEL_ROBOT2D"]
+    assert np.isnan(x[10:, is_r]).all() and np.isfinite(x[:, ~is_r]).all()
+    assert np.all(np.abs(x[1, is_r] - 0.3) < 0.05)                         # robots approach v_ref
+    # homogeneous reference runs
+    w = fb.BatchedWorld(nc); sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.init(sim, fb.TrimParameters(EAS=EAS, h_e=1000.0)); fb.step(sim, 2.0); w.sync()
+    assert np.array_equal(w.x, x[:, ~is_r])
+    w.close(); fleet.close()

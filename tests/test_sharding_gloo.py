@@ -63,3 +63,27 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         sh.shard_range(10, 3, 2)
+
+
+def test_pack_fleet_same_mix_on_every_rank():
+    """Mixed-fleet packer (config 5): types interleaved in the input order; every rank gets a contiguous slice of each
+    type's sorted list, the union over ranks is a partition, order within a type is preserved, unpack inverts pack."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sharding", os.path.join(ROOT, "flight.jl_amd", "flightbatch", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec); spec.loader.exec_module(sh)
+    rng = np.random.default_rng(0)
+    for n, world in ((1000, 1), (1001, 2), (4096, 8), (37, 8)):
+        types = rng.integers(0, 2, n) * 2          # ids 0 (C172) and 2 (Robot2D), random interleaving
+        seen = np.zeros(n, int)
+        for r in range(world):
+            parts = sh.pack_fleet(types, r, world)
+            for t, idx in parts.items():
+                assert (types[idx] == t).all() and (np.diff(idx) > 0).all()
+                seen[idx] += 1
+                tot = int((types == t).sum())
+                assert abs(idx.size - tot / world) < 1.0 + 1e-9      # same mix everywhere
+            vals = {t: np.vstack([idx.astype(float), -idx.astype(float)]) for t, idx in parts.items()}
+            back = sh.unpack_fleet(parts, vals, n, fill=np.nan)
+            for t, idx in parts.items():
+                assert np.array_equal(back[0, idx], idx) and np.array_equal(back[1, idx], -idx)
+        assert (seen == 1).all()
