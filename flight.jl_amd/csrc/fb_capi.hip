@@ -499,6 +499,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
             const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
             hipLaunchKernelGGL(k_step<false>, grid_for(h->n, 256), dim3(256), 0, h->stream, a, k);
             left -= k;
+            h->steps_done += k;
             h->launches++;
         }
     }
@@ -592,6 +593,28 @@ int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double
             for (size_t k = 0; k < f.size(); k++) data[k] = (double)f[k];
         }
     }
+    return 0;
+}
+/* checkpoint / restore support: the step counter (phase of the periodic update) and the sticky status words */
+int32_t fb_get_step_count(fb_handle h, int64_t* count) {
+    if (!h || !count) return fail("null argument");
+    *count = h->model == FB_MODEL_ROBOT2D ? (int64_t)h->r2->steps_done : h->steps_done;
+    return 0;
+}
+int32_t fb_set_step_count(fb_handle h, int64_t count, double t) {
+    if (!h) return fail("null handle");
+    if (count < 0) return fail("step count must be >= 0");
+    if (h->model == FB_MODEL_ROBOT2D) h->r2->steps_done = count;
+    h->steps_done = count;
+    if (h->log) h->log->step_index = count;
+    h->t = t;
+    return 0;
+}
+int32_t fb_set_status(fb_handle h, const int32_t* status) {
+    if (!h || !status) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->status, status, sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 int32_t fb_sync(fb_handle h) {

@@ -6,7 +6,7 @@ Julia host. Importing it requires the built shared library; there is no CPU fall
 """
 from ._lib import K, EXPORTED, LIB_PATH, FlightBatchError, lib  # noqa: F401
 from .modeling import (BatchedWorld, Simulation, SimulationTermination, TimeSeries, TrimParameters, TrimState,  # noqa: F401
-                       f_init, f_ode, f_periodic, f_step, init, run, step)
+                       f_init, f_ode, f_periodic, f_step, init, run, step, checkpoint, restore)
 from . import tables  # noqa: F401
 from . import sharding  # noqa: F401
 from .robot2d import Robot2DWorld, InitParameters  # noqa: F401

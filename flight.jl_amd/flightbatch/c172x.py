@@ -68,6 +68,7 @@ class _ControlLaws:
 class Cessna172Xv2World(BatchedWorld):
     """N independent `Model(SimpleWorld(Cessna172Xv2()))` on one GPU."""
     MODEL = "FB_MODEL_C172X2"
+    _CKPT_ARRAYS = ("x", "s", "u", "ui", "cu", "cs")
 
     def __init__(self, n: int, device: int = 0, tables: dict | None = None, gains: np.ndarray | None = None):
         super().__init__(n, device, tables)

@@ -207,6 +207,30 @@ class BatchedWorld:
     def sync(self):
         check(lib.fb_sync(self._h))
 
+    # -- checkpoint / restore: everything a resumed run needs, as a dict of numpy arrays (np.savez-able) --
+    _CKPT_ARRAYS = ("x", "s", "u", "ui")
+
+    def checkpoint(self) -> dict:
+        self.sync()
+        cnt = C.c_int64()
+        check(lib.fb_get_step_count(self._h, C.byref(cnt)))
+        ck = {k: getattr(self, k) for k in self._CKPT_ARRAYS}
+        ck.update(status=self.status, step_count=np.int64(cnt.value), t=np.float64(lib.fb_time(self._h)))
+        return ck
+
+    def restore(self, ck: dict) -> None:
+        if "s" in self._CKPT_ARRAYS:
+            self.set_state(ck["x"], ck["s"])
+        else:
+            self.x = ck["x"]
+        for k in self._CKPT_ARRAYS:
+            if k not in ("x", "s"):
+                setattr(self, k, ck[k])
+        st = np.ascontiguousarray(ck["status"], dtype=np.int32)
+        check(lib.fb_set_status(self._h, _pi(st)))
+        check(lib.fb_set_step_count(self._h, int(ck["step_count"]), float(ck["t"])))
+        self.t = float(ck["t"])
+
 
 # ---- the verbs (all return None) ---------------------------------------------------------------------
 def f_init(world: BatchedWorld, init, trim_state: np.ndarray | None = None) -> None:
@@ -340,6 +364,17 @@ def step(sim: Simulation, Δt_total: float | None = None, stop_at_tdt: bool = Tr
     check(lib.fb_step(sim.mdl._h, n))
     sim._nstep += n
     sim.mdl.t = sim.t
+    return None
+
+
+def checkpoint(sim: Simulation) -> dict:
+    """Everything needed to resume `sim` later (or elsewhere): the world's arrays, the step counter and sim.t."""
+    return sim.mdl.checkpoint()
+
+
+def restore(sim: Simulation, ck: dict) -> None:
+    sim.mdl.restore(ck)
+    sim._nstep = int(ck["step_count"])
     return None
 
 

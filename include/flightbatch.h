@@ -271,6 +271,13 @@ int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double
 /* SimulationTermination / ArgumentError mapping: per-aircraft sticky status bits (FB_ST_*). */
 int32_t fb_status(fb_handle h, int32_t* status);
 
+/* Checkpoint / restore: together with fb_get/set_state, fb_get/set_inputs and (Xv2) fb_get/set_ctl_inputs|state these
+ * capture everything a resumed run needs: the number of steps taken since the last init (the phase of the periodic
+ * update, FC/modeling.jl:99 `_n`), sim.t, and the sticky status words (fb_set_state clears them, like init!). */
+int32_t fb_get_step_count(fb_handle h, int64_t* count);
+int32_t fb_set_step_count(fb_handle h, int64_t count, double t);
+int32_t fb_set_status(fb_handle h, const int32_t* status);
+
 /* HIP-event timing on the handle's stream around the fb_step launches issued between begin and end;
  * reports total elapsed ms and the number of stepping-kernel launches. */
 int32_t fb_timing_begin(fb_handle h);

@@ -139,3 +139,41 @@ def ModeLon(fb):
 def _y(fb, w):
     fb.f_ode(w)
     return w.y
+
+
+def test_checkpoint_restore_resumes_bitwise(fb, gains):
+    """Checkpoint in the middle of a control-law period (odd step count at Δt = 2 dt), keep going, restore into a NEW world
+    and repeat: identical bits. Same for Cessna172Sv0 and an fp32 Robot2D batch."""
+    import io
+    n = 512
+    tp = lattice_trim_params(fb, n, seed=5)
+
+    def exercise(make, prepare, T0, T1, **simkw):
+        w = make(); sim = fb.Simulation(w, save_on=False, **simkw); prepare(w, sim)
+        fb.step(sim, T0)
+        ck = fb.checkpoint(sim)
+        buf = io.BytesIO(); np.savez(buf, **ck); buf.seek(0); ck = dict(np.load(buf))      # survives serialisation
+        fb.step(sim, T1); w.sync()
+        a = w.checkpoint()
+        w2 = make(); sim2 = fb.Simulation(w2, save_on=False, **simkw)
+        fb.restore(sim2, ck)
+        assert sim2.t == pytest.approx(T0)
+        fb.step(sim2, T1); w2.sync()
+        b = w2.checkpoint()
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+        w.close(); w2.close()
+
+    def prep_x2(w, sim):
+        fb.init(sim, tp)
+        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 1.0
+        w.ctl.lat.mode_req = float(fb.ModeControlLat.χ_β); w.ctl.lat.χ_ref = 0.3
+
+    exercise(lambda: fb.Cessna172Xv2World(n, gains=gains), prep_x2, 0.37, 1.0, dt=0.01, Δt=0.02, steps_per_launch=50)
+    exercise(lambda: fb.BatchedWorld(n), lambda w, sim: fb.init(sim, tp), 0.37, 1.0, dt=0.01, steps_per_launch=50)
+
+    def prep_r2(w, sim):
+        fb.init(sim, fb.InitParameters(u_m=0.05))
+        u = w.u; u[0] = 2; u[3] = 1.0; w.u = u
+
+    exercise(lambda: fb.Robot2DWorld(n, dtype="f32"), prep_r2, 0.37, 1.0, dt=0.01, Δt=0.02, steps_per_launch=50)
