@@ -117,8 +117,11 @@ FBD void half_angle_cs(double y, double x, double& c, double& s) {
 FBD double geoid_height(const Tables& T, v3 n, double& lat, double& lon) {
     lat = atan2(n.z, sqrt(n.x * n.x + n.y * n.y));
     lon = atan2(n.y, n.x);
-    double lam = fmod(lon + 2 * PI, 2 * PI);
-    lam = lam < 0 ? lam + 2 * PI : lam;
+    // λ = mod(lon + 2π, 2π) (geodesy.jl:209) without calling fmod: lon ∈ [-π, π], so t = fl(lon + 2π) ∈ [π, 3π] and the
+    // remainder is t itself or t - 2π, which is exact (Sterbenz). Branch-free on purpose: library fmod brings divergent
+    // control flow into the stepping kernel, and with it the spill-placement bug tools/check_isa_spills.py guards against.
+    const double t2 = lon + 2 * PI;
+    const double lam = t2 >= 2 * PI ? t2 - 2 * PI : t2;
     const double xi = (lat + PI / 2) * (720 / PI);
     const double xj = lam * (1440 / (2 * PI));
     const int i = min(max((int)floor(xi), 0), 719);
@@ -177,6 +180,15 @@ FBD double normal_gravity(double nz, double h) {
     const double s2 = nz * nz;
     const double g0 = g_a * (1 + k_g * s2) / sqrt(1 - e2 * s2);
     return g0 * (1 - 2 / a * (1 + f + m - 2 * f * s2) * h + 3 / a2 * (h * h));
+}
+
+// ltf(n_e) = Rz(λ) ∘ Ry(-(ϕ + π/2)) with ψ_nw = 0 (geodesy.jl:132-135), λ = atan2(n_y, n_x), -(ϕ + π/2) = atan2(-p, -n_z),
+// p = |(n_x, n_y)|: built from half-angle cos/sin pairs, no atan2 / sincos
+FBD quat ltf_quat(v3 n) {
+    double sl, cl, sp, cp;
+    half_angle_cs(n.y, n.x, cl, sl);
+    half_angle_cs(-sqrt(n.x * n.x + n.y * n.y), -n.z, cp, sp);
+    return {cl * cp, -(sl * sp), cl * sp, sl * cp};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -426,7 +438,7 @@ struct PanelSink {
     int64_t n;
     FBD void put(int k, double v) const { Y[(int64_t)k * n] = v; }
 };
-template <class Sink, class Emit, class In, int NXT>
+template <int KIN, class Sink, class Emit, class In, int NXT>
 FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, const Env& env, const Tables& T,
                 Emit&& emit, StepAux& aux, Sink&& sink) {
     using namespace c172;
@@ -438,24 +450,43 @@ FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, 
     auto YP3 = [&](int k, v3 v) { if (WITH_Y) { sink.put(k, v.x); sink.put(k + 1, v.y); sink.put(k + 2, v.z); } };
     auto YP4 = [&](int k, quat q) { if (WITH_Y) { sink.put(k, q.w); sink.put(k + 1, q.x); sink.put(k + 2, q.y); sink.put(k + 3, q.z); } };
 
-    // ===== kinematics: wander-azimuth mechanisation (FlightPhysics/src/kinematics.jl:181-223) =====
-    const quat q_wb = {x[FB_X_Q_WB], x[FB_X_Q_WB + 1], x[FB_X_Q_WB + 2], x[FB_X_Q_WB + 3]};
-    const quat q_ew = {x[FB_X_Q_EW], x[FB_X_Q_EW + 1], x[FB_X_Q_EW + 2], x[FB_X_Q_EW + 3]};
-    const double h_e = x[FB_X_H_E];
+    // ===== kinematics (FlightPhysics/src/kinematics.jl): WA :181-223, ECEF :282-320, NED :366-407 =====
+    // Rows FB_X_Q_WB.. hold the mechanisation's own states: WA q_wb[4] q_ew[4] h_e; ECEF q_eb[4] n_e[3] h_e (one row unused);
+    // NED ψ θ φ ϕ λ h_e (three rows unused; unused rows carry a zero derivative).
+    constexpr int KX = FB_X_Q_WB;
     const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
     const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
+    const double h_e = x[KIN == FB_KIN_WA ? KX + 8 : (KIN == FB_KIN_ECEF ? KX + 7 : KX + 5)];
     if (!(h_e >= H_MIN)) st |= FB_ST_ALT_RANGE;
-
-    // ψ_nw and n_e straight from q_ew (geodesy.jl:62-69, 140-147)
-    const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
-    const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
-    const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
-    // q_nw = Rz(ψ_nw), ψ_nw = atan2(-(dq34+dq12), dq24-dq13): only cos, sin of ψ_nw/2 are needed
-    double s_nw, c_nw;
-    half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
-    const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
-    const quat q_nb = qmul(q_nw, q_wb);
-    const quat q_eb = qmul(q_ew, q_wb);
+    quat q_nb, q_eb, q_en = {1, 0, 0, 0}, q_nw = {1, 0, 0, 0};
+    v3 n_e;
+    if constexpr (KIN == FB_KIN_WA) {
+        const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+        const quat q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
+        // ψ_nw and n_e straight from q_ew (geodesy.jl:62-69, 140-147)
+        const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
+        const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
+        n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+        // q_nw = Rz(ψ_nw), ψ_nw = atan2(-(dq34+dq12), dq24-dq13): only cos, sin of ψ_nw/2 are needed
+        double s_nw, c_nw;
+        half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
+        q_nw = {c_nw, 0.0, 0.0, s_nw};
+        q_nb = qmul(q_nw, q_wb);
+        q_eb = qmul(q_ew, q_wb);
+    } else if constexpr (KIN == FB_KIN_ECEF) {
+        q_eb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+        n_e = {x[KX + 4], x[KX + 5], x[KX + 6]};   // state n-vector, normalised only in f_step! (kinematics.jl:286, 317-320)
+        q_en = ltf_quat(n_e);
+        q_nb = qmul(qconj(q_en), q_eb);
+    } else {
+        double s1, c1, s2, c2, s3, c3, sla, cla, slo, clo;
+        sincos(0.5 * x[KX], &s1, &c1); sincos(0.5 * x[KX + 1], &s2, &c2); sincos(0.5 * x[KX + 2], &s3, &c3);
+        q_nb = qmul(qmul(quat{c1, 0, 0, s1}, quat{c2, 0, s2, 0}), quat{c3, s3, 0, 0});   // Rz(ψ) ∘ Ry(θ) ∘ Rx(φ), attitude.jl:393-395
+        sincos(x[KX + 3], &sla, &cla); sincos(x[KX + 4], &slo, &clo);
+        n_e = {cla * clo, cla * slo, sla};                                               // geodesy.jl:97-101
+        q_en = ltf_quat(n_e);
+        q_eb = qmul(q_en, q_nb);
+    }
 
     double lat, lon;
     const double N_geoid = geoid_height(T, n_e, lat, lon);
@@ -470,33 +501,63 @@ FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, 
     const v3 r_eb_e = {(R_E + h_e) * n_e.x, (R_E + h_e) * n_e.y, (R_E * (1 - wgs::e2) + h_e) * n_e.z};
     // transport rate (kinematics.jl:232-242)
     const v3 w_ew_n = {v_eb_n.y / (R_E + h_e), -v_eb_n.x / (R_N + h_e), 0.0};
-    const v3 w_ew_w = qrot_inv(q_nw, w_ew_n);
-    const v3 w_ew_b = qrot_inv(q_wb, w_ew_w);
-    const v3 w_wb_b = w_eb_b - w_ew_b;
-
-    {
+    v3 w_wb_b;
+    if constexpr (KIN == FB_KIN_WA) {
+        const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+        const quat q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
+        const v3 w_ew_w = qrot_inv(q_nw, w_ew_n);
+        const v3 w_ew_b = qrot_inv(q_wb, w_ew_w);
+        w_wb_b = w_eb_b - w_ew_b;
         const quat a = qmul(q_wb, quat{0.0, w_wb_b.x, w_wb_b.y, w_wb_b.z});
         const quat b2 = qmul(q_ew, quat{0.0, w_ew_w.x, w_ew_w.y, w_ew_w.z});
-        emit(FB_X_Q_WB, 0.5 * a.w); emit(FB_X_Q_WB + 1, 0.5 * a.x); emit(FB_X_Q_WB + 2, 0.5 * a.y); emit(FB_X_Q_WB + 3, 0.5 * a.z);
-        emit(FB_X_Q_EW, 0.5 * b2.w); emit(FB_X_Q_EW + 1, 0.5 * b2.x); emit(FB_X_Q_EW + 2, 0.5 * b2.y); emit(FB_X_Q_EW + 3, 0.5 * b2.z);
-        emit(FB_X_H_E, -v_eb_n.z);
+        emit(KX, 0.5 * a.w); emit(KX + 1, 0.5 * a.x); emit(KX + 2, 0.5 * a.y); emit(KX + 3, 0.5 * a.z);
+        emit(KX + 4, 0.5 * b2.w); emit(KX + 5, 0.5 * b2.x); emit(KX + 6, 0.5 * b2.y); emit(KX + 7, 0.5 * b2.z);
+        emit(KX + 8, -v_eb_n.z);
+    } else if constexpr (KIN == FB_KIN_ECEF) {
+        w_wb_b = w_eb_b - qrot_inv(q_nb, w_ew_n);
+        const quat a = qmul(q_eb, quat{0.0, w_eb_b.x, w_eb_b.y, w_eb_b.z});   // Attitude.dt(q_eb, ω_eb_b)
+        const v3 nd = qrot(q_en, cross(w_ew_n, v3{0.0, 0.0, -1.0}));           // kinematics.jl:309
+        emit(KX, 0.5 * a.w); emit(KX + 1, 0.5 * a.x); emit(KX + 2, 0.5 * a.y); emit(KX + 3, 0.5 * a.z);
+        emit(KX + 4, nd.x); emit(KX + 5, nd.y); emit(KX + 6, nd.z);
+        emit(KX + 7, -v_eb_n.z);
+        emit(KX + 8, 0.0);
+    } else {
+        w_wb_b = w_eb_b - qrot_inv(q_nb, w_ew_n);
+        // ω_en_n (kinematics.jl:413-425) with ϕ = LatLon(Ob).ϕ re-derived from n_e, like the reference
+        const v3 w_en_n = {w_ew_n.x, w_ew_n.y, -v_eb_n.y * tan(lat) / (R_E + h_e)};
+        const v3 w_nb_b = w_eb_b - qrot_inv(q_nb, w_en_n);
+        double sph, cph;
+        sincos(x[KX + 2], &sph, &cph);
+        const double tth = tan(x[KX + 1]), sec = 1.0 / cos(x[KX + 1]);
+        emit(KX, sph * sec * w_nb_b.y + cph * sec * w_nb_b.z);                 // Attitude.dt(e_nb, ω_nb_b), attitude.jl:436-449
+        emit(KX + 1, cph * w_nb_b.y - sph * w_nb_b.z);
+        emit(KX + 2, w_nb_b.x + sph * tth * w_nb_b.y + cph * tth * w_nb_b.z);
+        emit(KX + 3, -w_en_n.y);                                               // Geodesy.dt(ϕ_λ, ω_en_n), geodesy.jl:112-118
+        emit(KX + 4, w_en_n.x / cos(x[KX + 3]));
+        emit(KX + 5, -v_eb_n.z);
+        emit(KX + 6, 0.0); emit(KX + 7, 0.0); emit(KX + 8, 0.0);
     }
-    quat q_en = {1, 0, 0, 0};
     if (WITH_Y) {
-        q_en = qmul(q_eb, qconj(q_nb));
-        // Euler angles (attitude.jl:382-391)
-        const double q1 = q_nb.w, q2 = q_nb.x, q3 = q_nb.y, q4 = q_nb.z;
-        YP(FB_Y_KIN + 0, atan2(2 * (q1 * q4 + q2 * q3), 1 - 2 * (q3 * q3 + q4 * q4)));
-        YP(FB_Y_KIN + 1, asin(fmin(fmax(2 * (q1 * q3 - q2 * q4), -1.0), 1.0)));
-        YP(FB_Y_KIN + 2, atan2(2 * (q1 * q2 + q3 * q4), 1 - 2 * (q2 * q2 + q3 * q3)));
+        if constexpr (KIN == FB_KIN_WA) q_en = qmul(q_eb, qconj(q_nb));
+        if constexpr (KIN == FB_KIN_NED) {   // e_nb, ϕ_λ are the states themselves
+            YP(FB_Y_KIN + 0, x[KX]); YP(FB_Y_KIN + 1, x[KX + 1]); YP(FB_Y_KIN + 2, x[KX + 2]);
+            lat = x[KX + 3]; lon = x[KX + 4];
+        } else {
+            // Euler angles (attitude.jl:382-391)
+            const double q1 = q_nb.w, q2 = q_nb.x, q3 = q_nb.y, q4 = q_nb.z;
+            YP(FB_Y_KIN + 0, atan2(2 * (q1 * q4 + q2 * q3), 1 - 2 * (q3 * q3 + q4 * q4)));
+            YP(FB_Y_KIN + 1, asin(fmin(fmax(2 * (q1 * q3 - q2 * q4), -1.0), 1.0)));
+            YP(FB_Y_KIN + 2, atan2(2 * (q1 * q2 + q3 * q4), 1 - 2 * (q2 * q2 + q3 * q3)));
+        }
         YP4(FB_Y_KIN + 3, q_nb); YP4(FB_Y_KIN + 7, q_eb); YP4(FB_Y_KIN + 11, q_en);
         YP(FB_Y_KIN + 15, lat); YP(FB_Y_KIN + 16, lon); YP3(FB_Y_KIN + 17, n_e);
         YP(FB_Y_KIN + 20, h_e); YP(FB_Y_KIN + 21, h_o); YP3(FB_Y_KIN + 22, r_eb_e);
         YP3(FB_Y_KIN + 25, w_wb_b); YP3(FB_Y_KIN + 28, w_eb_b); YP3(FB_Y_KIN + 31, v_eb_b); YP3(FB_Y_KIN + 34, v_eb_n);
         const double v_gnd = norm(v_eb_n);
         YP(FB_Y_KIN + 37, v_gnd);
-        YP(FB_Y_KIN + 38, v_gnd > 0.1 ? atan2(v_eb_n.y, v_eb_n.x) : 0.0);
-        YP(FB_Y_KIN + 39, v_gnd > 0.1 ? atan2(-v_eb_n.z, sqrt(v_eb_n.x * v_eb_n.x + v_eb_n.y * v_eb_n.y)) : 0.0);
+        const bool chi_ok = KIN == FB_KIN_NED || v_gnd > 0.1;   // the NED mechanisation has no low-speed guard (kinematics.jl:395-396)
+        YP(FB_Y_KIN + 38, chi_ok ? atan2(v_eb_n.y, v_eb_n.x) : 0.0);
+        YP(FB_Y_KIN + 39, chi_ok ? atan2(-v_eb_n.z, sqrt(v_eb_n.x * v_eb_n.x + v_eb_n.y * v_eb_n.y)) : 0.0);
     }
 
     FB_PHASE_FENCE();
@@ -795,10 +856,7 @@ FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, 
         // The composition order must be the reference's: at RK stages q_eb is not exactly unit, and
         // v + 2 q_im x (q_re v + q_im x v) with a non-unit q does not commute with re-association.
         // λ = atan2(n_y, n_x); θ = -(ϕ + π/2) = atan2(-p, -n_z) with p = |(n_x, n_y)|: half-angle forms, no atan2/sincos
-        double sl, cl, sp, cp;
-        half_angle_cs(n_c.y, n_c.x, cl, sl);
-        half_angle_cs(-sqrt(n_c.x * n_c.x + n_c.y * n_c.y), -n_c.z, cp, sp);
-        const quat q_el = {cl * cp, -(sl * sp), cl * sp, sl * cp};
+        const quat q_el = ltf_quat(n_c);
         const quat q_cl = qmul(qconj(q_eb), q_el);
         const v3 g_c_c = qrot(q_cl, v3{0.0, 0.0, g});
 
@@ -833,25 +891,23 @@ FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, 
 // f_step!(world): kinematics renormalisation, stall hysteresis, contact-regulator reset, crash checks,
 // engine state machine (aircraftbase.jl:172-181; kinematics.jl:226-229,114-118; c172.jl:375-384,715-724;
 // landinggear.jl:331-347,479-483; piston.jl:428-453). Returns true when x or s changed.
-template <class In, int NXT>
+template <int KIN, class In, int NXT>
 FBD bool f_step(double (&x)[NXT], int& stall, int& eng_state, const In& in, const StepAux& aux, int32_t& st) {
     bool mod = false;
-    {
-        const double n2 = x[FB_X_Q_WB] * x[FB_X_Q_WB] + x[FB_X_Q_WB + 1] * x[FB_X_Q_WB + 1] + x[FB_X_Q_WB + 2] * x[FB_X_Q_WB + 2] + x[FB_X_Q_WB + 3] * x[FB_X_Q_WB + 3];
+    // normalize_block!(x, ε = 1e-8) (kinematics.jl:114-118) on q_wb, q_ew (WA :226-229) or q_eb, n_e (ECEF :317-320); NED: nothing
+    auto renorm = [&](int k0, int len) {
+        double n2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < len) n2 += x[k0 + k] * x[k0 + k];
         const double nr = sqrt(n2);
         if (fabs(nr - 1.0) > 1e-8) {
-            x[FB_X_Q_WB] /= nr; x[FB_X_Q_WB + 1] /= nr; x[FB_X_Q_WB + 2] /= nr; x[FB_X_Q_WB + 3] /= nr;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k < len) x[k0 + k] /= nr;
             mod = true;
         }
-    }
-    {
-        const double n2 = x[FB_X_Q_EW] * x[FB_X_Q_EW] + x[FB_X_Q_EW + 1] * x[FB_X_Q_EW + 1] + x[FB_X_Q_EW + 2] * x[FB_X_Q_EW + 2] + x[FB_X_Q_EW + 3] * x[FB_X_Q_EW + 3];
-        const double nr = sqrt(n2);
-        if (fabs(nr - 1.0) > 1e-8) {
-            x[FB_X_Q_EW] /= nr; x[FB_X_Q_EW + 1] /= nr; x[FB_X_Q_EW + 2] /= nr; x[FB_X_Q_EW + 3] /= nr;
-            mod = true;
-        }
-    }
+    };
+    if constexpr (KIN == FB_KIN_WA) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4); }
+    else if constexpr (KIN == FB_KIN_ECEF) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_WB + 4, 3); }
     const int stall0 = stall, eng0 = eng_state;
     if (aux.alpha > c172::alpha_stall_hi) stall = 1;
     else if (aux.alpha < c172::alpha_stall_lo) stall = 0;

@@ -154,7 +154,7 @@ FBD double x2_command(const KArgs& a, int64_t i, int k) {
 template <bool X> struct Dims { static constexpr int NXT = X ? (int)FB_X2_NX : (int)FB_NX; };
 
 // f_ode!(world): xdot (optional) and the output record y
-template <bool X>
+template <bool X, int KIN>
 __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y) {
     constexpr int NXT = Dims<X>::NXT;
     __shared__ double lds[LDS_TABLE_DOUBLES];
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
 #pragma unroll
         for (int k = 0; k < FB_NACT; k++) xd[X2_ACT + k] = 1 / ACT_TAU * (x2_command(a, i, k) - x[X2_ACT + k]);   // Actuator1.f_ode!, c172x.jl:39-52
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
     }
     if (xdot) {
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
 
 // f_step!(world). The reference acts on the y left behind by the last f_ode!; f_ode! is a pure
 // function of (x,u,s), so it is recomputed here from the current x.
-template <bool X>
+template <bool X, int KIN>
 __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     constexpr int NXT = Dims<X>::NXT;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
@@ -206,13 +206,13 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
-        f_step(x, stall, eng, in, aux, st);
+        st = rhs<KIN>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        f_step<KIN>(x, stall, eng, in, aux, st);
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
-        f_step(x, stall, eng, in, aux, st);
+        st = rhs<KIN>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        f_step<KIN>(x, stall, eng, in, aux, st);
     }
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * a.n + i] = x[k];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 // X = Cessna172X: seven more states (first-order actuators driven by the commands in cs / u, constant during a
 // launch: the control laws run between launches), inputs derived from the actuator positions; with 34 rows per panel
 // there is no LDS left for an input panel, so mixture / payload / commands are read from global memory (L1/L2 hits).
-template <bool X>
+template <bool X, int KIN>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     constexpr int NXT = Dims<X>::NXT;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
@@ -277,6 +277,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         auto emit = [&](int j, double kj) {
             const int idx = j * STEP_BLOCK + t;
             const double xs = xs_l[idx];
+#ifdef FB_DEBUG_ROW
+            if (j == FB_DEBUG_ROW && i == 1) printf("emit row %d stage %d xs %.17g kj %.17g acc %.17g xt %.17g\n", j, stage, xs, kj, acc_l[idx], xt[j]);
+#endif
             if (stage == 0) {
                 acc_l[idx] = kj;
                 xn[j] = xs + cdt * kj;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         bool mod = false;
         if constexpr (X) {
             const InputsX inl = {&xt[X2_ACT], a.u + i + lds_off, a.n, ui};
-            bits = rhs(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            bits = rhs<KIN>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             KArgs ao = a;
             ao.cs = a.cs + lds_off; ao.u = a.u + lds_off;
 #pragma unroll
@@ -305,13 +308,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
 #pragma unroll
                     for (int k = 0; k < 8; k++) a.q_pre[(int64_t)k * a.n + i] = xt[FB_X_Q_WB + k];
                 }
-                mod = f_step(xt, stall, eng, inl, aux, bits);
+                mod = f_step<KIN>(xt, stall, eng, inl, aux, bits);
             }
         } else {
             InputsLds<STEP_BLOCK> inl = in;
             inl.p = in.p + lds_off;
-            bits = rhs(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-            if (stage == 0 && pending_cb) mod = f_step(xt, stall, eng, in, aux, bits);
+            bits = rhs<KIN>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (stage == 0 && pending_cb) mod = f_step<KIN>(xt, stall, eng, in, aux, bits);
         }
         if (stage == 0 && pending_cb) {  // this evaluation sat at x_{n+1} (= xt): the discrete callbacks have run on it
             pending_cb = false;
@@ -415,7 +418,7 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
     double uraw[FB_NU];
     trim_assign(p, z, env, T, x, in, uraw);
     StepAux aux;
-    rhs(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, NoSink{});
+    rhs<FB_KIN_WA>(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, NoSink{});
     const double nv = sqrt(x[FB_X_V_EB_B] * x[FB_X_V_EB_B] + x[FB_X_V_EB_B + 1] * x[FB_X_V_EB_B + 1] + x[FB_X_V_EB_B + 2] * x[FB_X_V_EB_B + 2]);
     r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
@@ -513,6 +516,37 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     for (int k = 0; k < 7; k++) ts[(int64_t)k * n + i] = z[k];
     if (success) success[i] = cost <= 1e-16;
     if (cost_out) cost_out[i] = cost;
+}
+
+// f_init!(kinematics::ECEF / ::NED, ic) (kinematics.jl:255-280, 336-364) applied to the WA initial condition k_trim leaves
+// (ψ_nw = 0 there, so q_wb = q_nb and q_ew = ltf(n_e) exactly): rows FB_X_Q_WB.. are rewritten in the mechanisation's states.
+template <int KIN>
+__global__ __launch_bounds__(256) void k_kin_convert(KArgs a, const double* tp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int64_t n = a.n;
+    constexpr int KX = FB_X_Q_WB;
+    double k[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) k[j] = a.x[(int64_t)(KX + j) * n + i];
+    const quat q_nb = {k[0], k[1], k[2], k[3]}, q_en = {k[4], k[5], k[6], k[7]};
+    const double h_e = k[8];
+    const v3 n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
+    double o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (KIN == FB_KIN_ECEF) {
+        const quat q_eb = qmul(q_en, q_nb);
+        o[0] = q_eb.w; o[1] = q_eb.x; o[2] = q_eb.y; o[3] = q_eb.z; o[4] = n_e.x; o[5] = n_e.y; o[6] = n_e.z; o[7] = h_e;
+    } else {
+        const double q1 = q_nb.w, q2 = q_nb.x, q3 = q_nb.y, q4 = q_nb.z;   // REuler(q_nb), attitude.jl:382-391
+        o[0] = atan2(2 * (q1 * q4 + q2 * q3), 1 - 2 * (q3 * q3 + q4 * q4));
+        o[1] = asin(fmin(fmax(2 * (q1 * q3 - q2 * q4), -1.0), 1.0));
+        o[2] = atan2(2 * (q1 * q2 + q3 * q4), 1 - 2 * (q2 * q2 + q3 * q3));
+        o[3] = atan2(n_e.z, sqrt(n_e.x * n_e.x + n_e.y * n_e.y));           // LatLon(n_e), geodesy.jl:103-106
+        o[4] = atan2(n_e.y, n_e.x);
+        o[5] = h_e;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) a.x[(int64_t)(KX + j) * n + i] = o[j];
 }
 
 }  // namespace fbd

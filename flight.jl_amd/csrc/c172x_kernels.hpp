@@ -20,7 +20,7 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
     const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
     StepAux aux;
     CtlSink tap;
-    rhs(x, a.s[i], a.s[a.n + i], in, a.env, T, [](int, double) {}, aux, tap);
+    rhs<FB_KIN_WA>(x, a.s[i], a.s[a.n + i], in, a.env, T, [](int, double) {}, aux, tap);
     CtlIn v;
     v.EAS = tap.EAS; v.h_e = x[FB_X_H_E]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
     v.w_wb_b = {tap.wx, tap.wy, tap.wz};

@@ -86,14 +86,34 @@ static int32_t check_ready(fb_handle h) {
 }
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 static bool is_x2(fb_handle h) { return h->model == FB_MODEL_C172X2; }
-static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (int)FB_NX; }
+// states of the C ABI: 27 (WA), 26 (ECEF: q_eb[4] n_e[3] h_e), 24 (NED: ψ θ φ ϕ λ h_e), 34 (Cessna172Xv2); the device keeps
+// 27 (34) rows for every mechanisation, the unused kinematic rows stay zero
+static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (h->kin == FB_KIN_ECEF ? FB_NX - 1 : (h->kin == FB_KIN_NED ? FB_NX - 3 : (int)FB_NX)); }
+static int ecef_dev_row(int k) { return k < FB_X_Q_WB + 8 ? k : k + 1; }
+static int ned_dev_row(int k) { return k < FB_X_Q_WB + 6 ? k : k + 3; }
 // Cessna172X: row of the C ABI state layout (reference order: act after pwp) -> device row (actuators last)
 static int x2_dev_row(int k) { return k < FB_X2_ACT ? k : (k < FB_X2_KIN ? FB_NX + (k - FB_X2_ACT) : k - FB_NACT); }
+typedef int (*row_map_t)(int);
+static row_map_t row_map_of(fb_handle h);
 static int32_t check_ready_x2(fb_handle h) {
     if (int32_t rc = check_ready(h)) return rc;
     if (is_x2(h) && !h->have_gains) return fail("table CTL_GAINS has not been uploaded (fb_set_table)");
     return 0;
 }
+static row_map_t row_map_of(fb_handle h) {
+    if (is_x2(h)) return x2_dev_row;
+    if (h->kin == FB_KIN_ECEF) return ecef_dev_row;
+    if (h->kin == FB_KIN_NED) return ned_dev_row;
+    return nullptr;
+}
+// one launch statement per (model, kinematics) instance of a kernel template
+#define FB_LAUNCH_MK(KERNEL, GRID, BLOCK, ...)                                                                                       \
+    do {                                                                                                                              \
+        if (is_x2(h)) hipLaunchKernelGGL((KERNEL<true, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                          \
+        else if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL((KERNEL<false, FB_KIN_ECEF>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);     \
+        else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
+    } while (0)
 static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
     CtlArgs c;
     for (int k = 0; k < 10; k++) c.tab.lk[k] = h->gains + h->gains_off[k];
@@ -124,7 +144,8 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (!out) return fail("out is null");
     *out = nullptr;
     if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
-    if (model_id != FB_MODEL_ROBOT2D && kin_id != FB_KIN_WA) return fail("kinematics not implemented (only FB_KIN_WA)");
+    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
+    if (model_id == FB_MODEL_C172X2 && kin_id != FB_KIN_WA) return fail("Cessna172Xv2: only FB_KIN_WA is implemented");
     if (model_id != FB_MODEL_ROBOT2D && dtype != FB_F64) return fail("dtype not implemented for the Cessna 172 models (only FB_F64)");
     if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
     if (n <= 0) return fail("n must be positive");
@@ -148,7 +169,7 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
         *out = h;
         return 0;
     }
-    const int nx = nx_of(h);
+    const int nx = is_x2(h) ? (int)FB_X2_NX : (int)FB_NX;   // device rows
     HIPCHK(hipMalloc(&h->x_own, sizeof(double) * nx * n));
     HIPCHK(hipMalloc(&h->s_own, sizeof(int32_t) * FB_NS * n));
     if (is_x2(h)) {
@@ -303,7 +324,7 @@ int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
         h->t = 0.0;
         return 0;
     }
-    if (x) { if (int32_t rc = copy_rows(h, h->x, x, nullptr, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc; }
+    if (x) { if (int32_t rc = copy_rows(h, h->x, x, nullptr, nx_of(h), row_map_of(h))) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -315,7 +336,7 @@ int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) return x ? r2_download(h, h->r2, x, h->r2->r, FB_R2_NX) : 0;
-    if (x) { if (int32_t rc = copy_rows(h, h->x, nullptr, x, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc; }
+    if (x) { if (int32_t rc = copy_rows(h, h->x, nullptr, x, nx_of(h), row_map_of(h))) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(s, h->s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -362,6 +383,8 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     HIPCHK(hipMemcpyAsync(d_ts, trim_state, sizeof(double) * FB_NTS * n, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_trim, grid_for(n, 64), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost);
     HIPCHK(hipGetLastError());
+    if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL(k_kin_convert<FB_KIN_ECEF>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
+    if (h->kin == FB_KIN_NED) hipLaunchKernelGGL(k_kin_convert<FB_KIN_NED>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
     if (is_x2(h)) {  // f_init!(aircraft, trim): actuator states, then f_init!(avionics, vehicle) (aircraftbase.jl:255-265)
         hipLaunchKernelGGL(k_x2_init, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
         HIPCHK(hipGetLastError());
@@ -382,12 +405,11 @@ int32_t fb_f_ode(fb_handle h, double* xdot) {
     HIPCHK(hipSetDevice(h->device));
     const int64_t n = h->n;
     if (!h->y) HIPCHK(hipMalloc(&h->y, sizeof(double) * FB_NY * n));
-    if (xdot && !h->xdot) HIPCHK(hipMalloc(&h->xdot, sizeof(double) * nx_of(h) * n));
-    if (is_x2(h)) hipLaunchKernelGGL(k_f_ode<true>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
-    else hipLaunchKernelGGL(k_f_ode<false>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
+    if (xdot && !h->xdot) HIPCHK(hipMalloc(&h->xdot, sizeof(double) * (is_x2(h) ? (int)FB_X2_NX : (int)FB_NX) * n));
+    FB_LAUNCH_MK(k_f_ode, grid_for(n, 256), dim3(256), make_args(h), xdot ? h->xdot : (double*)nullptr, h->y);
     HIPCHK(hipGetLastError());
     if (xdot) {
-        if (int32_t rc = copy_rows(h, h->xdot, nullptr, xdot, nx_of(h), is_x2(h) ? x2_dev_row : nullptr)) return rc;
+        if (int32_t rc = copy_rows(h, h->xdot, nullptr, xdot, nx_of(h), row_map_of(h))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return 0;
@@ -402,8 +424,7 @@ int32_t fb_f_step(fb_handle h) {
     }
     if (int32_t rc = check_ready(h)) return rc;
     HIPCHK(hipSetDevice(h->device));
-    if (is_x2(h)) hipLaunchKernelGGL(k_f_step<true>, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
-    else hipLaunchKernelGGL(k_f_step<false>, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h));
+    FB_LAUNCH_MK(k_f_step, grid_for(h->n, 256), dim3(256), make_args(h));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -488,7 +509,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
             const int64_t to_periodic = ratio - (h->steps_done % ratio);
             int64_t k = left < to_periodic ? left : to_periodic;
             if (k > h->steps_per_launch) k = h->steps_per_launch;
-            hipLaunchKernelGGL(k_step<true>, grid_for(h->n, 256), dim3(256), 0, h->stream, a, (int)k);
+            hipLaunchKernelGGL((k_step<true, FB_KIN_WA>), grid_for(h->n, 256), dim3(256), 0, h->stream, a, (int)k);
             h->launches++;
             h->steps_done += k;
             left -= k;
@@ -497,7 +518,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
     } else {
         while (left > 0) {
             const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
-            hipLaunchKernelGGL(k_step<false>, grid_for(h->n, 256), dim3(256), 0, h->stream, a, k);
+            FB_LAUNCH_MK(k_step, grid_for(h->n, 256), dim3(256), a, k);
             left -= k;
             h->steps_done += k;
             h->launches++;

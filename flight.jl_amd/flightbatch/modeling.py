@@ -89,10 +89,12 @@ class BatchedWorld:
 
     MODEL = "FB_MODEL_C172S0"
 
-    def __init__(self, n: int, device: int = 0, tables: dict | None = None):
+    def __init__(self, n: int, device: int = 0, tables: dict | None = None, kinematics: str = "WA"):
+        """kinematics: "WA" (default, FP/kinematics.jl:148), "ECEF" (:250) or "NED" (:329) — Cessna172Sv0(kinematics)."""
         self.n = int(n)
         self._h = C.c_void_p()
-        check(lib.fb_create(K[self.MODEL], K["FB_KIN_WA"], K["FB_F64"], self.n, int(device), C.byref(self._h)))
+        self.kinematics = kinematics
+        check(lib.fb_create(K[self.MODEL], K["FB_KIN_" + kinematics], K["FB_F64"], self.n, int(device), C.byref(self._h)))
         nx = C.c_int32()
         check(lib.fb_dims(self._h, C.byref(nx), None, None, None))
         self.nx = nx.value

@@ -31,6 +31,9 @@ typedef struct fb_handle_s* fb_handle;
 /* ---- model / kinematics / dtype ids -------------------------------------------------------- */
 enum { FB_MODEL_C172S0 = 0, FB_MODEL_C172X2 = 1, FB_MODEL_ROBOT2D = 2 }; /* FA/c172/c172s/c172s0.jl:14-18 */
 enum { FB_KIN_WA = 0, FB_KIN_ECEF = 1, FB_KIN_NED = 2 };                 /* FP/kinematics.jl:148,250,329   */
+/* The kinematic block of x follows the mechanisation (Modeling.X of each, kinematics.jl:152-153, 252-253, 331-332):
+ * WA q_wb[4] q_ew[4] h_e (Nx = 27), ECEF q_eb[4] n_e[3] h_e (Nx = 26), NED psi theta phi lat lon h_e (Nx = 24); the blocks
+ * before (rows 0-11) and after it (w_eb_b, v_eb_b) are the same. fb_dims reports Nx. */
 enum { FB_F64 = 0, FB_F32 = 1 };
 
 /* ---- continuous state x[FB_NX] of Cessna172Sv0 + WA kinematics (SURVEY.md §8 state layout) ---- */

@@ -168,7 +168,9 @@ struct C172Disc {  // discrete states
 };
 
 // All constant model data of Cessna172Sv0
+enum KinKind : int { KIN_WA = 0, KIN_ECEF = 1, KIN_NED = 2 };  // kinematics.jl:148, 250, 329
 struct C172Model {
+    int kin = KIN_WA;  // kinematic mechanisation of the vehicle; rows X_KIN.. hold its 9 / 8 / 6 states, the rest stay zero
     AeroParams aero;
     AeroTables aero_tb;
     GearUnitParams ldg[3];  // left, right, nose
@@ -215,7 +217,13 @@ inline int32_t c172_f_ode(const C172Model& M, const Env& env, const C172Inputs& 
                           const double* x, double* xdot, C172Y& y) {
     int32_t st = 0;
     // kinematics.u .= dynamics.x ; f_ode!(kinematics)
-    st |= wa_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
+    if (M.kin == KIN_WA) st |= wa_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
+    else {
+        for (int k = 0; k < 9; k++) xdot[X_KIN + k] = 0;
+        if (M.kin == KIN_ECEF) ecef_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
+        else ned_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
+        if (!(y.kin.h_e >= H_MIN) || !(y.kin.h_o >= H_MIN)) st |= ST_ALT_RANGE;
+    }
     y.air = air_data(env, y.kin, st);
 
     // ---- systems (c172.jl:697-713) ----
@@ -298,7 +306,8 @@ inline int32_t c172_f_step(const C172Model& M, const C172Inputs& u, C172Disc& s,
     double x0[NX];
     for (int i = 0; i < NX; i++) x0[i] = x[i];
     const C172Disc s0 = s;
-    wa_f_step(x + X_KIN);
+    if (M.kin == KIN_WA) wa_f_step(x + X_KIN);
+    else if (M.kin == KIN_ECEF) ecef_f_step(x + X_KIN);   // NED: f_step! is a no-op (kinematics.jl:409)
     // aero stall hysteresis (c172.jl:375-384)
     if (y.aero.alpha > M.aero.alpha_stall[1]) s.stall = true;
     else if (y.aero.alpha < M.aero.alpha_stall[0]) s.stall = false;
@@ -396,7 +405,9 @@ inline void trim_assign(const C172Model& M, const TrimParams& tp, const TrimStat
                         double* x, C172Inputs& u, C172Disc& s) {
     const KinInit ki = trim_kin_init(ts, tp, env);
     for (int i = 0; i < NX; i++) x[i] = 0;
-    wa_init(ki, x + X_KIN, x + X_DYN);  // dynamics.x .= kinematics.u
+    if (M.kin == KIN_WA) wa_init(ki, x + X_KIN, x + X_DYN);  // dynamics.x .= kinematics.u
+    else if (M.kin == KIN_ECEF) ecef_init(ki, x + X_KIN, x + X_DYN);
+    else ned_init(ki, x + X_KIN, x + X_DYN);
     u = C172Inputs{};
     u.m_pilot = tp.payload[0]; u.m_copilot = tp.payload[1]; u.m_lpass = tp.payload[2]; u.m_rpass = tp.payload[3]; u.m_baggage = tp.payload[4];
     u.throttle = ts.throttle; u.mixture = tp.mixture; u.mixture_ctl = MIX_AUTO;

@@ -128,6 +128,13 @@ int32_t fo_max_threads() {
 #endif
 }
 
+// kinematic mechanisation used by every fo_c172_* call that follows (0 WA, 1 ECEF, 2 NED); state arrays keep 27 rows,
+// rows 12.. hold the mechanisation's 9 / 8 / 6 states and the unused ones stay zero
+int32_t fo_set_kinematics(int32_t kin) {
+    if (!g_model || kin < 0 || kin > 2) return -1;
+    g_model->kin = kin;
+    return 0;
+}
 // f_ode!(world) for n aircraft. env[7] = T_sl, p_sl, wind N,E,D, h_terrain, surface.
 int32_t fo_c172_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* env,
                       double* xdot, double* y, int32_t* status) {
