@@ -17,15 +17,15 @@ struct CtlTab {
     const double* lk[10];  // te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ lookups inside the FB_TABLE_CTL_GAINS blob (global memory)
 };
 struct CtlMem {
-    const double* cu;  // &cu[0 * n + i]
+    double* cu;        // &cu[0 * n + i]  (guidance rewrites references and mode requests)
     double* cs;        // &cs[0 * n + i]
     int64_t n;
-    FBD double U(int k) const { return cu[(int64_t)k * n]; }
+    FBD double& U(int k) const { return cu[(int64_t)k * n]; }
     FBD double& S(int k) const { return cs[(int64_t)k * n]; }
 };
 // what the control laws read from vehicle.y (XLonRed/XLonFull/XLatRed, Zte/Ztv/Zvh/Zφβ/Zar: c172x_ctl.jl:84-199, 745-810)
 struct CtlIn {
-    double EAS, h_e, theta, phi, clm, chi;
+    double EAS, h_e, theta, phi, clm, chi, lat, lon;
     v3 w_wb_b, w_eb_b;
     double alpha, beta, alpha_filt, beta_filt, n_eng;
     double pos[4];  // throttle, aileron, elevator, rudder positions (Ranged)
@@ -35,10 +35,12 @@ struct CtlIn {
 // the few output-record components the control laws need, tapped from rhs()
 struct CtlSink {
     static constexpr bool enabled = true, full = false;
-    double theta, phi, wx, wy, wz, vd, chi, EAS, alpha, beta;
+    double theta, phi, wx, wy, wz, vd, chi, EAS, alpha, beta, lat, lon;
     FBD void put(int k, double v) {
         if (k == FB_Y_KIN + 1) theta = v;
         else if (k == FB_Y_KIN + 2) phi = v;
+        else if (k == FB_Y_KIN + 15) lat = v;
+        else if (k == FB_Y_KIN + 16) lon = v;
         else if (k == FB_Y_KIN + 25) wx = v;
         else if (k == FB_Y_KIN + 26) wy = v;
         else if (k == FB_Y_KIN + 27) wz = v;
@@ -51,6 +53,7 @@ struct CtlSink {
 };
 
 FBD double sgnd(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
+FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
 constexpr double CTL_INF = __builtin_huge_val();
 
 // ---- gain lookup: bilinear over the (EAS, h) grid, record by record -------------------------------------------
@@ -230,8 +233,50 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     M.S(FB_CS_THROTTLE_CMD) = clampd(throttle_cmd, 0, 1); M.S(FB_CS_ELEVATOR_CMD) = clampd(elevator_cmd, -1, 1);
 }
 
+// ---- guidance: GuidanceLaws f_periodic! with SegmentGuidance (c172x/guidance/c172x_gdc.jl:113-149, 232-252, 297-329) -----------
+struct GeoPt { double lat, lon, h; };
+FBD v3 nvec_of(const GeoPt& p) {
+    double sla, cla, slo, clo;
+    sincos(p.lat, &sla, &cla); sincos(p.lon, &slo, &clo);
+    return {cla * clo, cla * slo, sla};
+}
+FBD v3 ecef_of(const GeoPt& p) {   // Cartesian(Geographic{LatLon, Ellipsoidal}), geodesy.jl:418-428
+    const v3 n = nvec_of(p);
+    const double R_E = wgs::a / sqrt(1 - wgs::e2 * n.z * n.z);
+    return {(R_E + p.h) * n.x, (R_E + p.h) * n.y, (R_E * (1 - wgs::e2) + p.h) * n.z};
+}
+// Runs before the control laws and may rewrite their inputs (χ_ref + χ_β request, h_ref + EAS_alt request).
+FBD void gdc_update(const CtlMem& M, const CtlIn& v) {
+    const int mode = v.on_gnd ? (int)FB_GDC_DIRECT : (int)M.U(FB_CU_GDC_MODE_REQ);
+    if (mode == FB_GDC_SEGMENT) {
+        const GeoPt p1 = {M.U(FB_CU_SEG_P1), M.U(FB_CU_SEG_P1 + 1), M.U(FB_CU_SEG_P1 + 2)};
+        const GeoPt p2 = {M.U(FB_CU_SEG_P2), M.U(FB_CU_SEG_P2 + 1), M.U(FB_CU_SEG_P2 + 2)};
+        const GeoPt Ob = {v.lat, v.lon, v.h_e};
+        const v3 r_e1_e = ecef_of(p1), r_e2_e = ecef_of(p2), r_eb_e = ecef_of(Ob);
+        const quat q_en = ltf_quat(nvec_of(Ob));
+        const v3 r_1b_n = qrot_inv(q_en, r_eb_e - r_e1_e), r_12_n = qrot_inv(q_en, r_e2_e - r_e1_e);
+        const v3 r_1b_h = {r_1b_n.x, r_1b_n.y, 0.0}, r_12_h = {r_12_n.x, r_12_n.y, 0.0};
+        const double s_12 = norm(r_12_h);
+        const v3 u_12 = {r_12_h.x / s_12, r_12_h.y / s_12, 0.0};
+        const double s_1b = dot(u_12, r_1b_h);
+        const double e_sb = cross(u_12, r_1b_h).z;                   // cross-track distance, positive right
+        const double h_s = p1.h + (p2.h - p1.h) * s_1b / s_12;       // segment altitude abeam the aircraft
+        const double chi_12 = atan2(u_12.y, u_12.x);
+        constexpr double dchi_inf = PI / 2, e_sf = 250.0, e_thr = 1000.0;   // c172x_gdc.jl:200-204
+        const double dchi = -dchi_inf / (PI / 2) * atan(e_sb / e_sf);
+        const double chi_ref = wrap_to_pi(chi_12 + dchi);
+        const bool hor = M.U(FB_CU_SEG_HOR_REQ) != 0;
+        const bool vrt = fabs(e_sb) < e_thr ? (M.U(FB_CU_SEG_VRT_REQ) != 0) : false;
+        M.S(FB_CS_SEG_DCHI) = dchi; M.S(FB_CS_SEG_CHI_REF) = chi_ref; M.S(FB_CS_SEG_H_REF) = h_s;
+        M.S(FB_CS_SEG_HOR_GDC) = hor ? 1.0 : 0.0; M.S(FB_CS_SEG_VRT_GDC) = vrt ? 1.0 : 0.0;
+        M.S(FB_CS_SEG_E_SB) = e_sb; M.S(FB_CS_SEG_S_1B) = s_1b;
+        if (hor) { M.U(FB_CU_CHI_REF) = chi_ref; M.U(FB_CU_LAT_MODE_REQ) = FB_LAT_CHI_BETA; }
+        if (vrt) { M.U(FB_CU_H_REF) = h_s; M.U(FB_CU_LON_MODE_REQ) = FB_LON_EAS_ALT; }
+    }
+    M.S(FB_CS_GDC_MODE) = mode;
+}
+
 // ---- lateral channel -----------------------------------------------------------------------------------------------
-FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
 FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
     const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
     double phi_ref = M.U(FB_CU_PHI_REF);

@@ -22,6 +22,7 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
     CtlSink tap;
     rhs<FB_KIN_WA>(x, a.s[i], a.s[a.n + i], in, a.env, T, [](int, double) {}, aux, tap);
     CtlIn v;
+    v.lat = tap.lat; v.lon = tap.lon;
     v.EAS = tap.EAS; v.h_e = x[FB_X_H_E]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
     v.w_wb_b = {tap.wx, tap.wy, tap.wz};
     v.w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
         for (int k = 0; k < 8; k++) x[FB_X_Q_WB + k] = a.q_pre[(int64_t)k * a.n + i];
     }
     const CtlIn v = x2_ctl_inputs(a, i, T, x, [&](int k) { return x2_command(a, i, k); });
-    const CtlMem M = {a.cu + i, a.cs + i, a.n};
+    const CtlMem M = {const_cast<double*>(a.cu) + i, a.cs + i, a.n};
+    gdc_update(M, v);   // Avionics f_periodic!: guidance first, then the control laws (c172x2.jl:27-37)
     ctl_lon(c.tab, M, c.dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
     ctl_lat(c.tab, M, c.dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
 }
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_x2_init(KArgs a, CtlArgs c) {
 #pragma unroll
     for (int k = 0; k < FB_NACT; k++) { x[X2_ACT + k] = cmd7[k]; a.x[(int64_t)(X2_ACT + k) * n + i] = cmd7[k]; }
     const CtlIn v = x2_ctl_inputs(a, i, T, x, [&](int k) { return clampd(cmd7[k], k == 0 ? 0.0 : -1.0, 1.0); });
-    const CtlMem M = {a.cu + i, a.cs + i, n};
+    const CtlMem M = {cu + i, a.cs + i, n};
     for (int k = 0; k < FB_NCS; k++) M.S(k) = 0;
     M.S(FB_CS_H_STATE) = FB_ALT_HOLD;
     auto U = [&](int k) -> double& { return cu[(int64_t)k * n + i]; };
@@ -91,6 +93,10 @@ __global__ __launch_bounds__(256) void k_x2_init(KArgs a, CtlArgs c) {
 #pragma unroll 1
     for (int m = 0; m < 3; m++) ctl_lat(c.tab, M, c.dT, v, lat_seq[m]);
     U(FB_CU_LON_MODE_REQ) = FB_LON_DIRECT; U(FB_CU_LAT_MODE_REQ) = FB_LAT_DIRECT;
+    // guidance defaults: mode direct, no requests, target = Segment() (c172x_gdc.jl:85, 206-210, 281-283)
+    U(FB_CU_GDC_MODE_REQ) = FB_GDC_DIRECT; U(FB_CU_SEG_HOR_REQ) = 0; U(FB_CU_SEG_VRT_REQ) = 0;
+    U(FB_CU_SEG_P1) = 0; U(FB_CU_SEG_P1 + 1) = 0; U(FB_CU_SEG_P1 + 2) = 0;
+    U(FB_CU_SEG_P2) = 1e-3; U(FB_CU_SEG_P2 + 1) = 0; U(FB_CU_SEG_P2 + 2) = 0;
 }
 
 }  // namespace fbd

@@ -10,5 +10,6 @@ from .modeling import (BatchedWorld, Simulation, SimulationTermination, TimeSeri
 from . import tables  # noqa: F401
 from . import sharding  # noqa: F401
 from .robot2d import Robot2DWorld, InitParameters  # noqa: F401
-from .c172x import Cessna172Xv2World, ModeControlLon, ModeControlLat  # noqa: F401
+from .c172x import Cessna172Xv2World, ModeControlLon, ModeControlLat, ModeGuidance  # noqa: F401
+from . import ctl_gains  # noqa: F401
 from .fleet import MixedFleet  # noqa: F401

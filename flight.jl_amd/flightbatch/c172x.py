@@ -38,6 +38,13 @@ _LAT_FIELDS = {"mode_req": "LAT_MODE_REQ", "aileron_axis": "AILERON_AXIS", "aile
                "χ_ref": "CHI_REF"}
 
 
+class ModeGuidance(enum.IntEnum):    # c172x_gdc.jl:19-23
+    direct = 0; segment = 1; circular = 2
+
+
+_GDC_FIELDS = {"mode_req": "GDC_MODE_REQ", "hor_gdc_req": "SEG_HOR_REQ", "vrt_gdc_req": "SEG_VRT_REQ"}
+
+
 class _Channel:
     """ctl.u.lon / ctl.u.lat: attribute access to rows of the cu array; assignments go to the device at once."""
 
@@ -58,7 +65,15 @@ class _ControlLaws:
     def __init__(self, world):
         self.lon = _Channel(world, _LON_FIELDS)
         self.lat = _Channel(world, _LAT_FIELDS)
+        self.gdc = _Channel(world, _GDC_FIELDS)     # avionics.gdc.u.mode_req, gdc.seg.u.hor_gdc_req / vrt_gdc_req
         self._w = world
+
+    def set_target(self, p1, p2):
+        """gdc.seg.u.target = Segment(p1, p2): end points as (latitude, longitude, ellipsoidal altitude), each [3] or [3, n]."""
+        cu = self._w.cu
+        cu[K["FB_CU_SEG_P1"]:K["FB_CU_SEG_P1"] + 3] = np.asarray(p1, dtype=np.float64).reshape(3, -1)
+        cu[K["FB_CU_SEG_P2"]:K["FB_CU_SEG_P2"] + 3] = np.asarray(p2, dtype=np.float64).reshape(3, -1)
+        self._w.cu = cu
 
     def y(self, name: str) -> np.ndarray:
         """A row of the control-law record (FB_CS_* without the prefix): modes, references, commands, compensator states."""

@@ -117,8 +117,12 @@ enum {
     FB_CU_ELEVATOR_OFFSET = 4, FB_CU_Q_REF = 5, FB_CU_THETA_REF = 6, FB_CU_EAS_REF = 7, FB_CU_CLM_REF = 8, FB_CU_H_REF = 9,
     FB_CU_LAT_MODE_REQ = 10, FB_CU_AILERON_AXIS = 11, FB_CU_AILERON_OFFSET = 12, FB_CU_RUDDER_AXIS = 13,
     FB_CU_RUDDER_OFFSET = 14, FB_CU_P_REF = 15, FB_CU_BETA_REF = 16, FB_CU_PHI_REF = 17, FB_CU_CHI_REF = 18,
-    FB_NCU = 19
+    /* guidance inputs (avionics.gdc.u.mode_req, gdc.seg.u: c172x/guidance/c172x_gdc.jl:206-210, 281-283). The target segment
+     * is given by its end points p1, p2 as (latitude, longitude, ellipsoidal altitude); default Segment(): (0,0,0) -> (1e-3,0,0) */
+    FB_CU_GDC_MODE_REQ = 19, FB_CU_SEG_HOR_REQ = 20, FB_CU_SEG_VRT_REQ = 21, FB_CU_SEG_P1 = 22, FB_CU_SEG_P2 = 25,
+    FB_NCU = 28
 };
+enum { FB_GDC_DIRECT = 0, FB_GDC_SEGMENT = 1, FB_GDC_CIRCULAR = 2 }; /* ModeGuidance, c172x_gdc.jl:19-23 */
 enum { /* ModeControlLon, c172x_ctl.jl:29-39 */
     FB_LON_DIRECT = 0, FB_LON_SAS = 1, FB_LON_THR_Q = 2, FB_LON_THR_THETA = 3, FB_LON_THR_EAS = 4, FB_LON_EAS_Q = 5,
     FB_LON_EAS_THETA = 6, FB_LON_EAS_CLM = 7, FB_LON_EAS_ALT = 8
@@ -141,7 +145,10 @@ enum {
     FB_CS_AR2AR = 39,    /* int[2] sat[2] */
     FB_CS_PHIBETA2AR = 43, /* int[2] sat[2] z_ref[2] */
     FB_CS_P2PHI_INT = 49, FB_CS_P2PHI_PID = 51, FB_CS_CHI2PHI_PID = 54,
-    FB_NCS = 57
+    /* guidance outputs (gdc.y.mode, gdc.seg.y: c172x_gdc.jl:212-220, 285-289) */
+    FB_CS_GDC_MODE = 57, FB_CS_SEG_DCHI = 58, FB_CS_SEG_CHI_REF = 59, FB_CS_SEG_H_REF = 60, FB_CS_SEG_HOR_GDC = 61,
+    FB_CS_SEG_VRT_GDC = 62, FB_CS_SEG_E_SB = 63, FB_CS_SEG_S_1B = 64,
+    FB_NCS = 65
 };
 /* FB_TABLE_CTL_GAINS blob: ten lookups in the order te2te, tv2te, vh2te (LQR, NX = 8, 8, 9), q2e, c2theta, v2t (PID),
  * ar2ar, phibeta2ar (LQR, NX = 8), p2phi, chi2phi (PID)  [files FA/c172/c172x/control/data/{te2te,tv2te,vh2te,q2e,c2θ,v2t,

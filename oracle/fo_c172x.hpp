@@ -105,6 +105,7 @@ inline void lqr_init(const double* g, const double* lo, const double* hi, double
 // ---- what the control laws read from vehicle.y ---------------------------------------------------------------
 struct CtlIn {
     double EAS = 0, h_e = 0, theta = 0, phi = 0, clm = 0, chi = 0;
+    LatLon ll;  // kinematics.y.ϕ_λ (guidance)
     V3 w_wb_b, w_eb_b;
     double alpha = 0, beta = 0, alpha_filt = 0, beta_filt = 0, n_eng = 0;
     double pos[4] = {0, 0, 0, 0};  // throttle, aileron, elevator, rudder actuator positions (Ranged)
@@ -114,7 +115,7 @@ struct CtlIn {
 inline CtlIn ctl_in_from(const C172Model& M, const C172Y& y, const double* x, const double* cmd4) {
     CtlIn c;
     c.EAS = y.air.EAS; c.h_e = y.kin.h_e; c.theta = y.kin.e_nb.theta; c.phi = y.kin.e_nb.phi; c.clm = -y.kin.v_eb_n.z;
-    c.chi = y.kin.chi_gnd; c.w_wb_b = y.kin.w_wb_b; c.w_eb_b = y.kin.w_eb_b;
+    c.chi = y.kin.chi_gnd; c.w_wb_b = y.kin.w_wb_b; c.w_eb_b = y.kin.w_eb_b; c.ll = y.kin.ll;
     c.alpha = y.aero.alpha; c.beta = y.aero.beta; c.alpha_filt = x[X_AFILT]; c.beta_filt = x[X_AFILT + 1];
     c.n_eng = x[X_ENG] / M.eng.w_rated;
     for (int k = 0; k < 4; k++) { c.pos[k] = rngd(x[X_ACT + k], ACT_LO[k], ACT_HI[k]); c.cmd[k] = rngd(cmd4[k], ACT_LO[k], ACT_HI[k]); }
@@ -265,8 +266,61 @@ inline void ctl_lat_periodic(const CtlGains& G, double dT, const CtlIn& v, const
     cs[FB_CS_AILERON_REF] = aileron_ref; cs[FB_CS_RUDDER_REF] = rudder_ref; cs[FB_CS_PHI_REF] = phi_ref;
     cs[FB_CS_AILERON_CMD] = rngd(aileron_cmd, -1, 1); cs[FB_CS_RUDDER_CMD] = rngd(rudder_cmd, -1, 1);
 }
-// Avionics f_periodic! (c172x2.jl:27-37) with guidance in `direct` mode (c172x_gdc.jl:297-329: a no-op then)
-inline void ctl_periodic(const CtlGains& G, double dT, const CtlIn& v, const double* cu, double* cs) {
+// ---- guidance (c172x/guidance/c172x_gdc.jl) -------------------------------------------------------------------------
+struct GeoPoint { LatLon ll; double h = 0; };   // Geographic{LatLon, Ellipsoidal}
+inline V3 cartesian_of(const GeoPoint& p) { return cartesian_from_geographic(nvector_from_latlon(p.ll), p.h); }
+// Segment(p1; s, χ, Δh) (c172x_gdc.jl:56-83): the end point s metres along azimuth χ in the local-level frame of p1
+inline GeoPoint segment_end(const GeoPoint& p1, double s, double chi, double dh) {
+    const Quat q_en1 = ltf(nvector_from_latlon(p1.ll));
+    const V3 r_12_e = rotate(q_en1, V3{s * std::cos(chi), s * std::sin(chi), 0.0});
+    const V3 r_e2_e = cartesian_of(p1) + r_12_e;
+    const GeoNE g2 = geographic_from_cartesian(r_e2_e);   // LatLon(r_e2_e): Cartesian -> NVector -> LatLon
+    return {latlon_from_nvector(g2.n_e), p1.h + dh};
+}
+struct SegmentData { double chi_12 = 0, gamma_12 = 0, s_12 = 0, s_1b = 0, s_2b = 0, e_sb = 0, v_sb = 0, h_s = 0; };
+// SegmentGuidanceData(seg, Ob) (c172x_gdc.jl:113-149)
+inline SegmentData segment_data(const GeoPoint& p1, const GeoPoint& p2, const GeoPoint& Ob) {
+    const V3 r_e1_e = cartesian_of(p1), r_e2_e = cartesian_of(p2), r_eb_e = cartesian_of(Ob);
+    const Quat q_en = ltf(nvector_from_latlon(Ob.ll));
+    const V3 r_1b_n = rotate(inv(q_en), r_eb_e - r_e1_e);
+    const V3 r_1b_h = {r_1b_n.x, r_1b_n.y, 0.0};
+    const V3 r_12_n = rotate(inv(q_en), r_e2_e - r_e1_e);
+    const V3 r_12_h = {r_12_n.x, r_12_n.y, 0.0};
+    SegmentData d;
+    d.s_12 = norm(r_12_h);
+    const V3 u_12 = r_12_h / d.s_12;
+    d.s_1b = dot(u_12, r_1b_h);
+    d.s_2b = d.s_1b - d.s_12;
+    d.e_sb = cross(u_12, r_1b_h).z;
+    d.h_s = p1.h + (p2.h - p1.h) * d.s_1b / d.s_12;
+    d.v_sb = Ob.h - d.h_s;
+    d.chi_12 = azimuth(u_12);
+    d.gamma_12 = std::atan2(p2.h - p1.h, d.s_12);
+    return d;
+}
+// GuidanceLaws f_periodic! (c172x_gdc.jl:297-329) with SegmentGuidance (:232-252). Writes the control laws' inputs cu.
+inline void gdc_periodic(const CtlIn& v, double* cu, double* cs) {
+    const int mode_req = (int)cu[FB_CU_GDC_MODE_REQ];
+    const int mode = v.on_gnd ? (int)FB_GDC_DIRECT : mode_req;
+    if (mode == FB_GDC_SEGMENT) {
+        const GeoPoint p1 = {{cu[FB_CU_SEG_P1], cu[FB_CU_SEG_P1 + 1]}, cu[FB_CU_SEG_P1 + 2]};
+        const GeoPoint p2 = {{cu[FB_CU_SEG_P2], cu[FB_CU_SEG_P2 + 1]}, cu[FB_CU_SEG_P2 + 2]};
+        const SegmentData d = segment_data(p1, p2, GeoPoint{v.ll, v.h_e});
+        const double dchi_inf = PI / 2, e_sf = 250.0, e_thr = 1000.0;   // c172x_gdc.jl:200-204
+        const double dchi = -dchi_inf / (PI / 2) * std::atan(d.e_sb / e_sf);
+        const double chi_ref = wrap_to_pi(d.chi_12 + dchi);
+        const bool hor = cu[FB_CU_SEG_HOR_REQ] != 0;
+        const bool vrt = std::fabs(d.e_sb) < e_thr ? (cu[FB_CU_SEG_VRT_REQ] != 0) : false;
+        cs[FB_CS_SEG_DCHI] = dchi; cs[FB_CS_SEG_CHI_REF] = chi_ref; cs[FB_CS_SEG_H_REF] = d.h_s;
+        cs[FB_CS_SEG_HOR_GDC] = hor; cs[FB_CS_SEG_VRT_GDC] = vrt; cs[FB_CS_SEG_E_SB] = d.e_sb; cs[FB_CS_SEG_S_1B] = d.s_1b;
+        if (hor) { cu[FB_CU_CHI_REF] = chi_ref; cu[FB_CU_LAT_MODE_REQ] = FB_LAT_CHI_BETA; }
+        if (vrt) { cu[FB_CU_H_REF] = d.h_s; cu[FB_CU_LON_MODE_REQ] = FB_LON_EAS_ALT; }
+    }
+    cs[FB_CS_GDC_MODE] = mode;
+}
+// Avionics f_periodic! (c172x2.jl:27-37): guidance (it may rewrite the control laws' inputs), then the control laws
+inline void ctl_periodic(const CtlGains& G, double dT, const CtlIn& v, double* cu, double* cs) {
+    gdc_periodic(v, cu, cs);
     ctl_lon_periodic(G, dT, v, cu, cs);
     ctl_lat_periodic(G, dT, v, cu, cs);
 }
@@ -285,6 +339,10 @@ inline void ctl_init(const CtlGains& G, double dT, const CtlIn& v, double beta, 
     cu[FB_CU_P_REF] = v.w_wb_b.x; cu[FB_CU_PHI_REF] = v.phi; cu[FB_CU_BETA_REF] = beta; cu[FB_CU_CHI_REF] = v.chi;
     const int lat_seq[3] = {FB_LAT_SAS, FB_LAT_PHI_BETA, FB_LAT_DIRECT};
     for (int m : lat_seq) { cu[FB_CU_LAT_MODE_REQ] = m; ctl_lat_periodic(G, dT, v, cu, cs); }
+    // guidance: GuidanceLawsU / SegmentGuidanceU defaults (c172x_gdc.jl:206-210, 281-283; Segment() :85)
+    cu[FB_CU_GDC_MODE_REQ] = FB_GDC_DIRECT; cu[FB_CU_SEG_HOR_REQ] = 0; cu[FB_CU_SEG_VRT_REQ] = 0;
+    cu[FB_CU_SEG_P1] = 0; cu[FB_CU_SEG_P1 + 1] = 0; cu[FB_CU_SEG_P1 + 2] = 0;
+    cu[FB_CU_SEG_P2] = 1e-3; cu[FB_CU_SEG_P2 + 1] = 0; cu[FB_CU_SEG_P2 + 2] = 0;
 }
 
 // ---- vehicle with fly-by-wire actuation ------------------------------------------------------------------------
@@ -310,7 +368,7 @@ inline int32_t c172x_f_ode(const C172Model& M, const Env& env, const C172Inputs&
 }
 // One step!(sim): RK4 over the 34 states, evaluation at the new state, f_step!, then — when `periodic` — the control laws
 // (they read the y of that last evaluation, aircraftbase.jl:232-242; sim.jl:204-218).
-inline int32_t c172x_step(const C172Model& M, const CtlGains& G, const Env& env, const C172Inputs& u, const double* cu, double* cs,
+inline int32_t c172x_step(const C172Model& M, const CtlGains& G, const Env& env, const C172Inputs& u, double* cu, double* cs,
                           C172Disc& s, double* x, double dt, double dT, bool periodic, C172Y& y) {
     int32_t st = 0;
     double k1[NXX], k2[NXX], k3[NXX], k4[NXX], xt[NXX], cmd7[7];

@@ -581,6 +581,16 @@ static TrimParams trim_params_from(const double* tp, int64_t n, int64_t i) {
     for (int k = 0; k < 5; k++) p.payload[k] = TP(FB_TP_PAYLOAD + k);
     return p;
 }
+// Segment(p1; s, χ, Δh).p2 and SegmentGuidanceData(seg, Ob) (c172x_gdc.jl:56-83, 113-149). Points = (lat, lon, h).
+void fo_segment_end(const double* p1, double s_len, double chi, double dh, double* p2) {
+    const GeoPoint e = segment_end(GeoPoint{{p1[0], p1[1]}, p1[2]}, s_len, chi, dh);
+    p2[0] = e.ll.phi; p2[1] = e.ll.lam; p2[2] = e.h;
+}
+void fo_segment_data(const double* p1, const double* p2, const double* ob, double* out8) {
+    const SegmentData d = segment_data(GeoPoint{{p1[0], p1[1]}, p1[2]}, GeoPoint{{p2[0], p2[1]}, p2[2]}, GeoPoint{{ob[0], ob[1]}, ob[2]});
+    const double v[8] = {d.chi_12, d.gamma_12, d.s_12, d.s_1b, d.s_2b, d.e_sb, d.v_sb, d.h_s};
+    for (int k = 0; k < 8; k++) out8[k] = v[k];
+}
 // f_init!(aircraft, TrimParameters): trim, actuator states, control-law initialisation. dT = controller sample period.
 int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double* env, const double* blob, double dT, double* x,
                            double* u, int32_t* ui, int32_t* s, double* cu, double* cs, int32_t* success, double* cost, int32_t threads) {
@@ -609,7 +619,7 @@ int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double
     return 0;
 }
 // nsteps x step!(sim) with the control laws every `ratio` steps (step0 = steps already taken since init).
-int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* cu, double* cs,
+int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
                       const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
                       int32_t threads, double* traj, int64_t save_every) {
     const Env e = env_from(env);
@@ -639,6 +649,7 @@ int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, 
         }
         for (int k = 0; k < NXX; k++) x[k * n + i] = xi[k];
         for (int k = 0; k < FB_NCS; k++) cs[k * n + i] = csi[k];
+        for (int k = 0; k < FB_NCU; k++) cu[k * n + i] = cui[k];   // guidance rewrites references and mode requests
         s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
         if (status) status[i] = st;
     }
@@ -665,7 +676,7 @@ int32_t fo_c172x_f_ode(int64_t n, const double* x, const double* u, const int32_
     return 0;
 }
 // f_periodic!(Unconditional(), world): the control laws on the y of an f_ode! at the current x
-int32_t fo_c172x_f_periodic(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* cu, double* cs,
+int32_t fo_c172x_f_periodic(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, double* cu, double* cs,
                             const double* env, const double* blob, double dT) {
     const Env e = env_from(env);
     CtlGains G; G.bind(blob);
@@ -682,6 +693,7 @@ int32_t fo_c172x_f_periodic(int64_t n, const double* x, const double* u, const i
         c172x_f_ode(*g_model, e, in, cmd7, d, xi, xd, Y);
         ctl_periodic(G, dT, ctl_in_from(*g_model, Y, xi, cmd7), cui, csi);
         for (int k = 0; k < FB_NCS; k++) cs[k * n + i] = csi[k];
+        for (int k = 0; k < FB_NCU; k++) cu[k * n + i] = cui[k];
     }
     return 0;
 }

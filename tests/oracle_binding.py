@@ -113,7 +113,8 @@ class OracleX:
         n = tp.shape[1]
         tp = np.ascontiguousarray(tp); ts = np.array(ts, dtype=np.float64, order="C")
         x = np.zeros((34, n)); u = np.zeros((16, n)); ui = np.zeros(n, np.int32); s = np.zeros((2, n), np.int32)
-        cu = np.zeros((19, n)); cs = np.zeros((57, n)); ok = np.zeros(n, np.int32); cost = np.zeros(n)
+        K = header_enums()
+        cu = np.zeros((K["FB_NCU"], n)); cs = np.zeros((K["FB_NCS"], n)); ok = np.zeros(n, np.int32); cost = np.zeros(n)
         self.lib.fo_c172x_trim_init(C.c_int64(n), _p(tp), _p(ts), _p(env), _p(self.blob), C.c_double(dT), _p(x), _p(u), _p(ui), _p(s),
                                     _p(cu), _p(cs), _p(ok), _p(cost), C.c_int32(threads))
         return dict(ts=ts, x=x, u=u, ui=ui, s=s, cu=cu, cs=cs, ok=ok.astype(bool), cost=cost)

@@ -177,3 +177,42 @@ def test_checkpoint_restore_resumes_bitwise(fb, gains):
         u = w.u; u[0] = 2; u[3] = 1.0; w.u = u
 
     exercise(lambda: fb.Robot2DWorld(n, dtype="f32"), prep_r2, 0.37, 1.0, dt=0.01, Δt=0.02, steps_per_launch=50)
+
+
+def test_x2_segment_guidance_matches_oracle(fb, oracle, gains):
+    """Segment guidance (c172x_gdc.jl:232-329) in the loop: every aircraft gets its own target segment (left / right of its
+    course, above / below), horizontal and vertical guidance requested; 30 s against the oracle, then the same run continued
+    to 120 s must have captured the segment."""
+    from test_oracle_c172x import seg_end
+    K = fb.K
+    n = 512
+    w, sim, X, env, o = make_pair(fb, oracle, gains, n, seed=23)
+    perm = ref_to_dev_rows(K)
+    fb.f_ode(w)
+    y = w.y
+    rng = np.random.default_rng(11)
+    p1 = np.zeros((3, n)); p2 = np.zeros((3, n))
+    for i in range(n):
+        ob = np.array([y[K["FB_Y_KIN"] + 15, i], y[K["FB_Y_KIN"] + 16, i], y[K["FB_Y_KIN"] + 20, i]])
+        chi = y[K["FB_Y_KIN"] + 38, i]
+        p1[:, i] = seg_end(oracle, ob, rng.uniform(100, 600), chi + rng.choice([-1, 1]) * np.pi / 2, rng.uniform(-40, 40))
+        p2[:, i] = seg_end(oracle, p1[:, i], 3e4, chi + rng.uniform(-0.3, 0.3), rng.uniform(-100, 100))
+    w.ctl.set_target(p1, p2)
+    w.ctl.gdc.mode_req = float(fb.ModeGuidance.segment); w.ctl.gdc.hor_gdc_req = 1.0; w.ctl.gdc.vrt_gdc_req = 1.0
+    o["cu"] = np.ascontiguousarray(w.cu); o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
+    fb.step(sim, 30.0); w.sync()
+    X.step(o, env, 0.01, 2, 3000)
+    ok = (w.status == 0) & (o["status"] == 0) & w.trim_success
+    assert ok.mean() > 0.6 and np.array_equal(w.status != 0, o["status"] != 0)
+    err = (np.abs(w.x - o["x"][perm]) / x_scale(o["x"])[perm])[:, ok]
+    cerr = (np.abs(w.cs - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0))[:, ok]
+    uerr = (np.abs(w.cu - o["cu"]) / np.maximum(np.abs(o["cu"]), 1.0))[:, ok]
+    print("guidance closed loop after 3000 steps: state", err.max(), "record", cerr.max(), "inputs", uerr.max())
+    assert err.max() < 1e-6 and cerr.max() < 1e-6 and uerr.max() < 1e-6
+    assert (w.ctl.y("GDC_MODE")[ok] == fb.ModeGuidance.segment).all() and (w.ctl.y("LAT_MODE")[ok] == fb.ModeControlLat.χ_β).all()
+    fb.step(sim, 90.0); w.sync()
+    good = ok & (w.status == 0)
+    e_sb = np.abs(w.ctl.y("SEG_E_SB")[good])
+    print("cross-track error after 120 s: median", np.median(e_sb), "max", e_sb.max())
+    assert np.median(e_sb) < 2.0 and (e_sb < 20.0).mean() > 0.95
+    w.close()

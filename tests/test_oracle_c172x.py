@@ -114,7 +114,7 @@ def test_ground_overrides_mode_requests(oracle, gains):
     x[K["FB_X_Q_WB"]:K["FB_X_Q_WB"] + 4, 0] = [1, 0, 0, 0]
     y0 = oracle.f_ode(x[:27], o["u"], o["ui"], o["s"], env)[1][:, 0]
     x[K["FB_X_H_E"]] += 1.9 - y0[K["FB_Y_KIN"] + 21]   # orthometric height 1.9 m (the geoid is about 17.2 m up at ϕ = λ = 0)
-    st = dict(x=x, u=o["u"], ui=o["ui"], s=o["s"], cu=np.zeros((19, 1)), cs=np.zeros((57, 1)), status=np.zeros(1, np.int32), nstep=0)
+    st = dict(x=x, u=o["u"], ui=o["ui"], s=o["s"], cu=np.zeros((K["FB_NCU"], 1)), cs=np.zeros((K["FB_NCS"], 1)), status=np.zeros(1, np.int32), nstep=0)
     st["cs"][K["FB_CS_H_STATE"]] = 1
     st["cu"][K["FB_CU_LON_MODE_REQ"]] = K["FB_LON_EAS_CLM"]; st["cu"][K["FB_CU_LAT_MODE_REQ"]] = K["FB_LAT_P_BETA"]
     st["cu"][K["FB_CU_THROTTLE_AXIS"]] = 0.1; st["cu"][K["FB_CU_ELEVATOR_AXIS"]] = 0.3
@@ -239,3 +239,85 @@ def test_altitude_acquire_and_hold(oracle, gains):
     sim.step(80)
     assert sim.cs("H_STATE") == K["FB_ALT_HOLD"] and abs(sim.y()[Y_H_E] - sim.cu("H_REF")) < 1e-1
     assert sim.cs("LON_MODE") == K["FB_LON_EAS_ALT"]
+
+
+# ---- guidance: lib/FlightApps/test/c172/test_c172x2.jl --------------------------------------------------------------
+def seg_end(oracle, p1, s, chi, dh):
+    p1 = np.asarray(p1, dtype=np.float64); p2 = np.zeros(3)
+    oracle.lib.fo_segment_end(p1.ctypes.data_as(_D), C.c_double(s), C.c_double(chi), C.c_double(dh), p2.ctypes.data_as(_D))
+    return p2
+
+
+def seg_data(oracle, p1, p2, ob):
+    out = np.zeros(8)
+    a, b, c = (np.asarray(v, dtype=np.float64) for v in (p1, p2, ob))
+    oracle.lib.fo_segment_data(a.ctypes.data_as(_D), b.ctypes.data_as(_D), c.ctypes.data_as(_D), out.ctypes.data_as(_D))
+    return dict(zip(("chi_12", "gamma_12", "s_12", "s_1b", "s_2b", "e_sb", "v_sb", "h_s"), out))
+
+
+def test_segment_geometry(oracle):
+    """test_c172x2.jl:32-52: a point 1 km away at 45° off a 10 km, 5° climbing segment."""
+    chi, dchi, s = np.pi / 3, np.pi / 4, 1e3
+    p1 = np.zeros(3)
+    p2 = seg_end(oracle, p1, 1e4, chi, 1e4 * np.tan(np.deg2rad(5)))
+    p = seg_end(oracle, p1, s, chi + dchi, 0.0)
+    d = seg_data(oracle, p1, p2, p)
+    assert abs(d["s_1b"] - s * np.cos(dchi)) < 1e-2 and abs(d["e_sb"] - s * np.sin(dchi)) < 1e-2
+    assert abs(d["h_s"] - d["s_1b"] * np.tan(np.deg2rad(5))) < 1e-2
+    assert abs(d["chi_12"] - chi) < 1e-4 and abs(d["gamma_12"] - np.deg2rad(5)) < 1e-4 and abs(d["s_12"] - 1e4) < 5.0   # measured in the local-level frame of the aircraft, not of p1
+    di = seg_data(oracle, p2, p1, p)          # -seg
+    assert abs(di["e_sb"] + d["e_sb"]) < 1e-2
+
+
+def test_segment_guidance(oracle, gains):
+    """test_c172x2.jl:56-178: mode arbitration, horizontal / vertical engagement, sign of the intercept angle, and the
+    control-law mode requests being released when guidance is switched off."""
+    sim = XSim(oracle, gains).init_air()
+    y = sim.y()
+    ob = np.array([y[K["FB_Y_KIN"] + 15], y[K["FB_Y_KIN"] + 16], y[Y_H_E]])
+    chi_ac, h_e, e_thr = y[Y_CHI], y[Y_H_E], 1000.0
+
+    def target(side, dist, dh):
+        aux = seg_end(oracle, ob, dist, chi_ac + side * np.pi / 2, dh)
+        p2 = seg_end(oracle, aux, 1e4, 0.0, 1e4 * np.tan(np.deg2rad(5)))
+        sim.st["cu"][K["FB_CU_SEG_P1"]:K["FB_CU_SEG_P1"] + 3, 0] = aux
+        sim.st["cu"][K["FB_CU_SEG_P2"]:K["FB_CU_SEG_P2"] + 3, 0] = p2
+
+    sim.set(gdc_mode_req=K["FB_GDC_SEGMENT"], seg_hor_req=1, seg_vrt_req=1)
+    target(+1, e_thr / 2, 100.0)
+    sim.step(0.01)
+    assert sim.cs("GDC_MODE") == K["FB_GDC_SEGMENT"] and sim.cs("SEG_HOR_GDC") == 1
+    assert sim.cs("LAT_MODE") == K["FB_LAT_CHI_BETA"] and sim.cu("CHI_REF") == sim.cs("SEG_CHI_REF")
+    assert sim.cs("SEG_VRT_GDC") == 1 and sim.cs("LON_MODE") in (K["FB_LON_EAS_ALT"], K["FB_LON_THR_EAS"])
+    assert sim.cu("H_REF") == sim.cs("SEG_H_REF") and abs(sim.cu("H_REF") - (h_e + 100.0)) < 1
+    assert sim.cs("SEG_DCHI") > 0
+    target(-1, e_thr / 2, 0.0); sim.step(0.01)
+    assert sim.cs("SEG_DCHI") < 0
+    target(+1, 2 * e_thr, 0.0); sim.step(0.01)
+    assert sim.cs("SEG_VRT_GDC") == 0
+    lon_prev = sim.cs("LON_MODE")
+    sim.set(seg_vrt_req=0); sim.step(0.01)
+    assert sim.cs("SEG_VRT_GDC") == 0 and sim.cs("LON_MODE") == lon_prev
+    sim.set(lon_mode_req=K["FB_LON_SAS"]); sim.step(0.01)
+    assert sim.cs("LON_MODE") == K["FB_LON_SAS"]
+    lat_prev = sim.cs("LAT_MODE")
+    sim.set(seg_hor_req=0); sim.step(0.01)
+    assert sim.cs("SEG_HOR_GDC") == 0 and sim.cs("LAT_MODE") == lat_prev
+    sim.set(lat_mode_req=K["FB_LAT_SAS"]); sim.step(0.01)
+    assert sim.cs("LAT_MODE") == K["FB_LAT_SAS"]
+
+
+def test_segment_guidance_captures_the_segment(oracle, gains):
+    """Closed loop beyond the reference's one-sample checks: flying for 120 s the aircraft must settle on the segment
+    (cross-track error -> 0, altitude on the segment's profile)."""
+    sim = XSim(oracle, gains).init_air()
+    y = sim.y()
+    ob = np.array([y[K["FB_Y_KIN"] + 15], y[K["FB_Y_KIN"] + 16], y[Y_H_E]])
+    p1 = seg_end(oracle, ob, 400.0, y[Y_CHI] + np.pi / 2, 30.0)
+    p2 = seg_end(oracle, p1, 2e4, y[Y_CHI], 0.0)
+    sim.st["cu"][K["FB_CU_SEG_P1"]:K["FB_CU_SEG_P1"] + 3, 0] = p1
+    sim.st["cu"][K["FB_CU_SEG_P2"]:K["FB_CU_SEG_P2"] + 3, 0] = p2
+    sim.set(gdc_mode_req=K["FB_GDC_SEGMENT"], seg_hor_req=1, seg_vrt_req=1)
+    sim.step(120)
+    assert abs(sim.cs("SEG_E_SB")) < 5.0 and abs(sim.y()[Y_H_E] - sim.cs("SEG_H_REF")) < 1.0
+    assert sim.cs("LAT_MODE") == K["FB_LAT_CHI_BETA"] and sim.cs("LON_MODE") == K["FB_LON_EAS_ALT"]
