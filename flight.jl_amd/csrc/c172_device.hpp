@@ -438,7 +438,11 @@ struct PanelSink {
     int64_t n;
     FBD void put(int k, double v) const { Y[(int64_t)k * n] = v; }
 };
-template <int KIN, class Sink, class Emit, class In, int NXT>
+// GROUND = false compiles the landing gear's ground-contact branch (and the three per-wheel geodetic conversions) out: such an
+// instance can only evaluate states in the high-clearance regime and answers FB_ST_INTERNAL_REDO anywhere else, so that the
+// caller repeats the work with the full instance (k_step: the airborne pass, then a pass over the lanes that asked for it).
+constexpr int32_t FB_ST_INTERNAL_REDO = 1 << 30;
+template <int KIN, bool GROUND = true, class Sink, class Emit, class In, int NXT>
 FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, const Env& env, const Tables& T,
                 Emit&& emit, StepAux& aux, Sink&& sink) {
     using namespace c172;
@@ -658,7 +662,10 @@ FBD int32_t rhs(const double (&x)[NXT], int stall, int eng_state, const In& in, 
     // moves by < 1 mm over that distance, so when Ob is more than 10 m above the terrain no wheel can touch it:
     // wow = false, zero wrench, regulator input 0 (landinggear.jl:255-258, 418-424) without evaluating the three
     // ECEF->geodetic conversions and geoid gathers. Not taken when the FULL output record (which logs Δh) is requested.
-    const bool high_clearance = !SinkT::full && (h_o - env.h_trn > 10.0);
+    static_assert(GROUND || !SinkT::full, "the full output record needs the ground-capable instance");
+    const bool clear10 = !SinkT::full && (h_o - env.h_trn > 10.0);
+    if (!GROUND && !clear10) st |= FB_ST_INTERNAL_REDO;
+    const bool high_clearance = GROUND ? clear10 : true;
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         FB_PHASE_FENCE();

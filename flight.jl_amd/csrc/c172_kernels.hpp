@@ -117,6 +117,7 @@ struct KArgs {
     double* cs;         // [FB_NCS x n] control-law record (actuator commands live here)
     const double* cu;   // [FB_NCU x n] control-law inputs
     double* q_pre;      // [8 x n] q_wb, q_ew of the last evaluation before f_step! (what the periodic update must see)
+    int32_t* redo;      // [n] set by the airborne pass of k_step for lanes that came within reach of the ground
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
@@ -236,7 +237,11 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 // X = Cessna172X: seven more states (first-order actuators driven by the commands in cs / u, constant during a
 // launch: the control laws run between launches), inputs derived from the actuator positions; with 34 rows per panel
 // there is no LDS left for an input panel, so mixture / payload / commands are read from global memory (L1/L2 hits).
-template <bool X, int KIN>
+// Two passes per launch group: the AIRBORNE instance (GROUND = false: no ground-contact code, no call ABI, 15 % faster)
+// steps every lane; a lane that comes within 10 m of the terrain at any evaluation stops without committing anything and
+// raises its redo flag; the GROUND-capable instance then re-runs exactly those lanes from the same launch-start state
+// (workgroups without such a lane leave at once).
+template <bool X, int KIN, bool GROUND>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     constexpr int NXT = Dims<X>::NXT;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
@@ -244,9 +249,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     __shared__ double xs_l[NXT * STEP_BLOCK];   // x_n
     __shared__ double acc_l[NXT * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
     __shared__ double in_l[X ? 8 : INPUT_PANEL_ROWS * STEP_BLOCK];  // Sv0: per-lane inputs, read at the point of use
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    if constexpr (GROUND) {   // second pass: only the lanes the airborne pass handed over
+        const int mine = (i < a.n) && a.redo[i] != 0;
+        if (!__syncthreads_or(mine)) return;
+        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+        if (!mine) return;
+        a.redo[i] = 0;
+    } else {
+        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+        if (i >= a.n) return;
+    }
     if (a.status[i] != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
     bool dead = false;             // a status bit was raised during this launch (bits go straight to memory: rare)
     const int t = threadIdx.x;
@@ -298,7 +311,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         bool mod = false;
         if constexpr (X) {
             const InputsX inl = {&xt[X2_ACT], a.u + i + lds_off, a.n, ui};
-            bits = rhs<KIN>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            bits = rhs<KIN, GROUND>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
             KArgs ao = a;
             ao.cs = a.cs + lds_off; ao.u = a.u + lds_off;
 #pragma unroll
@@ -313,7 +327,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         } else {
             InputsLds<STEP_BLOCK> inl = in;
             inl.p = in.p + lds_off;
-            bits = rhs<KIN>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            bits = rhs<KIN, GROUND>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
             if (stage == 0 && pending_cb) mod = f_step<KIN>(xt, stall, eng, in, aux, bits);
         }
         if (stage == 0 && pending_cb) {  // this evaluation sat at x_{n+1} (= xt): the discrete callbacks have run on it

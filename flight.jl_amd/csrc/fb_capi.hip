@@ -59,6 +59,7 @@ struct fb_handle_s {
     double* cs = nullptr;      // [FB_NCS x n] control-law record
     double* cu = nullptr;      // [FB_NCU x n] control-law inputs
     double* q_pre = nullptr;   // [8 x n]
+    int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of k_step
     double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
     int64_t gains_off[10] = {0};
     bool have_gains = false;
@@ -72,7 +73,7 @@ static KArgs make_args(fb_handle h) {
     a.n = h->n;
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface};
     a.dt = h->params.dt;
-    a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre;
+    a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo;
     return a;
 }
 static int32_t check_ready(fb_handle h) {
@@ -113,6 +114,23 @@ static row_map_t row_map_of(fb_handle h) {
         else if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL((KERNEL<false, FB_KIN_ECEF>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);     \
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
+    } while (0)
+// the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
+#define FB_LAUNCH_STEP(GRID, A, K)                                                                                                    \
+    do {                                                                                                                              \
+        if (is_x2(h)) {                                                                                                               \
+            hipLaunchKernelGGL((k_step<true, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
+            hipLaunchKernelGGL((k_step<true, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                         \
+        } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_ECEF, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_ECEF, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
+        } else if (h->kin == FB_KIN_NED) {                                                                                            \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_NED, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_NED, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
+        } else {                                                                                                                      \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
+        }                                                                                                                             \
     } while (0)
 static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
     CtlArgs c;
@@ -183,6 +201,8 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
     HIPCHK(hipMalloc(&h->ui, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->status, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->redo, sizeof(int32_t) * n));
+    HIPCHK(hipMemsetAsync(h->redo, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->tables, sizeof(double) * LDS_TABLE_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
     h->x = h->x_own; h->s = h->s_own;
@@ -206,7 +226,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
-    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains); hipFree(h->redo);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
@@ -509,7 +529,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
             const int64_t to_periodic = ratio - (h->steps_done % ratio);
             int64_t k = left < to_periodic ? left : to_periodic;
             if (k > h->steps_per_launch) k = h->steps_per_launch;
-            hipLaunchKernelGGL((k_step<true, FB_KIN_WA>), grid_for(h->n, 256), dim3(256), 0, h->stream, a, (int)k);
+            FB_LAUNCH_STEP(grid_for(h->n, 256), a, (int)k);
             h->launches++;
             h->steps_done += k;
             left -= k;
@@ -518,7 +538,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
     } else {
         while (left > 0) {
             const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
-            FB_LAUNCH_MK(k_step, grid_for(h->n, 256), dim3(256), a, k);
+            FB_LAUNCH_STEP(grid_for(h->n, 256), a, k);
             left -= k;
             h->steps_done += k;
             h->launches++;

@@ -346,3 +346,45 @@ def test_ecef_and_ned_mechanisations(fb, oracle, kin):
         print(kin, "vs WA", rows, d.max())
         assert d.max() < tol, (kin, rows, d.max())
     w.close(); w0.close()
+
+
+def test_approach_crosses_the_air_ground_handover(fb, oracle):
+    """Descending approaches that start above the 10 m clearance limit of the airborne stepping instance and sink through it
+    (some down to the runway) inside fused launches: the lanes handed over to the ground-capable instance must give the same
+    trajectory as the oracle, and the result must not depend on where the launch boundaries fall."""
+    n = 1024
+    rng = np.random.default_rng(17)
+    h_trn = 300.0
+    tp = fb.TrimParameters(EAS=rng.uniform(33, 40, n), h_e=h_trn + rng.uniform(14, 40, n), γ_wb_n=-np.deg2rad(rng.uniform(2, 5, n)),
+                           flaps=1.0, ψ_nb=rng.uniform(-3, 3, n))
+    env = oracle.default_env(h_trn=h_trn)
+    results = []
+    for spl in (50, 7):
+        w = fb.BatchedWorld(n)
+        w.set_params(h_terrain=h_trn)
+        fb.f_init(w, tp)
+        x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+        ok = w.trim_success
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=spl)
+        fb.step(sim, 6.0); w.sync()
+        results.append((w.x, w.s, w.status))
+        w.close()
+    xo, so, sto = oracle.step(x0, u0, ui0, s0, env, 0.01, 600)
+    xg, sg, stg = results[0]
+    assert ok.mean() > 0.5
+    h_o_final = xo[20]   # ellipsoidal; the geoid is ~17 m here, only used to show the regime was crossed
+    _, yo, _ = oracle.f_ode(xo, u0, ui0, so, env)
+    agl = yo[fb.K["FB_Y_KIN"] + 21] - h_trn
+    wow = (yo[fb.K["FB_Y_LDG"] + 1] + yo[fb.K["FB_Y_LDG"] + 12] + yo[fb.K["FB_Y_LDG"] + 23]) > 0
+    print("final clearance: min %.2f m, below 10 m: %d, weight on wheels: %d, terminated: %d" % (agl[ok].min(), (agl[ok] < 10).sum(), wow[ok].sum(), (sto[ok] != 0).sum()))
+    assert (agl[ok] < 10).sum() > 50 and wow[ok].sum() > 5
+    assert np.array_equal(stg[ok], sto[ok])
+    live = ok & (sto == 0)
+    err = np.abs(xg - xo) / state_scale(xo)
+    near = agl < 2.5          # has been (or is about to be) on its wheels: contact forces are conditioned to ~1e-7 (see above)
+    print("approach, max scaled error after 600 steps: airborne %.2e, touched down %.2e" % (err[:, live & ~near].max(), err[:, live & near].max()))
+    assert err[:, live & ~near].max() < 1e-6 and err[:, live & near].max() < 2e-5 and np.array_equal(sg[:, live], so[:, live])
+    # launch boundaries elsewhere: same trajectories to rounding (a lane is stepped by one instance or the other per launch)
+    x2, s2, st2 = results[1]
+    assert np.array_equal(st2[ok], stg[ok])
+    assert (np.abs(x2 - xg) / state_scale(xo))[:, live & ~near].max() < 1e-9
