@@ -578,18 +578,21 @@ int32_t fb_log_configure(fb_handle h, int64_t every, int64_t capacity, const int
     log_free(h);
     if (every <= 0) return 0;  // logging off
     if (capacity <= 0 || nrows <= 0 || !rows) return fail("fb_log_configure: capacity and the row list must be non-empty");
-    const int ny = h->model == FB_MODEL_ROBOT2D ? FB_R2_NY : FB_NY, nx = h->model == FB_MODEL_ROBOT2D ? FB_R2_NX : FB_NX;
+    const int ny = h->model == FB_MODEL_ROBOT2D ? FB_R2_NY : FB_NY, nx = h->model == FB_MODEL_ROBOT2D ? (int)FB_R2_NX : nx_of(h);
     LogState* L = new LogState();
+    std::vector<int32_t> dev_rows(rows, rows + nrows);   // state rows are given in the C ABI's order; the gather works on device rows
+    const row_map_t map = h->model == FB_MODEL_ROBOT2D ? nullptr : row_map_of(h);
     for (int j = 0; j < nrows; j++) {
         const int r = rows[j];
         const bool ok = (r >= 0 && r < ny) || (r >= FB_LOG_X0 && r < FB_LOG_X0 + nx);
         if (!ok) { delete L; return fail("fb_log_configure: row %d is neither an output row [0,%d) nor FB_LOG_X0 + state row [0,%d)", r, ny, nx); }
         if (r < FB_LOG_X0) L->need_y = true;
+        else if (map) dev_rows[j] = FB_LOG_X0 + map(r - FB_LOG_X0);
     }
     h->log = L;
     L->every = every; L->capacity = capacity; L->nrows = nrows;
     HIPCHK(hipMalloc(&L->rows_dev, sizeof(int32_t) * nrows));
-    HIPCHK(hipMemcpy(L->rows_dev, rows, sizeof(int32_t) * nrows, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L->rows_dev, dev_rows.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice));
     const size_t bytes = (size_t)capacity * nrows * h->n * log_esize(h);
     if (hipMalloc(&L->data, bytes) != hipSuccess) {
         (void)hipGetLastError();
