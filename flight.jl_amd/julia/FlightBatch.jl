@@ -39,19 +39,40 @@ end
 
 check(rc::Integer) = rc == 0 || error(unsafe_string(ccall((:fb_last_error, lib), Cstring, ())))
 
-"N instances of SimpleWorld(Cessna172Sv0()) resident on one GPU (the batched counterpart of a root Model)."
+const MODEL_C172S0, MODEL_C172X2, MODEL_ROBOT2D = Cint(0), Cint(1), Cint(2)
+const KIN = Dict(WA => Cint(0), ECEF => Cint(1), NED => Cint(2))        # FB_KIN_*: the vehicle's kinematic descriptor
+const TABLE_CTL_GAINS = Cint(5)
+const NCU, NCS = 28, 65                                                 # FB_NCU, FB_NCS (Cessna172Xv2 control laws)
+
+"N instances of SimpleWorld(aircraft) resident on one GPU (the batched counterpart of a root Model).
+`aircraft` is `Cessna172Sv0(kin)` (kin = WA(), ECEF() or NED()) or `Cessna172Xv2()`; its type picks the model id."
 mutable struct BatchedWorld <: ModelDefinition
     handle::Ptr{Cvoid}
     n::Int
-    function BatchedWorld(n::Integer; device::Integer = 0)
+    nx::Int
+    function BatchedWorld(n::Integer, aircraft = Cessna172Sv0(); device::Integer = 0)
+        model = aircraft isa Cessna172Xv2 ? MODEL_C172X2 : MODEL_C172S0
+        kin = KIN[typeof(aircraft.vehicle.kinematics)]
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:fb_create, lib), Cint, (Cint, Cint, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}), 0, 0, 0, n, device, h))
-        w = new(h[], n)
+        check(ccall((:fb_create, lib), Cint, (Cint, Cint, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}), model, kin, 0, n, device, h))
+        nx = Ref{Cint}(0)
+        check(ccall((:fb_dims, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), h[], nx, C_NULL, C_NULL, C_NULL))
+        w = new(h[], n, nx[])      # 27 (WA) / 26 (ECEF) / 24 (NED) / 34 (Xv2): length(Model(aircraft).x)
         finalizer(w -> ccall((:fb_destroy, lib), Cint, (Ptr{Cvoid},), w.handle), w)
         upload_tables!(w)
+        # Xv2: the ten gain lookups of c172x/control/data packed as include/flightbatch.h documents (flightbatch/ctl_gains.py)
+        aircraft isa Cessna172Xv2 && set_table!(w, TABLE_CTL_GAINS, pack_ctl_gains(aircraft.avionics.ctl))
         return w
     end
 end
+pack_ctl_gains(ctl)::Vector{Float64} = error("see flightbatch/ctl_gains.py: ctl_gains_blob() for the layout to replicate")
+
+# avionics.ctl.u / avionics.gdc.u and the control laws' record, as N x NCU / N x NCS matrices (columns = FB_CU_* / FB_CS_*)
+ctl_inputs(w::BatchedWorld) = (cu = Matrix{Float64}(undef, w.n, NCU);
+    check(ccall((:fb_get_ctl_inputs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, cu)); cu)
+ctl_inputs!(w::BatchedWorld, cu::Matrix{Float64}) = check(ccall((:fb_set_ctl_inputs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, cu))
+ctl_record(w::BatchedWorld) = (cs = Matrix{Float64}(undef, w.n, NCS);
+    check(ccall((:fb_get_ctl_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, cs)); cs)
 
 function set_table!(w::BatchedWorld, kind::Cint, data::Array)
     dims = Int64[size(data)...]
@@ -80,7 +101,7 @@ pack_piston(lookup)::Vector{Float64} = error("see flightbatch/tables.py: piston_
 pack_aero(lookup)::Vector{Float64} = error("see flightbatch/tables.py: aero_blob() for the layout to replicate")
 
 # ---- the verbs --------------------------------------------------------------------------------------------
-state(w::BatchedWorld) = (x = Matrix{Float64}(undef, w.n, NX); s = Matrix{Int32}(undef, w.n, NS);
+state(w::BatchedWorld) = (x = Matrix{Float64}(undef, w.n, w.nx); s = Matrix{Int32}(undef, w.n, NS);
     check(ccall((:fb_get_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int32}), w.handle, x, s)); x)
 outputs(w::BatchedWorld) = (y = Matrix{Float64}(undef, w.n, NY);
     check(ccall((:fb_get_outputs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, y)); y)
