@@ -118,6 +118,8 @@ struct KArgs {
     const double* cu;   // [FB_NCU x n] control-law inputs
     double* q_pre;      // [8 x n] q_wb, q_ew of the last evaluation before f_step! (what the periodic update must see)
     int32_t* redo;      // [n] set by the airborne pass of k_step for lanes that came within reach of the ground
+    double* k1;         // [FB_NX x n] Cessna172X: derivative left by the last evaluation of the previous launch (FSAL across launches)
+    int32_t* k1_valid;  // [n] 1 when k1 is the derivative at the current x, s, u
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
@@ -277,6 +279,21 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     int stage = 0, step = 0;
     bool pending_cb = false;
+    if constexpr (X) {
+        // FSAL across launches. With the control laws between them, a launch is only Δt/dt steps long, and re-evaluating k1
+        // at its start would be one RHS in nine. The previous launch ended with an evaluation at this very state; its 27
+        // vehicle derivatives are still valid (they depend on the actuator POSITIONS, which are states, not on the commands
+        // the control laws have just changed) unless f_step! modified x or s, or the host touched x / u / the environment.
+        if (a.k1 && a.k1_valid[i]) {
+#pragma unroll
+            for (int j = 0; j < NXT; j++) {
+                const double kj = j < FB_NX ? a.k1[(int64_t)j * a.n + i] : 1 / ACT_TAU * (x2_command(a, i, j - X2_ACT) - xt[j]);
+                acc_l[j * STEP_BLOCK + t] = kj;
+                xt[j] = xt[j] + hdt * kj;
+            }
+            stage = 1;
+        }
+    }
 #pragma unroll 1
     while (true) {
         double xn[NXT];
@@ -339,7 +356,19 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
 #pragma unroll
                 for (int j = 0; j < FB_NX; j++) xs_l[j * STEP_BLOCK + t] = xt[j];
             }
-            if (dead || step == nsteps) break;
+            if (dead || step == nsteps) {
+                if constexpr (X) {
+                    if (a.k1) {   // this evaluation's derivatives (stage-0 emits: acc = k) are the next launch's k1 unless something changed
+                        const bool keep = !dead && !mod;
+                        if (keep) {
+#pragma unroll
+                            for (int j = 0; j < FB_NX; j++) a.k1[(int64_t)j * a.n + i] = acc_l[j * STEP_BLOCK + t];
+                        }
+                        a.k1_valid[i] = keep ? 1 : 0;
+                    }
+                }
+                break;
+            }
             if (mod) continue;  // re-evaluate k1 on the modified state (this pass's stage-0 emits are simply redone)
         }
         if (bits != 0) { a.status[i] |= bits; dead = true; }

@@ -34,7 +34,7 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_x2_ctl(KArgs a, CtlArgs c) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     stage_tables<PR_NC_STEP>(lds, rk, a.tables);

@@ -60,6 +60,8 @@ struct fb_handle_s {
     double* cu = nullptr;      // [FB_NCU x n] control-law inputs
     double* q_pre = nullptr;   // [8 x n]
     int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of k_step
+    double* k1 = nullptr;      // [FB_NX x n] Cessna172Xv2: FSAL derivative carried from launch to launch
+    int32_t* k1_valid = nullptr;
     double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
     int64_t gains_off[10] = {0};
     bool have_gains = false;
@@ -73,7 +75,8 @@ static KArgs make_args(fb_handle h) {
     a.n = h->n;
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface};
     a.dt = h->params.dt;
-    a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo;
+    a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
+    if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
     return a;
 }
 static int32_t check_ready(fb_handle h) {
@@ -87,6 +90,8 @@ static int32_t check_ready(fb_handle h) {
 }
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 static bool is_x2(fb_handle h) { return h->model == FB_MODEL_C172X2; }
+// anything that changes x, s, u or the environment from outside the stepping kernel invalidates the carried FSAL derivative
+static void fsal_invalidate(fb_handle h) { if (h->k1_valid) (void)hipMemsetAsync(h->k1_valid, 0, sizeof(int32_t) * h->n, h->stream); }
 // states of the C ABI: 27 (WA), 26 (ECEF: q_eb[4] n_e[3] h_e), 24 (NED: ψ θ φ ϕ λ h_e), 34 (Cessna172Xv2); the device keeps
 // 27 (34) rows for every mechanisation, the unused kinematic rows stay zero
 static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (h->kin == FB_KIN_ECEF ? FB_NX - 1 : (h->kin == FB_KIN_NED ? FB_NX - 3 : (int)FB_NX)); }
@@ -197,6 +202,9 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
         HIPCHK(hipMemsetAsync(h->cs, 0, sizeof(double) * FB_NCS * n, h->stream));
         HIPCHK(hipMemsetAsync(h->cu, 0, sizeof(double) * FB_NCU * n, h->stream));
         HIPCHK(hipMemsetAsync(h->q_pre, 0, sizeof(double) * 8 * n, h->stream));
+        HIPCHK(hipMalloc(&h->k1, sizeof(double) * FB_NX * n));
+        HIPCHK(hipMalloc(&h->k1_valid, sizeof(int32_t) * n));
+        HIPCHK(hipMemsetAsync(h->k1_valid, 0, sizeof(int32_t) * n, h->stream));
     }
     HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
     HIPCHK(hipMalloc(&h->ui, sizeof(int32_t) * n));
@@ -226,7 +234,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
-    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains); hipFree(h->redo);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
@@ -251,6 +259,7 @@ int32_t fb_set_stream(fb_handle h, void* hip_stream) {
     return 0;
 }
 int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev) {
+    if (h) fsal_invalidate(h);
     if (!h) return fail("null handle");
     if (h->model == FB_MODEL_ROBOT2D) return fail("fb_attach_state: not supported for Robot2D");
     if ((x_dev == nullptr) != (s_dev == nullptr)) return fail("x_dev and s_dev must both be given or both be NULL");
@@ -262,6 +271,7 @@ int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev) {
 }
 
 int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t* dims, int32_t ndims) {
+    if (h) fsal_invalidate(h);
     if (!h || !data || !dims) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     int64_t count = 1;
@@ -322,6 +332,7 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
     return 0;
 }
 int32_t fb_set_params(fb_handle h, const fb_params* p) {
+    if (h) fsal_invalidate(h);
     if (!h || !p) return fail("null argument");
     if (!(p->dt > 0)) return fail("dt must be positive");
     h->params = *p;
@@ -334,6 +345,7 @@ int32_t fb_get_params(fb_handle h, fb_params* p) {
 }
 
 int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
+    if (h) fsal_invalidate(h);
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) {
@@ -362,6 +374,7 @@ int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
     return 0;
 }
 int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui) {
+    if (h) fsal_invalidate(h);
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) return u ? r2_upload(h, h->r2, h->r2->u, u, FB_R2_NU) : 0;
@@ -387,6 +400,7 @@ int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit) {
     return fail("fb_f_init: Cessna172Sv0 initialises through fb_trim (TrimParameters) or fb_set_state");
 }
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost) {
+    if (h) fsal_invalidate(h);
     if (h && h->model == FB_MODEL_ROBOT2D) return fail("fb_trim: Robot2D has no trim (use fb_f_init)");
     if (int32_t rc = check_ready_x2(h)) return rc;
     if (!trim_params || !trim_state) return fail("null argument");
@@ -435,6 +449,7 @@ int32_t fb_f_ode(fb_handle h, double* xdot) {
     return 0;
 }
 int32_t fb_f_step(fb_handle h) {
+    if (h) fsal_invalidate(h);
     if (h && h->model == FB_MODEL_ROBOT2D) {
         if (int32_t rc = r2_ready(h)) return rc;
         HIPCHK(hipSetDevice(h->device));
@@ -646,6 +661,7 @@ int32_t fb_get_step_count(fb_handle h, int64_t* count) {
     return 0;
 }
 int32_t fb_set_step_count(fb_handle h, int64_t count, double t) {
+    if (h) fsal_invalidate(h);
     if (!h) return fail("null handle");
     if (count < 0) return fail("step count must be >= 0");
     if (h->model == FB_MODEL_ROBOT2D) h->r2->steps_done = count;
