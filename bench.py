@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="f64: the parity path (default, BASELINE.json's metric). f32: the fp32 airborne stepper (config 5's dtype)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,7 +134,7 @@ def main():
     import flightbatch as fb
 
     n = N_PER_GPU
-    w = fb.BatchedWorld(n, device=local_rank)
+    w = fb.BatchedWorld(n, device=local_rank, dtype=args.dtype)
     # the state lives in a torch tensor so that RCCL can gather it without a host round trip
     x_dev = torch.zeros((fb.K["FB_NX"], n), dtype=torch.float64, device="cuda")
     s_dev = torch.zeros((fb.K["FB_NS"], n), dtype=torch.int32, device="cuda")
@@ -188,7 +190,7 @@ def main():
         traffic = None
         valu = None
         prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
-        if os.path.exists(prof):
+        if os.path.exists(prof) and args.dtype == "f64":   # the committed counters describe the fp64 kernel
             pj = json.load(open(prof))
             if pj.get("n") == n and pj.get("inner") == args.inner:
                 traffic = pj.get("hbm_bytes_per_launch")
@@ -200,13 +202,13 @@ def main():
         line = {
             "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "N=1048576 Cessna172Sv0 per GPU, randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, "
-                                   "LCG-permuted), fp64, dt=0.01 (BASELINE.json configs[2])",
+                                   "LCG-permuted), " + ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])",
                        "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
                        "trim_success_fraction": trim_ok, "terminated_aircraft": status_bad},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "fbd::k_step<false, 0, false> (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": ("fbd::k_step<false, 0, false>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "
                                  "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,

@@ -8,6 +8,7 @@
 #include <vector>
 #include "c172_kernels.hpp"
 #include "c172x_kernels.hpp"
+#include "c172_kernels_f32.hpp"
 #include "robot2d_kernels.hpp"
 
 using namespace fbd;
@@ -132,6 +133,9 @@ static row_map_t row_map_of(fb_handle h) {
         } else if (h->kin == FB_KIN_NED) {                                                                                            \
             hipLaunchKernelGGL((k_step<false, FB_KIN_NED, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
             hipLaunchKernelGGL((k_step<false, FB_KIN_NED, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
+        } else if (h->dtype == FB_F32) {   /* fp32 airborne stepper; lanes near the ground go to the fp64 ground-capable kernel */    \
+            hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
+            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         } else {                                                                                                                      \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
@@ -169,7 +173,8 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
     if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
     if (model_id == FB_MODEL_C172X2 && kin_id != FB_KIN_WA) return fail("Cessna172Xv2: only FB_KIN_WA is implemented");
-    if (model_id != FB_MODEL_ROBOT2D && dtype != FB_F64) return fail("dtype not implemented for the Cessna 172 models (only FB_F64)");
+    if (model_id == FB_MODEL_C172X2 && dtype != FB_F64) return fail("Cessna172Xv2: only FB_F64 is implemented");
+    if (model_id == FB_MODEL_C172S0 && dtype == FB_F32 && kin_id != FB_KIN_WA) return fail("Cessna172Sv0 in fp32: only FB_KIN_WA is implemented");
     if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
     if (n <= 0) return fail("n must be positive");
     if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");

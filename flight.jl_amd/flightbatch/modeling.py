@@ -89,12 +89,16 @@ class BatchedWorld:
 
     MODEL = "FB_MODEL_C172S0"
 
-    def __init__(self, n: int, device: int = 0, tables: dict | None = None, kinematics: str = "WA"):
-        """kinematics: "WA" (default, FP/kinematics.jl:148), "ECEF" (:250) or "NED" (:329) — Cessna172Sv0(kinematics)."""
+    def __init__(self, n: int, device: int = 0, tables: dict | None = None, kinematics: str = "WA", dtype: str = "f64"):
+        """kinematics: "WA" (default, FP/kinematics.jl:148), "ECEF" (:250) or "NED" (:329) — Cessna172Sv0(kinematics).
+        dtype "f32" (Cessna172Sv0 + WA only) steps airborne aircraft with the fp32 kernel (positions still integrated in
+        fp64, ground contact handed to the fp64 kernel); state, trim, f_ode! and the ABI stay fp64."""
         self.n = int(n)
         self._h = C.c_void_p()
         self.kinematics = kinematics
-        check(lib.fb_create(K[self.MODEL], K["FB_KIN_" + kinematics], K["FB_F64"], self.n, int(device), C.byref(self._h)))
+        self.dtype = dtype
+        check(lib.fb_create(K[self.MODEL], K["FB_KIN_" + kinematics], K["FB_F64" if dtype == "f64" else "FB_F32"], self.n, int(device),
+                            C.byref(self._h)))
         nx = C.c_int32()
         check(lib.fb_dims(self._h, C.byref(nx), None, None, None))
         self.nx = nx.value

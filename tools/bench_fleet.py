@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json on one GPU: a mixed fleet of N vehicles, 50 % Cessna172Sv0 / 50 % Robot2D interleaved in the input
 order, dt = 0.01, Δt = 0.02. The packer (flightbatch/fleet.py) sorts by model into two homogeneous batches on
-two HIP streams. The C172 batch runs in fp64 (no fp32 instance of the aircraft exists), the robots in fp32.
+two HIP streams. Both batches run their fp32 steppers by default (argv[3] = f64 for the fp64 aircraft kernel).
 Prints one JSON line: vehicle-steps/s of the whole fleet and of each batch."""
 import json
 import os
@@ -18,7 +18,8 @@ T = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 KC, KR = fb.K["FB_MODEL_C172S0"], fb.K["FB_MODEL_ROBOT2D"]
 types = np.where(np.arange(n) % 2 == 0, KC, KR)
 t0 = time.perf_counter()
-fleet = fb.MixedFleet(types, {KC: lambda m: fb.BatchedWorld(m), KR: lambda m: fb.Robot2DWorld(m, dtype="f32")})
+DT = sys.argv[3] if len(sys.argv) > 3 else "f32"
+fleet = fb.MixedFleet(types, {KC: lambda m: fb.BatchedWorld(m, dtype=DT), KR: lambda m: fb.Robot2DWorld(m, dtype="f32")})
 pack_s = time.perf_counter() - t0
 fleet.simulate(dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
 fleet.init({KC: fb.TrimParameters(), KR: fb.InitParameters()})
@@ -32,7 +33,7 @@ t0 = time.perf_counter(); fb.step(fleet.sims[KC], T); fleet.worlds[KC].sync(); e
 t0 = time.perf_counter(); fb.step(fleet.sims[KR], T); rw.sync(); el_r = time.perf_counter() - t0
 st = fleet.gather("status", fill=-1)
 print(json.dumps({"metric": "vehicle-steps/sec", "value": n * steps / el, "unit": "vehicle-steps/s", "n_gpus": 1,
-                  "config": {"workload": f"mixed fleet N={n}: 50% Cessna172Sv0 (fp64) / 50% Robot2D (fp32), interleaved input order, dt=0.01, Δt=0.02"},
+                  "config": {"workload": f"mixed fleet N={n}: 50% Cessna172Sv0 ({DT}) / 50% Robot2D (fp32), interleaved input order, dt=0.01, Δt=0.02"},
                   "fleet_s": el, "c172_alone_s": el_c, "robot2d_alone_s": el_r, "overlap_gain": (el_c + el_r) / el, "pack_s": pack_s,
                   "terminated": int((st != 0).sum())}))
 fleet.close()
