@@ -581,6 +581,18 @@ static TrimParams trim_params_from(const double* tp, int64_t n, int64_t i) {
     for (int k = 0; k < 5; k++) p.payload[k] = TP(FB_TP_PAYLOAD + k);
     return p;
 }
+// discrete compensators on their own (FlightPhysics/test/test_control.jl:254-330): p = {k_p, k_i, k_d, tau_f, lo, hi}, s = {x_i0, x_d0, sat_out_0}
+double fo_pid_run(const double* p, double dT, double input, double sat_ext, double* s, int32_t nruns) {
+    const PidP P = {p[0], p[1], p[2], p[3], p[4], p[5]};
+    double out = 0;
+    for (int k = 0; k < nruns; k++) out = pid_run(P, dT, input, sat_ext, s);
+    return out;
+}
+double fo_integ_run(double dT, double input, double sat_ext, double* s, int32_t nruns) {
+    double out = 0;
+    for (int k = 0; k < nruns; k++) out = integ_run(dT, input, sat_ext, s);
+    return out;
+}
 // Segment(p1; s, χ, Δh).p2 and SegmentGuidanceData(seg, Ob) (c172x_gdc.jl:56-83, 113-149). Points = (lat, lon, h).
 void fo_segment_end(const double* p1, double s_len, double chi, double dh, double* p2) {
     const GeoPoint e = segment_end(GeoPoint{{p1[0], p1[1]}, p1[2]}, s_len, chi, dh);

@@ -321,3 +321,43 @@ def test_segment_guidance_captures_the_segment(oracle, gains):
     sim.step(120)
     assert abs(sim.cs("SEG_E_SB")) < 5.0 and abs(sim.y()[Y_H_E] - sim.cs("SEG_H_REF")) < 1.0
     assert sim.cs("LAT_MODE") == K["FB_LAT_CHI_BETA"] and sim.cs("LON_MODE") == K["FB_LON_EAS_ALT"]
+
+
+def test_discrete_pid_and_integrator(oracle):
+    """lib/FlightPhysics/test/test_control.jl:254-330 (PIDDiscrete at Δt = 0.01): proportional / integral paths after 1 s,
+    output saturation halting the integrator, release when the input changes sign, external saturation of the same / opposite
+    sign, and the filtered-derivative configuration."""
+    L = oracle.lib
+    L.fo_pid_run.restype = C.c_double; L.fo_integ_run.restype = C.c_double
+
+    def run(p, s, inp, sat_ext=0.0, n=100):
+        p = np.asarray(p, dtype=np.float64)
+        return L.fo_pid_run(p.ctypes.data_as(_D), C.c_double(0.01), C.c_double(inp), C.c_double(sat_ext), s.ctypes.data_as(_D), n)
+
+    inf = np.inf
+    s = np.zeros(3)
+    p = [1.0, 1.0, 0.1, 0.01, -inf, inf]
+    out = run(p, s, 1.0)                                   # step!(sim, 1): 100 updates
+    assert abs(s[0] - 1.0) < 1e-9 and abs(out - 2.0) < 1e-3 and s[2] == 0      # y_i ≈ 1, out_free ≈ 2, not saturated
+    p[4:6] = [-1.0, 1.0]
+    x_i_before = s[0]
+    out = run(p, s, 1.0)
+    assert out == 1.0 and s[2] == 1 and s[0] < x_i_before + 0.02               # saturated high: the integrator halted at once
+    out = run(p, s, -1.0, n=200)
+    assert s[2] == -1 and out == -1.0                                          # drove through to the lower bound and halted there
+    out = run(p, s, 0.1)
+    assert s[2] == 0                                                           # released
+    x_i = s[0]; run(p, s, 0.1, sat_ext=-1.0, n=1)
+    assert s[0] > x_i                                                          # opposite external saturation: keeps integrating
+    x_i = s[0]; run(p, s, 0.1, sat_ext=+1.0, n=1)
+    assert s[0] == x_i                                                         # same-sign external saturation: halted
+    # filtered derivative: k_p = k_i = 0, k_d = 1, τ_f = 0.2 — a step input gives a positive kick that decays
+    s = np.zeros(3); pd = [0.0, 0.0, 1.0, 0.2, -inf, inf]
+    y1 = run(pd, s, 1.0, n=1); y6 = run(pd, s, 1.0, n=5)
+    assert y1 > 0 and 0 < y6 < y1
+    # Integrator (test_control.jl:213-252 analogue): integrates, halts under same-sign external saturation
+    si = np.zeros(2)
+    out = L.fo_integ_run(C.c_double(0.01), C.c_double(2.0), C.c_double(0.0), si.ctypes.data_as(_D), 100)
+    assert abs(out - 2.0) < 1e-12
+    out2 = L.fo_integ_run(C.c_double(0.01), C.c_double(2.0), C.c_double(1.0), si.ctypes.data_as(_D), 10)
+    assert out2 == out
