@@ -33,7 +33,7 @@ DT = 0.01
 BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flags, C172Sv0 fp64
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r01e_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r01f_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
 
 
 def lattice(rank: int):
@@ -208,7 +208,7 @@ def main():
                        "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
                        "trim_success_fraction": trim_ok, "terminated_aircraft": status_bad},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("fbd::k_step<false, 0, false>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": ("fbd::k_step_air" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "
                                  "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,

@@ -387,6 +387,123 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
     a.s[a.n + i] = eng;
 }
 
+// ---- the airborne pass of Cessna172Sv0 / WA, third generation ---------------------------------------------------------------
+// k_step<false, WA, false> keeps the stage state xt[27] and the next stage's state xn[27] in registers: 108 of the 256
+// addressable VGPRs, which is why a fifth of its VALU instructions are v_accvgpr moves. Here the stage state lives in a third
+// LDS panel and is read at the point of use; emit() updates it IN PLACE (every row's derivative is produced after the last
+// read of that row within one evaluation — checked against rhs()'s source order), so neither array exists in registers.
+// LDS room for the third panel comes from two facts about an airborne aircraft: its six contact-regulator states are
+// identically zero (reset by f_step! whenever a wheel is off the ground, zero derivative at zero) so they need no rows —
+// a lane that arrives with a non-zero one is handed to the ground-capable pass — and the eleven per-lane inputs fit in the
+// registers the panels freed. 3 x 21 rows x 2 KB + 22 KB of tables = 151 KB.
+template <int STRIDE>
+struct StateLds {
+    lds_cptr p;   // &panel[lane]
+    __device__ __forceinline__ static constexpr int row(int k) { return k < FB_X_LDG_FRC ? k : k - 6; }
+    __device__ __forceinline__ double operator[](int k) const { return (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : p[row(k) * STRIDE]; }
+};
+__global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
+    constexpr int B = STEP_BLOCK, NR = FB_NX - 6;
+    using SV = StateLds<B>;
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
+    __shared__ double rk[LDS_RK_DOUBLES];
+    __shared__ double xs_l[NR * B];    // x_n
+    __shared__ double acc_l[NR * B];   // k1 + 2 k2 + 2 k3
+    __shared__ double xc_l[NR * B];    // the state being evaluated (x_n, or x_n + c dt k_j), updated in place by emit()
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    if (a.status[i] != 0) return;
+    const int t = threadIdx.x;
+    bool to_ground = false;
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) {
+        const double v = a.x[(int64_t)k * a.n + i];
+        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) to_ground = to_ground || (v != 0.0);
+        else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; }
+    }
+    if (to_ground) { a.redo[i] = 1; return; }
+    Inputs in;
+    load_inputs(a, i, in);
+    in.u_glob = nullptr;   // ground-only inputs are never read here
+    int stall = a.s[i], eng = a.s[a.n + i];
+    const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    int stage = 0, step = 0;
+    bool pending_cb = false, dead = false;
+#pragma unroll 1
+    while (true) {
+        StepAux aux;
+        int lds_off = 0;
+        asm volatile("" : "+s"(lds_off));   // see k_step: keeps loop-invariant LDS loads inside the loop
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
+        Inputs inl = in;                    // and keeps products of the per-lane inputs from being hoisted out of it
+        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
+        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+        const double cdt = (stage == 2) ? dt : hdt;
+        auto emit = [&](int j, double kj) {
+            if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+            const int idx = SV::row(j) * B + t;
+            const double xs = xs_l[idx];
+            if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = xs + cdt * kj; }
+            else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = xs + cdt * kj; }
+            else { const double v = xs + dt6 * (acc_l[idx] + kj); xs_l[idx] = v; xc_l[idx] = v; }
+        };
+        const SV xv = {(lds_cptr)xc_l + t + lds_off};
+        int32_t bits = rhs<FB_KIN_WA, false>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+        if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
+        if (stage == 0 && pending_cb) {
+            // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
+            pending_cb = false;
+            step++;
+            bool mod = false;
+            auto renorm4 = [&](int k0) {   // normalize_block!(q, 1e-8), kinematics.jl:114-118, 226-229
+                double q[4], n2 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
+                const double nr = sqrt(n2);
+                if (fabs(nr - 1.0) > 1e-8) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
+                    mod = true;
+                }
+            };
+            renorm4(FB_X_Q_WB); renorm4(FB_X_Q_EW);
+            const int stall0 = stall, eng0 = eng;
+            if (aux.alpha > c172::alpha_stall_hi) stall = 1;
+            else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
+            if (aux.crash) bits |= FB_ST_GROUND_CRASH;
+            const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
+            const bool fuel = aux.m_avail > 0;
+            const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
+            if (eng == 0) { if (start) eng = 1; }
+            else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
+            else if (stop || w < c172::w_stall || !fuel) eng = 0;
+            mod = mod || stall != stall0 || eng != eng0;
+            if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
+            if (dead || step == nsteps) break;
+            if (mod) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+#pragma unroll
+                for (int r = 0; r < NR; r++) xc_l[r * B + t] = xs_l[r * B + t];
+                continue;
+            }
+        }
+        if (bits != 0) { a.status[i] |= bits; dead = true; }
+        stage = (stage + 1) & 3;
+        pending_cb = (stage == 0);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) {
+        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) continue;
+        const double v = xs_l[SV::row(k) * B + t];
+        bad = bad || !isfinite(v);
+        a.x[(int64_t)k * a.n + i] = v;
+    }
+    if (bad) a.status[i] |= FB_ST_NAN;
+    a.s[i] = stall;
+    a.s[a.n + i] = eng;
+}
+
 // ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------
 struct TrimP {
     v3 n_e;

@@ -137,7 +137,8 @@ static row_map_t row_map_of(fb_handle h) {
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         } else {                                                                                                                      \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
+            if (getenv("FB_OLD_AIR_KERNEL")) hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K); \
+            else hipLaunchKernelGGL(k_step_air, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         }                                                                                                                             \
     } while (0)
