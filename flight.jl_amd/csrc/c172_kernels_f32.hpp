@@ -20,34 +20,28 @@
 
 namespace fbf {
 
-constexpr int F32_ROWS_INPUT = 6;            // de da dr df throttle mixture; payload masses are read from global memory
-constexpr int XP0 = FB_X_Q_EW, XPN = 5;      // rows integrated in fp64: q_ew[4], h_e
-FBD constexpr int xsrow(int j) { return j < XP0 ? j : j - XPN; }   // row of state j in the fp32 x_n panel
+constexpr int XP0 = FB_X_Q_EW, XPN = 5;      // states integrated in fp64: q_ew[4], h_e
+// Panels as in k_step_air (c172_kernels.hpp): the six contact-regulator states are identically zero in the air and have no
+// rows; the state being evaluated lives in an LDS panel (fp32) that emit() updates in place.
 template <int STRIDE>
-struct InputsLdsF {
-    lds_cptr p;
-    const double* u_glob;
-    int64_t n;
-    int ui;
-    FBD real get_de() const { return p[0 * STRIDE]; }
-    FBD real get_da() const { return p[1 * STRIDE]; }
-    FBD real get_dr() const { return p[2 * STRIDE]; }
-    FBD real get_df() const { return p[3 * STRIDE]; }
-    FBD real get_throttle() const { return p[4 * STRIDE]; }
-    FBD real get_mixture() const { return p[5 * STRIDE]; }
-    FBD real get_m_pld(int k) const { return clampd((real)u_glob[(FB_U_M_PILOT + k) * n], 0, 100); }
-    FBD real get_steering() const { return 0; }   // ground-only inputs: never read by the airborne instance
-    FBD real get_brake(int) const { return 0; }
+struct StateLdsF {
+    lds_cptr p;   // &panel[lane]
+    FBD static constexpr int row(int k) { return k < FB_X_LDG_FRC ? k : k - 6; }
+    FBD real operator[](int k) const { return (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? real(0) : p[row(k) * STRIDE]; }
 };
+constexpr int NRF = FB_NX - 6;                              // 21 panel rows
+constexpr int RP0 = XP0 - 6;                                // panel row of the first fp64-integrated state
+FBD constexpr int xsrow(int r) { return r < RP0 ? r : r - XPN; }   // panel row -> row of the fp32 x_n panel (r outside [RP0, RP0+5))
 
 __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, int nsteps) {
     constexpr int B = fbd::STEP_BLOCK;
+    using SV = StateLdsF<B>;
     __shared__ float lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ float rk[LDS_RK_DOUBLES];
-    __shared__ float xs_l[(FB_NX - XPN) * B];   // x_n of the fp32 rows (the five fp64-integrated rows live in xp_l)
-    __shared__ float acc_l[FB_NX * B];     // k1 + 2 k2 + 2 k3
-    __shared__ double xp_l[XPN * B];       // x_n of the fp64-integrated rows
-    __shared__ float in_l[F32_ROWS_INPUT * B];
+    __shared__ float xs_l[(NRF - XPN) * B];   // x_n of the fp32-integrated states
+    __shared__ double xp_l[XPN * B];          // x_n of the fp64-integrated states
+    __shared__ float acc_l[NRF * B];          // k1 + 2 k2 + 2 k3
+    __shared__ float xc_l[NRF * B];           // the state being evaluated, updated in place by emit()
     // tables: fp64 blob in global memory -> fp32 in LDS (propeller compacted to four coefficients like the fp64 stepper)
     for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = (float)a.tables[k];
     for (int k = threadIdx.x; k < PR_NJ * PR_NM * PR_NC_STEP; k += blockDim.x)
@@ -57,74 +51,87 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (a.status[i] != 0) return;
-    bool dead = false;
     const int t = threadIdx.x;
-    float xt[FB_NX];
+    bool to_ground = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
         const double v = a.x[(int64_t)k * a.n + i];
-        xt[k] = (float)v;
+        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) { to_ground = to_ground || (v != 0.0); continue; }
+        const int r = SV::row(k);
+        xc_l[r * B + t] = (float)v;
         if (k >= XP0 && k < XP0 + XPN) xp_l[(k - XP0) * B + t] = v;
-        else xs_l[xsrow(k) * B + t] = xt[k];
+        else xs_l[xsrow(r) * B + t] = (float)v;
     }
+    if (to_ground) { a.redo[i] = 1; return; }
+    Inputs in;
     {
         fbd::Inputs in_r;
         fbd::load_inputs(a, i, in_r);
-        lds_ptr q = (lds_ptr)in_l + t;
-        q[0 * B] = (float)in_r.de; q[1 * B] = (float)in_r.da; q[2 * B] = (float)in_r.dr; q[3 * B] = (float)in_r.df;
-        q[4 * B] = (float)in_r.throttle; q[5 * B] = (float)in_r.mixture;
+        in.de = (float)in_r.de; in.da = (float)in_r.da; in.dr = (float)in_r.dr; in.df = (float)in_r.df;
+        in.throttle = (float)in_r.throttle; in.mixture = (float)in_r.mixture;
+#pragma unroll
+        for (int k = 0; k < 5; k++) in.m_pld[k] = (float)in_r.m_pld[k];
+        in.ui = in_r.ui; in.u_glob = nullptr; in.n = 0;
     }
-    const int ui = a.ui[i];
     int stall = a.s[i], eng = a.s[a.n + i];
     const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface};
     const float dt = (float)a.dt, hdt = (float)(a.dt / 2), dt6 = (float)(a.dt / 6);
     const double dtd = a.dt, hdtd = a.dt / 2, dt6d = a.dt / 6;
     int stage = 0, step = 0;
-    bool pending_cb = false;
+    bool pending_cb = false, dead = false;
 #pragma unroll 1
     while (true) {
-        float xn[FB_NX];
         StepAux aux;
         int lds_off = 0;
-        asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table / input loads inside the loop (see k_step)
+        asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step)
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
-        const InputsLdsF<B> inl = {(lds_cptr)in_l + t + lds_off, a.u + i + lds_off, a.n, ui};
+        Inputs inl = in;
+        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
+        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
         const float cdt = (stage == 2) ? dt : hdt;
         const double cdtd = (stage == 2) ? dtd : hdtd;
         auto emit = [&](int j, float kj) {
-            const int idx = j * B + t;
-            if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position rows (j is a compile-time constant at every call)
+            if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+            const int r = SV::row(j), idx = r * B + t;
+            if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position states (j is a compile-time constant at every call)
                 const int ip = (j - XP0) * B + t;
                 const double xs = xp_l[ip];
-                if (stage == 0) { acc_l[idx] = kj; xn[j] = (float)(xs + cdtd * (double)kj); }
-                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xn[j] = (float)(xs + cdtd * (double)kj); }
-                else { const double v = xs + dt6d * ((double)acc_l[idx] + (double)kj); xp_l[ip] = v; xn[j] = (float)v; }
+                if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = (float)(xs + cdtd * (double)kj); }
+                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = (float)(xs + cdtd * (double)kj); }
+                else { const double v = xs + dt6d * ((double)acc_l[idx] + (double)kj); xp_l[ip] = v; xc_l[idx] = (float)v; }
             } else {
-                const int ix = xsrow(j) * B + t;
+                const int ix = xsrow(r) * B + t;
                 const float xs = xs_l[ix];
-                if (stage == 0) { acc_l[idx] = kj; xn[j] = xs + cdt * kj; }
-                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xn[j] = xs + cdt * kj; }
-                else { const float v = xs + dt6 * (acc_l[idx] + kj); xs_l[ix] = v; xn[j] = v; }
+                if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = xs + cdt * kj; }
+                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = xs + cdt * kj; }
+                else { const float v = xs + dt6 * (acc_l[idx] + kj); xs_l[ix] = v; xc_l[idx] = v; }
             }
         };
-        int32_t bits = rhs<FB_KIN_WA, false>(xt, stall, eng, inl, env, T, emit, aux, NoSink{});
+        const SV xv = {(lds_cptr)xc_l + t + lds_off};
+        int32_t bits = rhs<FB_KIN_WA, false>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
         if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // within reach of the ground: the fp64 kernel takes this lane over
-        bool mod = false;
-        if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
+        if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} = the x_n panels (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
             pending_cb = false;
             step++;
-            {   // q_wb: renormalised every step, silently (fp32 drift); q_ew: the reference's rule, on the fp64 copy
-                const float inr = rsqrtf(xt[FB_X_Q_WB] * xt[FB_X_Q_WB] + xt[FB_X_Q_WB + 1] * xt[FB_X_Q_WB + 1] +
-                                         xt[FB_X_Q_WB + 2] * xt[FB_X_Q_WB + 2] + xt[FB_X_Q_WB + 3] * xt[FB_X_Q_WB + 3]);
+            bool mod = false;
+            {   // q_wb: renormalised every step, silently (fp32 drift); its copy in the evaluation panel has already moved on by
+                // this evaluation's emits (x + dt/2 k1): rescaling it by the same factor keeps the two consistent to O(ulp)
+                float q[4], n2 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { xt[FB_X_Q_WB + k] *= inr; xs_l[xsrow(FB_X_Q_WB + k) * B + t] = xt[FB_X_Q_WB + k]; }
-                double n2 = 0;
+                for (int k = 0; k < 4; k++) { q[k] = xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t]; n2 += q[k] * q[k]; }
+                const float inr = rsqrtf(n2);
 #pragma unroll
-                for (int k = 0; k < 4; k++) n2 += xp_l[k * B + t] * xp_l[k * B + t];
-                const double nr = sqrt(n2);
+                for (int k = 0; k < 4; k++) {
+                    xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t] = q[k] * inr;
+                    xc_l[SV::row(FB_X_Q_WB + k) * B + t] *= inr;
+                }
+                double n2d = 0;   // q_ew: the reference's rule, on the fp64 values
+#pragma unroll
+                for (int k = 0; k < 4; k++) n2d += xp_l[k * B + t] * xp_l[k * B + t];
+                const double nr = sqrt(n2d);
                 if (fabs(nr - 1.0) > 1e-8) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { const double v = xp_l[k * B + t] / nr; xp_l[k * B + t] = v; xt[XP0 + k] = (float)v; }
+                    for (int k = 0; k < 4; k++) xp_l[k * B + t] = xp_l[k * B + t] / nr;
                     mod = true;
                 }
             }
@@ -132,34 +139,36 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
             if (aux.alpha > c172::alpha_stall_hi) stall = 1;
             else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
             if (aux.crash) bits |= FB_ST_GROUND_CRASH;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {   // airborne: the contact regulators are reset (landinggear.jl:479-483)
-                if (xt[FB_X_LDG_FRC + k] != 0.0f) { xt[FB_X_LDG_FRC + k] = 0.0f; xs_l[xsrow(FB_X_LDG_FRC + k) * B + t] = 0.0f; mod = true; }
-            }
-            const float w = xt[FB_X_ENG_OMEGA];
+            const float w = xs_l[xsrow(SV::row(FB_X_ENG_OMEGA)) * B + t];
             const bool fuel = aux.m_avail > 0;
-            const bool start = ui & FB_UI_ENG_START, stop = ui & FB_UI_ENG_STOP;
+            const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
             if (eng == 0) { if (start) eng = 1; }
             else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
             else if (stop || w < c172::w_stall || !fuel) eng = 0;
             mod = mod || stall != stall0 || eng != eng0;
             if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
             if (dead || step == nsteps) break;
-            if (mod) continue;   // k1 must be re-evaluated on the modified state
+            if (mod) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+#pragma unroll
+                for (int r = 0; r < NRF; r++)
+                    xc_l[r * B + t] = (r >= RP0 && r < RP0 + XPN) ? (float)xp_l[(r - RP0) * B + t] : xs_l[xsrow(r) * B + t];
+                continue;
+            }
         }
         if (bits != 0) { a.status[i] |= bits; dead = true; }
-#pragma unroll
-        for (int j = 0; j < FB_NX; j++) xt[j] = xn[j];
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
     bool bad = false;
 #pragma unroll
-    for (int j = 0; j < FB_NX; j++) bad = bad || !isfinite(xt[j]);
+    for (int k = 0; k < FB_NX; k++) {
+        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) continue;
+        const int r = SV::row(k);
+        const double v = (k >= XP0 && k < XP0 + XPN) ? xp_l[(k - XP0) * B + t] : (double)xs_l[xsrow(r) * B + t];
+        bad = bad || !isfinite(v);
+        a.x[(int64_t)k * a.n + i] = v;
+    }
     if (bad) a.status[i] |= FB_ST_NAN;
-#pragma unroll
-    for (int j = 0; j < FB_NX; j++)
-        a.x[(int64_t)j * a.n + i] = (j >= XP0 && j < XP0 + XPN) ? xp_l[(j - XP0) * B + t] : (double)xt[j];
     a.s[i] = stall;
     a.s[a.n + i] = eng;
 }
