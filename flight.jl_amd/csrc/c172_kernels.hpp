@@ -402,6 +402,7 @@ struct StateLds {
     __device__ __forceinline__ static constexpr int row(int k) { return k < FB_X_LDG_FRC ? k : k - 6; }
     __device__ __forceinline__ double operator[](int k) const { return (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : p[row(k) * STRIDE]; }
 };
+template <int KIN>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     constexpr int B = STEP_BLOCK, NR = FB_NX - 6;
     using SV = StateLds<B>;
@@ -449,25 +450,26 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             else { const double v = xs + dt6 * (acc_l[idx] + kj); xs_l[idx] = v; xc_l[idx] = v; }
         };
         const SV xv = {(lds_cptr)xc_l + t + lds_off};
-        int32_t bits = rhs<FB_KIN_WA, false>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+        int32_t bits = rhs<KIN, false>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
         if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
         if (stage == 0 && pending_cb) {
             // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
             pending_cb = false;
             step++;
             bool mod = false;
-            auto renorm4 = [&](int k0) {   // normalize_block!(q, 1e-8), kinematics.jl:114-118, 226-229
-                double q[4], n2 = 0;
+            auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
+                double q[4] = {0, 0, 0, 0}, n2 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
+                for (int k = 0; k < 4; k++) if (k < len) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
                 const double nr = sqrt(n2);
                 if (fabs(nr - 1.0) > 1e-8) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
+                    for (int k = 0; k < 4; k++) if (k < len) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
                     mod = true;
                 }
             };
-            renorm4(FB_X_Q_WB); renorm4(FB_X_Q_EW);
+            if constexpr (KIN == FB_KIN_WA) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4); }
+            else if constexpr (KIN == FB_KIN_ECEF) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_WB + 4, 3); }
             const int stall0 = stall, eng0 = eng;
             if (aux.alpha > c172::alpha_stall_hi) stall = 1;
             else if (aux.alpha < c172::alpha_stall_lo) stall = 0;

@@ -128,17 +128,17 @@ static row_map_t row_map_of(fb_handle h) {
             hipLaunchKernelGGL((k_step<true, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
             hipLaunchKernelGGL((k_step<true, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                         \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_ECEF, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
+            hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
             hipLaunchKernelGGL((k_step<false, FB_KIN_ECEF, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
         } else if (h->kin == FB_KIN_NED) {                                                                                            \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_NED, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
+            hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
             hipLaunchKernelGGL((k_step<false, FB_KIN_NED, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
         } else if (h->dtype == FB_F32) {   /* fp32 airborne stepper; lanes near the ground go to the fp64 ground-capable kernel */    \
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         } else {                                                                                                                      \
             if (getenv("FB_OLD_AIR_KERNEL")) hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K); \
-            else hipLaunchKernelGGL(k_step_air, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
+            else hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         }                                                                                                                             \
     } while (0)
