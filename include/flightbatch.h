@@ -210,9 +210,11 @@ int32_t fb_dims(fb_handle h, int32_t* nx, int32_t* ns, int32_t* nu, int32_t* ny)
 
 /* Run on an externally created HIP stream (hipStream_t passed as void*); NULL = the handle's own stream. */
 int32_t fb_set_stream(fb_handle h, void* hip_stream);
-/* Use caller-owned DEVICE memory for x [N x FB_NX doubles] and s [N x FB_NS int32] (e.g. a torch
- * tensor's data_ptr), so collectives can run on the state without a host round trip. NULL restores
- * the handle's own buffers. */
+/* Use caller-owned DEVICE memory for x and s [N x FB_NS int32] (e.g. a torch tensor's data_ptr), so collectives can run
+ * on the state without a host round trip. NULL restores the handle's own buffers. The buffer holds the DEVICE layout:
+ * [N x FB_NX] doubles for every Cessna172Sv0 mechanisation (ECEF / NED: their 8 / 6 kinematic states in rows 12.., the
+ * remaining kinematic rows zero, then w_eb_b, v_eb_b in rows 21-26) and [N x FB_X2_NX] for Cessna172Xv2 with the Sv0 rows
+ * first and the seven actuator positions in rows 27-33; fb_get_state / fb_set_state present the reference's order. */
 int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev);
 
 /* Lookup tables: what the reference builds at construction time (Appendix B of SURVEY.md). */
