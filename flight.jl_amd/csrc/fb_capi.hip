@@ -92,7 +92,11 @@ static int32_t check_ready(fb_handle h) {
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 static bool is_x2(fb_handle h) { return h->model == FB_MODEL_C172X2; }
 // anything that changes x, s, u or the environment from outside the stepping kernel invalidates the carried FSAL derivative
-static void fsal_invalidate(fb_handle h) { if (h->k1_valid) (void)hipMemsetAsync(h->k1_valid, 0, sizeof(int32_t) * h->n, h->stream); }
+static void fsal_invalidate(fb_handle h) {
+    if (!h->k1_valid) return;
+    (void)hipSetDevice(h->device);
+    (void)hipMemsetAsync(h->k1_valid, 0, sizeof(int32_t) * h->n, h->stream);
+}
 // states of the C ABI: 27 (WA), 26 (ECEF: q_eb[4] n_e[3] h_e), 24 (NED: ψ θ φ ϕ λ h_e), 34 (Cessna172Xv2); the device keeps
 // 27 (34) rows for every mechanisation, the unused kinematic rows stay zero
 static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (h->kin == FB_KIN_ECEF ? FB_NX - 1 : (h->kin == FB_KIN_NED ? FB_NX - 3 : (int)FB_NX)); }
