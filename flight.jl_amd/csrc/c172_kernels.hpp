@@ -396,6 +396,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
 // identically zero (reset by f_step! whenever a wheel is off the ground, zero derivative at zero) so they need no rows —
 // a lane that arrives with a non-zero one is handed to the ground-capable pass — and the eleven per-lane inputs fit in the
 // registers the panels freed. 3 x 21 rows x 2 KB + 22 KB of tables = 151 KB.
+#ifndef FB_AIR_SCALAR_KNOTS
+#define FB_AIR_SCALAR_KNOTS true
+#endif
 template <int STRIDE>
 struct StateLds {
     lds_cptr p;   // &panel[lane]
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         StepAux aux;
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));   // see k_step: keeps loop-invariant LDS loads inside the loop
-        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
         Inputs inl = in;                    // and keeps products of the per-lane inputs from being hoisted out of it
         asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
         asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             else { const double v = xs + dt6 * (acc_l[idx] + kj); xs_l[idx] = v; xc_l[idx] = v; }
         };
         const SV xv = {(lds_cptr)xc_l + t + lds_off};
-        int32_t bits = rhs<KIN, false>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+        int32_t bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
         if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
         if (stage == 0 && pending_cb) {
             // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
