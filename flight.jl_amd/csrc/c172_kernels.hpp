@@ -302,7 +302,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         // (~150 knots and values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
-        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
         const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
         auto emit = [&](int j, double kj) {
             const int idx = j * STEP_BLOCK + t;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         bool mod = false;
         if constexpr (X) {
             const InputsX inl = {&xt[X2_ACT], a.u + i + lds_off, a.n, ui};
-            bits = rhs<KIN, GROUND>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            bits = rhs<KIN, GROUND, true>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
             KArgs ao = a;
             ao.cs = a.cs + lds_off; ao.u = a.u + lds_off;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
         } else {
             InputsLds<STEP_BLOCK> inl = in;
             inl.p = in.p + lds_off;
-            bits = rhs<KIN, GROUND>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            bits = rhs<KIN, GROUND, true>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
             if (stage == 0 && pending_cb) mod = f_step<KIN>(xt, stall, eng, in, aux, bits);
         }
