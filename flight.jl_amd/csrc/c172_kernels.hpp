@@ -109,6 +109,7 @@ struct KArgs {
     const int32_t* ui;  // [n]
     int32_t* status;    // [n]
     const double* tables;  // LDS_TABLE_DOUBLES doubles
+    const float* tables_f32;  // the same blob in fp32 (fp32 stepper only)
     const float* egm96;
     int64_t n;
     Env env;

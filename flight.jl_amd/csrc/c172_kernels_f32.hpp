@@ -43,9 +43,9 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
     __shared__ float acc_l[NRF * B];          // k1 + 2 k2 + 2 k3
     __shared__ float xc_l[NRF * B];           // the state being evaluated, updated in place by emit()
     // tables: fp64 blob in global memory -> fp32 in LDS (propeller compacted to four coefficients like the fp64 stepper)
-    for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = (float)a.tables[k];
+    for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = a.tables_f32[k];
     for (int k = threadIdx.x; k < PR_NJ * PR_NM * PR_NC_STEP; k += blockDim.x)
-        lds[LDS_PROP + k] = (float)a.tables[LDS_PROP + (k / PR_NC_STEP) * PR_NC + (k % PR_NC_STEP)];
+        lds[LDS_PROP + k] = a.tables_f32[LDS_PROP + (k / PR_NC_STEP) * PR_NC + (k % PR_NC_STEP)];
     for (int k = threadIdx.x; k < LDS_RK_DOUBLES; k += blockDim.x) rk[k] = (float)(1.0 / (a.tables[k + 1] - a.tables[k]));
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
         StepAux aux;
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step)
-        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off};
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables_f32 + lds_off};
         Inputs inl = in;
         asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
         asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
             }
         };
         const SV xv = {(lds_cptr)xc_l + t + lds_off};
-        int32_t bits = rhs<FB_KIN_WA, false>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
+        int32_t bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
         if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // within reach of the ground: the fp64 kernel takes this lane over
         if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} = the x_n panels (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
             pending_cb = false;

@@ -45,6 +45,8 @@ struct fb_handle_s {
     double* y = nullptr;      // [FB_NY x n], allocated on first use
     double* xdot = nullptr;   // scratch [FB_NX x n]
     double* tables = nullptr; // LDS_TABLE_DOUBLES
+    float* tables_f32 = nullptr;  // fp32 mirror of `tables` (FB_F32 handles), refreshed when a table is uploaded
+    bool tables_f32_stale = true;
     float* egm96 = nullptr;
     double* trim_buf = nullptr;  // tp | ts | cost
     int32_t* trim_ok = nullptr;
@@ -72,7 +74,7 @@ struct fb_handle_s {
 
 static KArgs make_args(fb_handle h) {
     KArgs a;
-    a.x = h->x; a.s = h->s; a.u = h->u; a.ui = h->ui; a.status = h->status; a.tables = h->tables; a.egm96 = h->egm96;
+    a.x = h->x; a.s = h->s; a.u = h->u; a.ui = h->ui; a.status = h->status; a.tables = h->tables; a.tables_f32 = h->tables_f32; a.egm96 = h->egm96;
     a.n = h->n;
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface};
     a.dt = h->params.dt;
@@ -243,7 +245,7 @@ int32_t fb_destroy(fb_handle h) {
     log_free(h);
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
-    hipFree(h->tables); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
+    hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
     hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
@@ -339,6 +341,7 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
         default: return fail("unknown table kind");
     }
     h->have_table[kind] = true;
+    h->tables_f32_stale = true;
     return 0;
 }
 int32_t fb_set_params(fb_handle h, const fb_params* p) {
@@ -543,6 +546,14 @@ int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
 // nsteps of the stepping kernel, no logging
 static int32_t step_raw(fb_handle h, int64_t nsteps) {
     if (h->model == FB_MODEL_ROBOT2D) return r2_step(h, nsteps);
+    if (h->dtype == FB_F32 && h->tables_f32_stale) {   // fp32 mirror of the table blob for the fp32 stepper
+        std::vector<double> d(LDS_TABLE_DOUBLES);
+        HIPCHK(hipMemcpy(d.data(), h->tables, sizeof(double) * LDS_TABLE_DOUBLES, hipMemcpyDeviceToHost));
+        std::vector<float> f(d.begin(), d.end());
+        if (!h->tables_f32) HIPCHK(hipMalloc(&h->tables_f32, sizeof(float) * LDS_TABLE_DOUBLES));
+        HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * LDS_TABLE_DOUBLES, hipMemcpyHostToDevice));
+        h->tables_f32_stale = false;
+    }
     const KArgs a = make_args(h);
     int64_t left = nsteps;
     if (is_x2(h)) {
