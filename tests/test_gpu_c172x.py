@@ -216,3 +216,56 @@ def test_x2_segment_guidance_matches_oracle(fb, oracle, gains):
     print("cross-track error after 120 s: median", np.median(e_sb), "max", e_sb.max())
     assert np.median(e_sb) < 2.0 and (e_sb < 20.0).mean() > 0.95
     w.close()
+
+
+def test_x2_control_laws_fuzz(fb, oracle, gains):
+    """f_periodic!(Unconditional(), world) — guidance + control laws — from 16 384 random controller records: every pair of
+    previous / requested modes (so every bumpless-transfer branch), arbitrary compensator states and saturation flags, references
+    all over the place, gain lookups inside, on the edge of and outside the (EAS, h) grid; record and inputs against the oracle."""
+    K = fb.K
+    n = 16384
+    rng = np.random.default_rng(99)
+    tp = fb.TrimParameters(EAS=rng.uniform(36, 56, n), h_e=rng.uniform(100, 3300, n), ψ_nb=rng.uniform(-3, 3, n))
+    w = fb.Cessna172Xv2World(n, gains=gains)
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False)
+    fb.init(sim, tp)
+    x = w.x
+    x[K["FB_X2_DYN"]:K["FB_X2_DYN"] + 3] += rng.normal(0, 0.05, (3, n)); x[K["FB_X2_DYN"] + 3:] += rng.normal(0, 2.0, (3, n))
+    x[K["FB_X2_ACT"]:K["FB_X2_ACT"] + 4] += rng.normal(0, 0.2, (4, n))
+    w.set_state(x, w.s)
+    cu = w.cu
+    cu[K["FB_CU_LON_MODE_REQ"]] = rng.integers(0, 9, n); cu[K["FB_CU_LAT_MODE_REQ"]] = rng.integers(0, 5, n)
+    for k in ("THROTTLE_AXIS", "THROTTLE_OFFSET", "ELEVATOR_AXIS", "ELEVATOR_OFFSET", "AILERON_AXIS", "AILERON_OFFSET", "RUDDER_AXIS", "RUDDER_OFFSET"):
+        cu[K["FB_CU_" + k]] = rng.uniform(-1.3, 1.3, n)
+    cu[K["FB_CU_Q_REF"]] = rng.normal(0, 0.05, n); cu[K["FB_CU_THETA_REF"]] = rng.normal(0, 0.2, n); cu[K["FB_CU_EAS_REF"]] = rng.uniform(20, 70, n)
+    cu[K["FB_CU_CLM_REF"]] = rng.normal(0, 3, n); cu[K["FB_CU_H_REF"]] += rng.choice([-200.0, -10.5, -9.5, 0.0, 8.9, 11.2, 300.0], n)
+    cu[K["FB_CU_P_REF"]] = rng.normal(0, 0.1, n); cu[K["FB_CU_BETA_REF"]] = rng.normal(0, 0.1, n); cu[K["FB_CU_PHI_REF"]] = rng.normal(0, 0.6, n)
+    cu[K["FB_CU_CHI_REF"]] = rng.uniform(-7, 7, n)
+    cu[K["FB_CU_GDC_MODE_REQ"]] = rng.integers(0, 3, n); cu[K["FB_CU_SEG_HOR_REQ"]] = rng.integers(0, 2, n); cu[K["FB_CU_SEG_VRT_REQ"]] = rng.integers(0, 2, n)
+    fb.f_ode(w); y = w.y
+    cu[K["FB_CU_SEG_P1"]] = y[K["FB_Y_KIN"] + 15] + rng.normal(0, 2e-4, n); cu[K["FB_CU_SEG_P1"] + 1] = y[K["FB_Y_KIN"] + 16] + rng.normal(0, 2e-4, n)
+    cu[K["FB_CU_SEG_P1"] + 2] = y[K["FB_Y_KIN"] + 20] + rng.normal(0, 50, n)
+    cu[K["FB_CU_SEG_P2"]] = cu[K["FB_CU_SEG_P1"]] + rng.normal(0, 3e-3, n); cu[K["FB_CU_SEG_P2"] + 1] = cu[K["FB_CU_SEG_P1"] + 1] + rng.normal(0, 3e-3, n)
+    cu[K["FB_CU_SEG_P2"] + 2] = cu[K["FB_CU_SEG_P1"] + 2] + rng.normal(0, 100, n)
+    cs = rng.normal(0, 0.3, (K["FB_NCS"], n))
+    cs[K["FB_CS_LON_MODE"]] = rng.integers(0, 9, n); cs[K["FB_CS_LAT_MODE"]] = rng.integers(0, 5, n); cs[K["FB_CS_H_STATE"]] = rng.integers(0, 2, n)
+    for blk, cnt in (("TE2TE", 2), ("TV2TE", 2), ("VH2TE", 2), ("AR2AR", 2), ("PHIBETA2AR", 2)):
+        cs[K["FB_CS_" + blk] + 2:K["FB_CS_" + blk] + 4] = rng.integers(-1, 2, (2, n))
+    for blk, off in (("Q2E_INT", 1), ("P2PHI_INT", 1), ("Q2E_PID", 2), ("C2THETA_PID", 2), ("V2T_PID", 2), ("P2PHI_PID", 2), ("CHI2PHI_PID", 2)):
+        cs[K["FB_CS_" + blk] + off] = rng.integers(-1, 2, n)
+    for k in ("THROTTLE_CMD",):
+        cs[K["FB_CS_" + k]] = rng.uniform(0, 1, n)
+    w.cu = cu; w.cs = cs
+    perm = ref_to_dev_rows(K)
+    X = OracleX(oracle, gains)
+    st = dict(x=np.zeros((34, n)), u=w.u, ui=w.ui, s=w.s, cu=cu.copy(), cs=cs.copy())
+    st["x"][perm] = w.x
+    fb.f_periodic(w); w.sync()
+    X.f_periodic(st, oracle.default_env(), 0.02)
+    dcs = np.abs(w.cs - st["cs"]) / np.maximum(np.abs(st["cs"]), 1.0)
+    dcu = np.abs(w.cu - st["cu"]) / np.maximum(np.abs(st["cu"]), 1.0)
+    print("control-law fuzz: record %.2e (row %d), inputs %.2e" % (dcs.max(), dcs.max(1).argmax(), dcu.max()))
+    assert dcs.max() < 1e-9 and dcu.max() < 1e-9
+    for row in ("LON_MODE", "LAT_MODE", "H_STATE", "GDC_MODE", "SEG_HOR_GDC", "SEG_VRT_GDC"):
+        assert np.array_equal(w.cs[K["FB_CS_" + row]], st["cs"][K["FB_CS_" + row]]), row
+    w.close()

@@ -388,3 +388,51 @@ def test_approach_crosses_the_air_ground_handover(fb, oracle):
     x2, s2, st2 = results[1]
     assert np.array_equal(st2[ok], stg[ok])
     assert (np.abs(x2 - xg) / state_scale(xo))[:, live & ~near].max() < 1e-9
+
+
+def test_f_ode_fuzz_wide_envelope(fb, oracle):
+    """f_ode! on 65 536 random states far outside the benchmark's envelope — every attitude, −500 m … 25 km (three ISA layers),
+    0 … 120 m/s in any direction, tumbling rates, every engine state, stalled or not, random inputs, wind and a non-standard day —
+    against the oracle: ẋ, the output record and the status words."""
+    n = 65536
+    rng = np.random.default_rng(2026)
+    x = np.zeros((27, n))
+    x[0] = rng.uniform(-0.3, 0.5, n); x[1] = rng.uniform(-0.3, 0.3, n)
+    x[2:8] = rng.normal(0, 0.3, (6, n)) * (rng.random((1, n)) < 0.3)
+    x[8] = rng.uniform(0, 1, n)
+    x[9] = rng.uniform(0, 320, n); x[10] = rng.uniform(-0.5, 0.5, n); x[11] = rng.uniform(-1, 1, n)
+    q = rng.normal(size=(4, n)); q /= np.linalg.norm(q, axis=0); x[12:16] = q * (1 + rng.uniform(-1e-8, 1e-8, n))
+    qe = rng.normal(size=(4, n)); qe /= np.linalg.norm(qe, axis=0); x[16:20] = qe * (1 + rng.uniform(-1e-8, 1e-8, n))
+    x[20] = np.where(rng.random(n) < 0.2, rng.uniform(11000, 25000, n), rng.uniform(-500, 11000, n))
+    x[21:24] = rng.normal(0, 0.5, (3, n))
+    x[24:27] = rng.normal(0, 1, (3, n)); x[24:27] *= rng.uniform(0, 120, n) / np.linalg.norm(x[24:27], axis=0)
+    s = np.stack([rng.integers(0, 2, n), rng.integers(0, 3, n)]).astype(np.int32)
+    u = np.zeros((16, n))
+    u[0] = rng.uniform(-0.2, 1.2, n); u[1] = rng.uniform(-0.2, 1.2, n); u[2:8] = rng.uniform(-1.3, 1.3, (6, n)); u[8] = rng.uniform(-0.2, 1.2, n)
+    u[9:11] = rng.uniform(0, 1, (2, n)); u[11:16] = rng.uniform(-10, 120, (5, n))
+    ui = rng.integers(0, 16, n).astype(np.int32)
+    env = oracle.default_env(T_sl=300.0, p_sl=99000.0, wind=(12.0, -7.0, 1.5), h_trn=-600.0)   # terrain far below: airborne everywhere
+    w = fb.BatchedWorld(n)
+    w.set_params(T_sl=300.0, p_sl=99000.0, wind_ned=(12.0, -7.0, 1.5), h_terrain=-600.0)
+    w.set_state(x, s); w.u = u; w.ui = ui
+    xd = np.zeros((27, n)); fb.f_ode(w, xd)
+    y, st = w.y, w.status
+    xdo, yo, sto = oracle.f_ode(x, u, ui, s, env)
+    assert np.array_equal(st, sto)
+    ok = sto == 0
+    assert ok.mean() > 0.9
+    err = (np.abs(xd - xdo) / np.maximum(np.abs(xdo), 1.0))[:, ok]
+    sc_y = np.maximum(np.abs(yo), 1.0); sc_y[22:25] = 6.4e6
+    erry = (np.abs(y - yo) / sc_y)[:, ok]
+    print("fuzz: max scaled xdot error %.2e (row %d), y error %.2e (row %d)" % (err.max(), err.max(1).argmax(), erry.max(), erry.max(1).argmax()))
+    assert err.max() < 1e-8 and erry.max() < 1e-8
+    # and the stepping kernels on the same wild states: 20 steps against the oracle, airborne lanes that stay valid
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=20)
+    fb.step(sim, 0.2); w.sync()
+    xo, so, sto2 = oracle.step(x, u, ui, s, env, 0.01, 20)
+    both = (w.status == 0) & (sto2 == 0)
+    assert np.array_equal(w.status != 0, sto2 != 0) and both.mean() > 0.85
+    e2 = (np.abs(w.x - xo) / state_scale(xo))[:, both]
+    print("fuzz: 20 steps, max scaled state error %.2e (row %d)" % (e2.max(), e2.max(1).argmax()))
+    assert e2.max() < 1e-6 and np.array_equal(w.s[:, both], so[:, both])
+    w.close()
