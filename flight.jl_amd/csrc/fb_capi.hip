@@ -168,6 +168,7 @@ static int32_t copy_rows(fb_handle h, double* dev, const double* host_in, double
 
 #include "fb_robot2d.inc"
 #include "fb_log.inc"
+struct ncclUniqueIdBlob { char internal[128]; };   // ncclUniqueId (rccl.h:40-43), passed by value
 
 extern "C" {
 
@@ -737,3 +738,6 @@ int32_t fb_timing_end(fb_handle h, float* ms, int64_t* n_launches) {
 }
 
 }  // extern "C"
+
+#include "fb_comm.inc"
+

@@ -150,6 +150,18 @@ function step!(sim::BatchedSimulation, Δt_total::Real = sim.dt, stop_at_tdt::Bo
 end
 Base.getproperty(sim::BatchedSimulation, s::Symbol) = s === :t ? getfield(sim, :nstep) * getfield(sim, :dt) : getfield(sim, s)
 
+# ---- multi-GPU trajectory collection: one process per GPU, one RCCL all-gather of the state panels (include/flightbatch.h) -------
+"rank 0: `id = comm_unique_id()`, hand the 128 bytes to the other ranks (file, MPI, sockets); every rank: `comm_init(world_handle, nranks, rank, id)`"
+comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:fb_comm_unique_id, lib), Cint, (Ptr{UInt8},), id)); id)
+function comm_init(w::BatchedWorld, nranks::Integer, rank::Integer, id::Vector{UInt8})
+    comm = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:fb_comm_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ptr{Ptr{Cvoid}}), w.handle, nranks, rank, id, comm))
+    return comm[]
+end
+"all-gather of the device-layout state into `recv_dev` (device pointer to nranks x Nx x N doubles), asynchronous on the world's stream"
+gather_state!(w::BatchedWorld, comm::Ptr{Cvoid}, recv_dev::Ptr{Cvoid}) =
+    check(ccall((:fb_gather_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), w.handle, comm, recv_dev))
+
 # ---- saving: the SavingCallback / TimeSeries(sim) of FC/sim.jl:210-217,644-704, kept on the device -------------------
 const LOG_X0 = Cint(1000)   # FB_LOG_X0: rows >= LOG_X0 select state rows, rows < LOG_X0 rows of the output record y
 "Log `rows` (0-based, see include/flightbatch.h FB_Y_*) every `saveat` seconds into a device buffer of `capacity` samples."

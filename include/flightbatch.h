@@ -283,6 +283,16 @@ int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double
 /* SimulationTermination / ArgumentError mapping: per-aircraft sticky status bits (FB_ST_*). */
 int32_t fb_status(fb_handle h, int32_t* status);
 
+/* Trajectory collection across GPUs: one RCCL all-gather of the state panels over xGMI; no other
+ * communication exists on this path. One process per GPU; rank 0 calls fb_comm_unique_id and the host distributes the 128
+ * bytes out of band; every rank calls fb_comm_init (collective), then fb_gather_state enqueues, on the handle's stream,
+ * an all-gather of its x (DEVICE layout, [N x FB_NX] or [N x FB_X2_NX] doubles, see fb_attach_state) into recv_dev
+ * [world x Nx x N] (device memory, rank-major). RCCL is loaded on first use. */
+int32_t fb_comm_unique_id(char* id128);
+int32_t fb_comm_init(fb_handle h, int32_t world, int32_t rank, const char* id128, void** comm);
+int32_t fb_gather_state(fb_handle h, void* comm, double* recv_dev);
+int32_t fb_comm_destroy(void* comm);
+
 /* Checkpoint / restore: together with fb_get/set_state, fb_get/set_inputs and (Xv2) fb_get/set_ctl_inputs|state these
  * capture everything a resumed run needs: the number of steps taken since the last init (the phase of the periodic
  * update, FC/modeling.jl:99 `_n`), sim.t, and the sticky status words (fb_set_state clears them, like init!). */

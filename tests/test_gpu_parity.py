@@ -436,3 +436,41 @@ def test_f_ode_fuzz_wide_envelope(fb, oracle):
     print("fuzz: 20 steps, max scaled state error %.2e (row %d)" % (e2.max(), e2.max(1).argmax()))
     assert e2.max() < 1e-6 and np.array_equal(w.s[:, both], so[:, both])
     w.close()
+
+
+def test_rccl_gather_state_single_rank(fb):
+    """fb_comm_* / fb_gather_state: the C-level trajectory collection (RCCL all-gather on the handle's stream). The GPU box has
+    one GPU, so this is the world-size-1 communicator: the gathered panel must equal the state. Runs in a child process that
+    never imports torch: torch bundles its own HIP / HSA / RCCL runtimes, and the system RCCL this entry point loads must see the
+    same runtime as libflightbatch."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys, numpy as np
+        sys.path.insert(0, os.path.join(os.getcwd(), "flight.jl_amd")); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        import flightbatch as fb
+        hip = C.CDLL("libamdhip64.so")
+        n = 4096
+        w = fb.BatchedWorld(n)
+        fb.f_init(w, fb.TrimParameters(EAS=np.linspace(40, 50, n)))
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=10)
+        fb.step(sim, 0.1)
+        uid = C.create_string_buffer(128)
+        fb._lib.check(fb.lib.fb_comm_unique_id(uid))
+        comm = C.c_void_p()
+        fb._lib.check(fb.lib.fb_comm_init(w._h, 1, 0, uid, C.byref(comm)))
+        recv = C.c_void_p()
+        assert hip.hipMalloc(C.byref(recv), C.c_size_t(27 * n * 8)) == 0
+        fb._lib.check(fb.lib.fb_gather_state(w._h, comm, recv))
+        w.sync()
+        out = np.zeros((27, n))
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), recv, C.c_size_t(27 * n * 8), 2) == 0
+        assert np.array_equal(out, w.x), "gathered panel differs from the state"
+        fb._lib.check(fb.lib.fb_comm_destroy(comm))
+        print("RCCL_GATHER_OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert "RCCL_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
