@@ -290,8 +290,10 @@ class Simulation:
 
     def __init__(self, mdl: BatchedWorld, dt: float = 0.02, Δt: float | None = None, t_start: float = 0.0,
                  t_end: float = 10000.0, save_on: bool = True, saveat: float | None = None, steps_per_launch: int | None = None,
-                 save_outputs: bool = False, save_rows=None, save_x: bool = True, log_capacity: int | None = None):
+                 save_outputs: bool = False, save_rows=None, save_x: bool = True, log_capacity: int | None = None,
+                 user_callback=None):
         self.mdl = mdl
+        self.user_callback = user_callback   # user_callback!(mdl), FC/sim.jl:190,331-341: runs after every step's f_step!/f_periodic!
         self.dt = float(dt)
         self.Δt = float(Δt if Δt is not None else dt)
         ratio = self.Δt / self.dt
@@ -367,9 +369,17 @@ def step(sim: Simulation, Δt_total: float | None = None, stop_at_tdt: bool = Tr
     """step!(sim) / step!(sim, Δt_total, true): FC/sim.jl:386 (OrdinaryDiffEq step!). Asynchronous: the launches (and the
     device-side saves between them) are queued on the world's stream."""
     n = 1 if Δt_total is None else int(round(Δt_total / sim.dt))
-    check(lib.fb_step(sim.mdl._h, n))
-    sim._nstep += n
-    sim.mdl.t = sim.t
+    if sim.user_callback is None:
+        check(lib.fb_step(sim.mdl._h, n))
+        sim._nstep += n
+        sim.mdl.t = sim.t
+        return None
+    # cb_user_affect! (FC/sim.jl:331-341) runs on the host after EVERY step: launches are one step long while a callback is set
+    for _ in range(n):
+        check(lib.fb_step(sim.mdl._h, 1))
+        sim._nstep += 1
+        sim.mdl.t = sim.t
+        sim.user_callback(sim.mdl)
     return None
 
 

@@ -119,3 +119,23 @@ def test_mixed_fleet_c172_and_robot2d(fb, oracle):
     fb.init(sim, fb.TrimParameters(EAS=EAS, h_e=1000.0)); fb.step(sim, 2.0); w.sync()
     assert np.array_equal(w.x, x[:, ~is_r])
     w.close(); fleet.close()
+
+
+def test_user_callback_runs_after_every_step(fb):
+    """Simulation(mdl; user_callback!) (FC/sim.jl:190, 331-341): the callback sees the model after each step and may change its
+    inputs — here a velocity reference that follows sin(t), like the reference's own use in FPt/test_control.jl:221-232."""
+    n = 64
+    w = fb.Robot2DWorld(n)
+    calls = []
+
+    def cb(mdl):
+        calls.append(mdl.t)
+        u = mdl.u; u[0] = 1; u[2] = 0.2 * np.sin(mdl.t); mdl.u = u
+
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, user_callback=cb)
+    fb.init(sim, fb.InitParameters())
+    fb.step(sim, 3.0); w.sync()
+    assert len(calls) == 300 and np.allclose(calls, 0.01 * np.arange(1, 301))
+    v = w.x[1]
+    assert np.all((np.abs(v) > 0.02) & (np.abs(v) < 0.25)) and (w.status == 0).all()   # driven by the moving reference (with the loop's lag)
+    w.close()
