@@ -170,40 +170,14 @@ static int32_t copy_rows(fb_handle h, double* dev, const double* host_in, double
 #include "fb_log.inc"
 struct ncclUniqueIdBlob { char internal[128]; };   // ncclUniqueId (rccl.h:40-43), passed by value
 
-extern "C" {
-
-const char* fb_last_error(void) { return g_err.c_str(); }
-const char* fb_version(void) { return "flightbatch 0.1 (gfx950)"; }
-
-int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out) {
-    if (!out) return fail("out is null");
-    *out = nullptr;
-    if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
-    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
-    if (model_id == FB_MODEL_C172X2 && kin_id != FB_KIN_WA) return fail("Cessna172Xv2: only FB_KIN_WA is implemented");
-    if (model_id == FB_MODEL_C172X2 && dtype != FB_F64) return fail("Cessna172Xv2: only FB_F64 is implemented");
-    if (model_id == FB_MODEL_C172S0 && dtype == FB_F32 && kin_id != FB_KIN_WA) return fail("Cessna172Sv0 in fp32: only FB_KIN_WA is implemented");
-    if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
-    if (n <= 0) return fail("n must be positive");
-    if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: libflightbatch requires a GPU");
-    if (device_id >= ndev) return fail("device_id out of range");
-    HIPCHK(hipSetDevice(device_id));
-    fb_handle h = new fb_handle_s();
-    h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
-    h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
-    h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
-    h->params.wind_ned[0] = h->params.wind_ned[1] = h->params.wind_ned[2] = 0.0;
-    h->params.h_terrain = 0.0;
+// device-side resources of a new handle; on failure fb_create destroys the partially built handle (nothing leaks)
+static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, int64_t n) {
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     if (model_id == FB_MODEL_ROBOT2D) {
-        if (int32_t rc = r2_create(h, dtype)) { return rc; }
-        *out = h;
-        return 0;
+        return r2_create(h, dtype);
     }
     const int nx = is_x2(h) ? (int)FB_X2_NX : (int)FB_NX;   // device rows
     HIPCHK(hipMalloc(&h->x_own, sizeof(double) * nx * n));
@@ -235,6 +209,41 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
         std::vector<int32_t> ui((size_t)n, FB_UI_DEFAULT);
         HIPCHK(hipMemcpyAsync(h->ui, ui.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" {
+
+const char* fb_last_error(void) { return g_err.c_str(); }
+const char* fb_version(void) { return "flightbatch 0.1 (gfx950)"; }
+
+int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, int32_t device_id, fb_handle* out) {
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
+    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
+    if (model_id == FB_MODEL_C172X2 && kin_id != FB_KIN_WA) return fail("Cessna172Xv2: only FB_KIN_WA is implemented");
+    if (model_id == FB_MODEL_C172X2 && dtype != FB_F64) return fail("Cessna172Xv2: only FB_F64 is implemented");
+    if (model_id == FB_MODEL_C172S0 && dtype == FB_F32 && kin_id != FB_KIN_WA) return fail("Cessna172Sv0 in fp32: only FB_KIN_WA is implemented");
+    if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
+    if (n <= 0) return fail("n must be positive");
+    if (device_id < 0) return fail("device_id < 0: libflightbatch has no CPU backend");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: libflightbatch requires a GPU");
+    if (device_id >= ndev) return fail("device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    fb_handle h = new fb_handle_s();
+    h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
+    h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
+    h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
+    h->params.wind_ned[0] = h->params.wind_ned[1] = h->params.wind_ned[2] = 0.0;
+    h->params.h_terrain = 0.0;
+    if (int32_t rc = create_resources(h, model_id, dtype, n)) {
+        const std::string msg = g_err;   // fb_destroy must not clobber the reason
+        fb_destroy(h);
+        g_err = msg;
+        return rc;
     }
     *out = h;
     return 0;
