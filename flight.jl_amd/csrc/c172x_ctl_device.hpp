@@ -13,8 +13,16 @@
 
 namespace fbd {
 
-struct CtlTab {
-    const double* lk[10];  // te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ lookups inside the FB_TABLE_CTL_GAINS blob (global memory)
+// the ten lookups (te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ) inside the FB_TABLE_CTL_GAINS blob: offsets in doubles, and the
+// pointer type the control laws read them through — global memory (init kernel) or the workgroup's LDS copy (periodic kernel:
+// 46 KB staged once per workgroup; the ~330 corner loads per aircraft then cost LDS, not L2, latency)
+struct CtlOffsets { int off[10]; int total; };
+typedef __attribute__((address_space(3))) const double* ldsd_cptr;
+template <class P>
+struct CtlTabT {
+    P base;
+    CtlOffsets o;
+    FBD P lk(int k) const { return base + o.off[k]; }
 };
 struct CtlMem {
     double* cu;        // &cu[0 * n + i]  (guidance rewrites references and mode requests)
@@ -57,8 +65,8 @@ FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI))
 constexpr double CTL_INF = __builtin_huge_val();
 
 // ---- gain lookup: bilinear over the (EAS, h) grid, record by record -------------------------------------------
-template <int REC>
-FBD void ctl_lookup(const double* lk, double EAS, double h, double (&out)[REC]) {
+template <int REC, class P>
+FBD void ctl_lookup(P lk, double EAS, double h, double (&out)[REC]) {
     const int nE = (int)lk[0], nH = (int)lk[1];
     int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
     double wE = 0, wH = 0;
@@ -70,18 +78,19 @@ FBD void ctl_lookup(const double* lk, double EAS, double h, double (&out)[REC]) 
         const double xj = (fmin(fmax(h, lk[4]), lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
         j0 = min(max((int)floor(xj), 0), nH - 2); j1 = j0 + 1; wH = xj - j0;
     }
-    const double* d = lk + FB_CTL_GRID_HDR;
-    const double* a00 = d + (size_t)(i0 + nE * j0) * REC;
-    const double* a10 = d + (size_t)(i1 + nE * j0) * REC;
-    const double* a01 = d + (size_t)(i0 + nE * j1) * REC;
-    const double* a11 = d + (size_t)(i1 + nE * j1) * REC;
+    const P d = lk + FB_CTL_GRID_HDR;
+    const P a00 = d + (i0 + nE * j0) * REC;
+    const P a10 = d + (i1 + nE * j0) * REC;
+    const P a01 = d + (i0 + nE * j1) * REC;
+    const P a11 = d + (i1 + nE * j1) * REC;
 #pragma unroll
     for (int c = 0; c < REC; c++) out[c] = (1 - wE) * ((1 - wH) * a00[c] + wH * a01[c]) + wE * ((1 - wH) * a10[c] + wH * a11[c]);
 }
 
 // ---- compensators; their states are rows of the cs record ------------------------------------------------------
 struct PidGains { double k_p, k_i, k_d, tau_f; };
-FBD PidGains pid_gains(const double* lk, double EAS, double h) {
+template <class P>
+FBD PidGains pid_gains(P lk, double EAS, double h) {
     double g[FB_CTL_PID_REC];
     ctl_lookup<FB_CTL_PID_REC>(lk, EAS, h, g);
     return {g[0], g[1], g[2], g[3]};
@@ -145,7 +154,8 @@ FBD void lqr_init(const CtlMem& M, int s0, const double* g, const double (&lo)[2
 }
 
 // ---- longitudinal channel ------------------------------------------------------------------------------------------
-FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+template <class TAB>
+FBD void ctl_lon(const TAB& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
     double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
     const double EAS_ref = M.U(FB_CU_EAS_REF), clm_ref = M.U(FB_CU_CLM_REF), h_ref = M.U(FB_CU_H_REF);
     const double EAS = v.EAS, h_e = v.h_e, q = v.w_wb_b.y, r = v.w_wb_b.z, theta = v.theta;
@@ -179,12 +189,12 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     if (te2te) {
         const double sat_thr = M.S(FB_CS_TE2TE + 2), sat_ele = M.S(FB_CS_TE2TE + 3);   // te2te_lqr.y.out_sat of the previous update
         if (v2t) {
-            const PidGains P = pid_gains(T.lk[5], EAS, h_e);
+            const PidGains P = pid_gains(T.lk(5), EAS, h_e);
             if (changed) { pid_init(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT); if (P.k_i != 0) M.S(FB_CS_V2T_PID) = M.S(FB_CS_THROTTLE_CMD); }
             throttle_ref = pid_run(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT, EAS_ref - EAS, sat_thr);
         }
         if (q2e) {
-            const PidGains P = pid_gains(T.lk[3], EAS, h_e);
+            const PidGains P = pid_gains(T.lk(3), EAS, h_e);
             if (changed) {
                 integ_init(M, FB_CS_Q2E_INT, dT);
                 pid_init(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT);
@@ -192,7 +202,7 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
             }
             if (th2q) {
                 if (mode == FB_LON_EAS_CLM) {
-                    const PidGains Pc = pid_gains(T.lk[4], EAS, h_e);
+                    const PidGains Pc = pid_gains(T.lk(4), EAS, h_e);
                     if (changed) { pid_init(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT); if (Pc.k_i != 0) M.S(FB_CS_C2THETA_PID) = theta; }
                     theta_ref = pid_run(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT, clm_ref - v.clm, sat_ele);
                 }
@@ -204,7 +214,7 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
             elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
         }
         double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[0], EAS, h_e, g);
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g);
         const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
         M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
         lqr_run<8>(M, FB_CS_TE2TE, g, lo, hi, dT, x_red, z, z_ref, out);
@@ -212,7 +222,7 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     }
     if (mode == FB_LON_THR_EAS) {
         double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[1], EAS, h_e, g);
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(1), EAS, h_e, g);
         if (changed) lqr_init<8>(M, FB_CS_TV2TE, g, lo, hi, dT);
         const double z[2] = {v.cmd[0], EAS}, z_ref[2] = {throttle_ref, EAS_ref};
         lqr_run<8>(M, FB_CS_TV2TE, g, lo, hi, dT, x_red, z, z_ref, out);
@@ -220,7 +230,7 @@ FBD void ctl_lon(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     }
     if (mode == FB_LON_EAS_ALT) {
         double g[FB_CTL_LQR9_REC];
-        ctl_lookup<FB_CTL_LQR9_REC>(T.lk[2], EAS, h_e, g);
+        ctl_lookup<FB_CTL_LQR9_REC>(T.lk(2), EAS, h_e, g);
         if (changed) lqr_init<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
         const double x_full[9] = {v.w_eb_b.y, theta, EAS, v.alpha, h_e, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
         const double z[2] = {EAS, h_e}, z_ref[2] = {EAS_ref, h_ref};
@@ -277,7 +287,8 @@ FBD void gdc_update(const CtlMem& M, const CtlIn& v) {
 }
 
 // ---- lateral channel -----------------------------------------------------------------------------------------------
-FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+template <class TAB>
+FBD void ctl_lat(const TAB& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
     const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
     double phi_ref = M.U(FB_CU_PHI_REF);
     const double EAS = v.EAS, h_e = v.h_e;
@@ -292,7 +303,7 @@ FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     double out[2];
     if (mode == FB_LAT_SAS) {
         double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[6], EAS, h_e, g);
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(6), EAS, h_e, g);
         const double z[2] = {v.cmd[1], v.cmd[3]}, z_ref[2] = {aileron_ref, rudder_ref};
         lqr_run<8>(M, FB_CS_AR2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
         aileron_cmd = out[0]; rudder_cmd = out[1];
@@ -300,7 +311,7 @@ FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
     if (mode == FB_LAT_P_BETA || mode == FB_LAT_PHI_BETA || mode == FB_LAT_CHI_BETA) {
         const double sat_ail = M.S(FB_CS_PHIBETA2AR + 2);
         if (mode == FB_LAT_P_BETA) {
-            const PidGains P = pid_gains(T.lk[8], EAS, h_e);
+            const PidGains P = pid_gains(T.lk(8), EAS, h_e);
             if (changed) {
                 integ_init(M, FB_CS_P2PHI_INT, dT);
                 pid_init(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT);
@@ -309,12 +320,12 @@ FBD void ctl_lat(const CtlTab& T, const CtlMem& M, double dT, const CtlIn& v, in
             const double io = integ_run(M, FB_CS_P2PHI_INT, dT, p_ref - v.w_wb_b.x, sat_ail);
             phi_ref = pid_run(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ail);
         } else if (mode == FB_LAT_CHI_BETA) {
-            const PidGains P = pid_gains(T.lk[9], EAS, h_e);
+            const PidGains P = pid_gains(T.lk(9), EAS, h_e);
             if (changed) { pid_init(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT); if (P.k_i != 0) M.S(FB_CS_CHI2PHI_PID) = M.S(FB_CS_PHIBETA2AR + 4); }
             phi_ref = pid_run(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT, wrap_to_pi(chi_ref - v.chi), sat_ail);
         }
         double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk[7], EAS, h_e, g);
+        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(7), EAS, h_e, g);
         if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT);
         const double z[2] = {v.phi, v.beta}, z_ref[2] = {phi_ref, beta_ref};
         M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];

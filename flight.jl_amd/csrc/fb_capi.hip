@@ -67,6 +67,7 @@ struct fb_handle_s {
     int32_t* k1_valid = nullptr;
     double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
     int64_t gains_off[10] = {0};
+    int64_t gains_total = 0;
     bool have_gains = false;
     int64_t steps_done = 0;    // steps since the last init (phase of the periodic update)
     struct LogState* log = nullptr;  // on-device TimeSeries log (fb_log_*)
@@ -150,7 +151,9 @@ static row_map_t row_map_of(fb_handle h) {
     } while (0)
 static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
     CtlArgs c;
-    for (int k = 0; k < 10; k++) c.tab.lk[k] = h->gains + h->gains_off[k];
+    c.gains = h->gains;
+    for (int k = 0; k < 10; k++) c.off.off[k] = (int)h->gains_off[k];
+    c.off.total = (int)h->gains_total;
     c.dT = h->params.dt * (h->params.periodic_n > 0 ? h->params.periodic_n : 1);
     c.use_q_pre = use_q_pre;
     return c;
@@ -319,6 +322,8 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
             off += FB_CTL_GRID_HDR + nE * nH * rec[k];
         }
         if (off != count) return fail("control-law gains blob: %lld doubles given, layout needs %lld", (long long)count, (long long)off);
+        if (count > CTL_GAINS_MAX) return fail("control-law gains blob: %lld doubles exceed the %d the periodic kernel stages in LDS", (long long)count, (int)CTL_GAINS_MAX);
+        h->gains_total = count;
         if (h->gains) { (void)hipFree(h->gains); h->gains = nullptr; }
         HIPCHK(hipMalloc(&h->gains, sizeof(double) * count));
         HIPCHK(hipMemcpy(h->gains, data, sizeof(double) * count, hipMemcpyHostToDevice));
