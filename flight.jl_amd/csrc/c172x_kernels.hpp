@@ -37,11 +37,12 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
 
 constexpr int CTL_GAINS_MAX = 6144;   // doubles of LDS reserved for the gains blob (the shipped lookups need 5744)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_x2_ctl(KArgs a, CtlArgs c) {
-    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
-    __shared__ double rk[LDS_RK_DOUBLES];
+    // The partial sink needs none of the aero / engine / propeller tables (everything that reads them is dead code here), so
+    // they are not staged; the pointers below are never dereferenced.
     __shared__ double gains_l[CTL_GAINS_MAX];
     for (int k = threadIdx.x; k < c.off.total; k += blockDim.x) gains_l[k] = c.gains[k];
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    __syncthreads();
+    double* lds = gains_l; double* rk = gains_l;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (a.status[i] != 0) return;
