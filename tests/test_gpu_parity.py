@@ -474,3 +474,45 @@ def test_rccl_gather_state_single_rank(fb):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert "RCCL_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_takeoff_ground_to_air_handover(fb, oracle):
+    """Take-off roll from rest, rotation, lift-off and climb through the 10 m limit: lanes start in the ground-capable pass
+    (non-zero contact regulators, weight on wheels) and must migrate to the airborne pass without a seam. Ground contact is
+    ill-conditioned (see test_ground_contact_matches_oracle), so the comparison with the oracle is on the flight path."""
+    n = 128
+    rng = np.random.default_rng(23)
+    env = oracle.default_env()
+    r = oracle.trim(lattice_trim_params(fb, 1, seed=1).pack(1), fb.TrimState(1), env)
+    x = np.repeat(r["x"], n, axis=1)
+    x[21:27] = 0; x[12:16] = np.array([1.0, 0, 0, 0])[:, None]            # level, at rest
+    y0 = oracle.f_ode(x[:, :1], r["u"], r["ui"], r["s"], env)[1][:, 0]
+    x[20] += 1.85 - y0[fb.K["FB_Y_KIN"] + 21]                              # wheels just compressed on the runway (terrain at 0 m)
+    u = np.repeat(r["u"], n, axis=1)
+    u[fb.K["FB_U_THROTTLE"]] = 1.0; u[fb.K["FB_U_FLAPS"]] = 0.3
+    u[fb.K["FB_U_ELEVATOR"]] = rng.uniform(-0.35, -0.2, n)                 # stick held back: rotates when the tail has authority
+    u[fb.K["FB_U_AILERON"]] = 0.0; u[fb.K["FB_U_RUDDER"]] = rng.uniform(0.0, 0.08, n)
+    ui = np.repeat(r["ui"], n); s = np.repeat(r["s"], n, axis=1)
+    w = fb.BatchedWorld(n)
+    w.set_state(x, s); w.u = u; w.ui = ui
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    xo, so = x.copy(), s.copy()
+    lift_g = np.full(n, np.nan); lift_o = np.full(n, np.nan)
+    for k in range(35):
+        fb.step(sim, 1.0); w.sync()
+        xo, so, sto = oracle.step(xo, u, ui, so, env, 0.01, 100)
+        fb.f_ode(w); yg = w.y
+        yo = oracle.f_ode(xo, u, ui, so, env)[1]
+        wg = (yg[79] + yg[90] + yg[101]) > 0; wo = (yo[79] + yo[90] + yo[101]) > 0
+        lift_g = np.where(np.isnan(lift_g) & ~wg, k + 1.0, lift_g); lift_o = np.where(np.isnan(lift_o) & ~wo, k + 1.0, lift_o)
+    assert np.array_equal(w.status, sto)
+    ok = (sto == 0)
+    agl = yo[fb.K["FB_Y_KIN"] + 21]
+    print("lift-off after %.0f-%.0f s; final height %.1f-%.1f m; still on wheels: %d; terminated %d"
+          % (np.nanmin(lift_o), np.nanmax(lift_o), agl[ok].min(), agl[ok].max(), int(np.isnan(lift_o).sum()), int((~ok).sum())))
+    assert np.isnan(lift_o).sum() == 0 and (agl[ok] > 10).mean() > 0.8, "the scenario must leave the ground and cross the hand-over"
+    assert np.array_equal(lift_g, lift_o)
+    err = (np.abs(w.x - xo) / state_scale(xo))[:, ok]
+    print("take-off, max scaled error after 35 s: %.2e" % err.max())
+    assert err.max() < 1e-3 and np.abs(w.x[20] - xo[20])[ok].max() < 1e-2
+    w.close()
