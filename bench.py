@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("c172s0", "c172x2"), default="c172s0",
+                    help="c172s0: BASELINE.json configs[2] (default, the headline metric). c172x2: configs[3] — 524 288 Cessna172Xv2 per GPU "
+                         "with the autopilot at Δt = 0.02 in the README-example-2 scenario (fp64 only)")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f64: the parity path (default, BASELINE.json's metric). f32: the fp32 airborne stepper (config 5's dtype)")
     args = ap.parse_args()
@@ -133,19 +136,30 @@ def main():
     import ctypes as C
     import flightbatch as fb
 
-    n = N_PER_GPU
-    w = fb.BatchedWorld(n, device=local_rank, dtype=args.dtype)
+    x2 = args.workload == "c172x2"
+    if x2 and args.dtype != "f64":
+        raise SystemExit("--workload c172x2 is fp64 only")
+    n = N_PER_GPU // 2 if x2 else N_PER_GPU
+    nrows = fb.K["FB_X2_NX"] if x2 else fb.K["FB_NX"]
+    w = fb.Cessna172Xv2World(n, device=local_rank) if x2 else fb.BatchedWorld(n, device=local_rank, dtype=args.dtype)
     # the state lives in a torch tensor so that RCCL can gather it without a host round trip
-    x_dev = torch.zeros((fb.K["FB_NX"], n), dtype=torch.float64, device="cuda")
+    x_dev = torch.zeros((nrows, n), dtype=torch.float64, device="cuda")
     s_dev = torch.zeros((fb.K["FB_NS"], n), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     fb._lib.check(fb.lib.fb_attach_state(w._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(s_dev.data_ptr())))
-    EAS, h, psi = lattice(rank)
-    fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+    if x2:   # README example 2: default trim, wind N = 1, E = 0.5 m/s, EAS + climb rate (2 m/s), bank + sideslip (30 deg)
+        w.set_params(wind_ned=(1.0, 0.5, 0.0))
+        sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=2)
+        fb.init(sim, fb.TrimParameters())
+        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+        w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+    else:
+        EAS, h, psi = lattice(rank)
+        fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+        sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=args.inner)
     trim_ok = float(w.trim_success.mean())
-    x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
-
-    sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=args.inner)
+    if not x2:
+        x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
 
     def barrier():
         if world > 1:
@@ -174,7 +188,7 @@ def main():
         torch.cuda.synchronize(); g0 = time.perf_counter()
         gathered = fb.sharding.all_gather_state(x_dev, n * world)
         torch.cuda.synchronize(); gather_ms = (time.perf_counter() - g0) * 1e3
-        assert gathered.shape == (fb.K["FB_NX"], n * world)
+        assert gathered.shape == (nrows, n * world)
     else:
         gather_ms = None
 
@@ -185,12 +199,13 @@ def main():
     value = total_units / elapsed
 
     if rank == 0:
-        units_per_launch = float(n) * args.inner
-        achieved_gbs = BYTES_PER_AIRCRAFT_STEP * units_per_launch / (kernel_ms * 1e-3) / 1e9
+        units_per_launch = float(n) * (2 if x2 else args.inner)   # c172x2: one launch group = one control period = 2 RK4 steps
+        bytes_per_unit = 756.0 if x2 else BYTES_PER_AIRCRAFT_STEP
+        achieved_gbs = bytes_per_unit * units_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         valu = None
         prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
-        if os.path.exists(prof) and args.dtype == "f64":   # the committed counters describe the fp64 kernel
+        if os.path.exists(prof) and args.dtype == "f64" and not x2:   # the committed counters describe the fp64 kernel
             pj = json.load(open(prof))
             if pj.get("n") == n and pj.get("inner") == args.inner:
                 traffic = pj.get("hbm_bytes_per_launch")
@@ -203,9 +218,11 @@ def main():
             "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "N=1048576 Cessna172Sv0 per GPU, randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, "
+            "config": {"workload": ("N=524288 Cessna172Xv2 per GPU, default trim, README example 2 scenario (wind, EAS + climb-rate and bank + sideslip "
+                                    "modes), autopilot every 2 steps, fp64, dt=0.01 (BASELINE.json configs[3])") if x2 else
+                                   "N=1048576 Cessna172Sv0 per GPU, randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, "
                                    "LCG-permuted), " + ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])",
-                       "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
+                       "aircraft_per_gpu": n, "rk4_steps_per_launch": (2 if x2 else args.inner), "rk4_steps_per_contract_step": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
                        "trim_success_fraction": trim_ok, "terminated_aircraft": status_bad},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("fbd::k_step_air<0>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
@@ -215,7 +232,10 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
-        if not args.no_cpu_baseline and world == 1:
+        if x2:
+            line["roofline"]["kernel"] = "fbd::k_step<true, 0, false> + k_x2_ctl per control period"
+            line["roofline"]["note"] = "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d); kernel_ms = one control period: the 2-step stepping launch, its ground pass and the control-law kernel"
+        if not args.no_cpu_baseline and world == 1 and not x2:
             line["cpu_baseline"] = cpu_baseline(x0, u0, ui0, s0)
         print(json.dumps(line), flush=True)
     if world > 1:
