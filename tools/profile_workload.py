@@ -10,7 +10,8 @@ import flightbatch as fb
 from bench import lattice, N_PER_GPU, DT
 inner = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-w = fb.BatchedWorld(N_PER_GPU)
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f64"
+w = fb.BatchedWorld(N_PER_GPU, dtype=dtype)
 EAS, h, psi = lattice(0)
 fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
 xd = np.zeros((27, N_PER_GPU)); fb.f_ode(w, xd)          # calibration launch (k_f_ode with xdot)
