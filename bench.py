@@ -104,6 +104,28 @@ def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
             "single_core_value": m1 * 100 / el1}
 
 
+def parity_sample(fb, x0, u0, ui0, s0, dtype, m=256, nsteps=1000):
+    """The second half of BASELINE.json's metric ("fp64 rel-err vs CPU"): the first m aircraft of the benchmark batch stepped
+    nsteps times on the GPU and by the CPU oracle from the same initial condition; max over aircraft and states of
+    |x_gpu - x_cpu| / max(|x_cpu|, floor) with the floors of SURVEY.md §8(d) (quaternions 1, rates 1e-3 rad/s, ...)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle
+    orc = Oracle()
+    sel = slice(0, m)
+    xs, us, uis, ss = (np.ascontiguousarray(x0[:, sel]), np.ascontiguousarray(u0[:, sel]), np.ascontiguousarray(ui0[sel]), np.ascontiguousarray(s0[:, sel]))
+    w = fb.BatchedWorld(m, dtype=dtype)
+    w.set_state(xs, ss); w.u = us; w.ui = uis
+    sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=50)
+    fb.step(sim, nsteps * DT); w.sync()
+    xo, so, sto = orc.step(xs, us, uis, ss, orc.default_env(), DT, nsteps)
+    ok = (sto == 0) & (w.status == 0)
+    sc = np.maximum(np.abs(xo), 1e-3)
+    sc[12:20] = 1.0; sc[2:8] = 1.0; sc[10:12] = 1.0; sc[0:2] = np.maximum(np.abs(xo[0:2]), 1e-2); sc[24:27] = np.maximum(np.abs(xo[24:27]), 1.0)
+    err = float((np.abs(w.x - xo) / sc)[:, ok].max())
+    w.close()
+    return {"max_scaled_error": err, "sample": f"{int(ok.sum())} aircraft x {nsteps} RK4 steps vs the CPU oracle (fp64)", "tolerance": 1e-6 if dtype == "f64" else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +259,7 @@ def main():
             line["roofline"]["note"] = "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d); kernel_ms = one control period: the 2-step stepping launch, its ground pass and the control-law kernel"
         if not args.no_cpu_baseline and world == 1 and not x2:
             line["cpu_baseline"] = cpu_baseline(x0, u0, ui0, s0)
+            line["rel_err_vs_cpu"] = parity_sample(fb, x0, u0, ui0, s0, args.dtype)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
