@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""The reference's scripted crosswind landing (lib/FlightApps/demos/c172_demos.jl:406-497) for a BATCH of Cessna172Xv2:
+every aircraft flies the final leg to runway 15 of LOWS under segment guidance in a 6 m/s crosswind, flares 6 m above the
+runway (climb-rate hold at -0.3 m/s, crab turned into a sideslip), closes the throttle at touchdown and brakes to a stop.
+The phase logic is the demo's user callback, vectorised over the batch; the aircraft differ in their starting distance and
+approach speed. `python examples/crosswind_landing.py [n]` prints a summary; tests/test_gpu_scenarios.py asserts on it."""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flight.jl_amd"))
+import flightbatch as fb  # noqa: E402
+from flightbatch.guidance import Segment  # noqa: E402
+
+LOC = (np.deg2rad(47.80433), np.deg2rad(12.997)); H_ORTH = 427.2; PSI = np.deg2rad(157.0)   # c172_demos.jl:17-19
+
+
+def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False):
+    K = fb.K
+    rng = np.random.default_rng(seed)
+    w = fb.Cessna172Xv2World(n)
+    w.set_params(h_terrain=H_ORTH, wind_ned=(0.0, 6.0, 0.0))          # HorizontalTerrain(h_LOWS15); atmosphere.wind.u.E = 6
+    # ellipsoidal altitude of the runway: orthometric + geoid height at the threshold (asked from the device model itself)
+    probe = fb.TrimParameters(n_e=np.array([np.cos(LOC[0]) * np.cos(LOC[1]), np.cos(LOC[0]) * np.sin(LOC[1]), np.sin(LOC[0])]), h_e=1000.0)
+    sim = fb.Simulation(w, dt=dt, Δt=dt, save_on=False, steps_per_launch=1)
+    fb.init(sim, probe)
+    fb.f_ode(w)
+    y = w.y
+    geoid = float((y[K["FB_Y_KIN"] + 20] - y[K["FB_Y_KIN"] + 21])[0])
+    p_rwy = np.array([LOC[0], LOC[1], H_ORTH + geoid])
+    # final leg: from s metres out on the extended centreline, 3 degrees above the threshold, down to the threshold
+    s0 = rng.uniform(2500.0, 3500.0, n)
+    far = np.stack([Segment.from_origin(p_rwy, s0[i], PSI + np.pi, γ=np.deg2rad(3)).p2 for i in range(n)], axis=1)
+    p2 = np.repeat(p_rwy[:, None], n, axis=1)
+    EAS = rng.uniform(29.0, 32.0, n)
+    n_e = np.array([np.cos(far[0]) * np.cos(far[1]), np.cos(far[0]) * np.sin(far[1]), np.sin(far[0])])
+    fb.init(sim, fb.TrimParameters(n_e=n_e, h_e=far[2], EAS=EAS, ψ_nb=PSI, γ_wb_n=-np.deg2rad(3), flaps=1.0, fuel_load=0.5))
+    assert w.trim_success.all(), "approach trim failed"
+    phase = np.zeros(n, dtype=int)          # 0 init, 1 final, 2 flare, 3 ground
+    touchdown = np.full((3, n), np.nan)     # time, along-track distance past the threshold, cross-track error
+
+    def callback(mdl):
+        fb.f_ode(mdl)
+        yy = mdl.y
+        h_e, psi = yy[K["FB_Y_KIN"] + 20], yy[0]
+        on_gnd = (yy[K["FB_Y_LDG"] + 1] + yy[K["FB_Y_LDG"] + 12] + yy[K["FB_Y_LDG"] + 23]) > 0
+        cu, u, cs = mdl.cu, mdl.u, mdl.cs
+        init = phase == 0
+        if init.any():
+            cu[K["FB_CU_GDC_MODE_REQ"], init] = fb.ModeGuidance.segment
+            cu[K["FB_CU_SEG_P1"]:K["FB_CU_SEG_P1"] + 3, init] = far[:, init]; cu[K["FB_CU_SEG_P2"]:K["FB_CU_SEG_P2"] + 3, init] = p2[:, init]
+            cu[K["FB_CU_SEG_HOR_REQ"], init] = 1; cu[K["FB_CU_SEG_VRT_REQ"], init] = 1
+            cu[K["FB_CU_EAS_REF"], init] = EAS[init]
+            u[K["FB_U_FLAPS"], init] = 1.0
+            phase[init] = 1
+        flare = (phase == 1) & (h_e - p_rwy[2] < 6) & ~init
+        if flare.any():
+            chi_12 = cs[K["FB_CS_SEG_CHI_REF"]] - cs[K["FB_CS_SEG_DCHI"]]
+            cu[K["FB_CU_SEG_VRT_REQ"], flare] = 0
+            cu[K["FB_CU_LON_MODE_REQ"], flare] = fb.ModeControlLon.EAS_clm; cu[K["FB_CU_CLM_REF"], flare] = -0.3
+            cu[K["FB_CU_LAT_MODE_REQ"], flare] = fb.ModeControlLat.φ_β
+            d = psi - chi_12
+            cu[K["FB_CU_BETA_REF"], flare] = (d + 2 * np.pi * np.floor((np.pi - d) / (2 * np.pi)))[flare]     # wrap_to_π
+            cu[K["FB_CU_PHI_REF"], flare] = 0.0
+            # the demo leaves hor_gdc_req set, so its guidance re-requests χ_β on the following update; the request is dropped
+            # here so that the bank + sideslip mode of the flare (the de-crab) stays in force until touchdown
+            cu[K["FB_CU_SEG_HOR_REQ"], flare] = 0
+            phase[flare] = 2
+        touch = (phase == 2) & on_gnd
+        if touch.any():
+            cu[K["FB_CU_THROTTLE_AXIS"], touch] = 0.0; cu[K["FB_CU_RUDDER_AXIS"], touch] = -0.04
+            u[K["FB_U_FLAPS"], touch] = 0.0
+            touchdown[0, touch] = mdl.t
+            touchdown[1, touch] = cs[K["FB_CS_SEG_S_1B"], touch] - s0[touch]
+            touchdown[2, touch] = cs[K["FB_CS_SEG_E_SB"], touch]
+            phase[touch] = 3
+        gnd = phase == 3
+        if gnd.any():
+            cu[K["FB_CU_THROTTLE_AXIS"], gnd] = 0.0
+            u[K["FB_U_BRAKE_LEFT"], gnd] = 1.0; u[K["FB_U_BRAKE_RIGHT"], gnd] = 1.0
+        mdl.cu = cu; mdl.u = u
+
+    sim = fb.Simulation(w, dt=dt, Δt=dt, save_on=False, user_callback=callback)
+    sim._nstep = 0
+    fb.step(sim, t_end); w.sync()
+    fb.f_ode(w)
+    y = w.y
+    out = dict(phase=phase.copy(), status=w.status, v_gnd=y[K["FB_Y_KIN"] + 37], touchdown=touchdown, h_agl=y[K["FB_Y_KIN"] + 21] - H_ORTH,
+               e_sb=w.cs[K["FB_CS_SEG_E_SB"]])
+    if verbose:
+        print(f"n = {n}: phases {np.bincount(phase, minlength=4)}, terminated {int((w.status != 0).sum())}, touchdown at "
+              f"{np.nanmin(touchdown[0]):.1f}-{np.nanmax(touchdown[0]):.1f} s, {np.nanmin(touchdown[1]):.0f}..{np.nanmax(touchdown[1]):.0f} m past the threshold, "
+              f"cross-track {np.nanmax(np.abs(touchdown[2])):.2f} m max, final ground speed {out['v_gnd'].max():.2f} m/s")
+    w.close()
+    return out
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 64, verbose=True)

@@ -1,0 +1,24 @@
+"""End-to-end scripted scenario on the GPU: the reference's crosswind-landing demo (lib/FlightApps/demos/c172_demos.jl:406-497)
+for a batch — trim on final, segment guidance, flare, touchdown, braking — through everything the path contains: Cessna172Xv2
+actuators, control laws, guidance, landing gear ground contact, the air / ground kernel hand-over, wind, user callback."""
+import os
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_crosswind_landing_batch(fb):
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import crosswind_landing as demo
+    out = demo.run(n=32, t_end=150.0, seed=3)
+    td = out["touchdown"]
+    print("touchdown: %.1f-%.1f s, %.0f..%.0f m past the threshold, |cross-track| <= %.2f m; final ground speed <= %.3f m/s"
+          % (td[0].min(), td[0].max(), td[1].min(), td[1].max(), np.abs(td[2]).max(), out["v_gnd"].max()))
+    assert (out["status"] == 0).all(), "an aircraft crashed or left the envelope"
+    assert (out["phase"] == 3).all(), "every aircraft must reach the ground roll"
+    assert np.isfinite(td).all() and (td[1] > -50).all() and (td[1] < 300).all()       # on the runway, near the aiming point
+    assert np.abs(td[2]).max() < 3.0                                                    # on the centreline in a 6 m/s crosswind
+    assert out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2         # stopped, sitting on its wheels
