@@ -279,7 +279,7 @@ FBD void gdc_update(const CtlMem& M, const CtlIn& v) {
         const bool vrt = fabs(e_sb) < e_thr ? (M.U(FB_CU_SEG_VRT_REQ) != 0) : false;
         M.S(FB_CS_SEG_DCHI) = dchi; M.S(FB_CS_SEG_CHI_REF) = chi_ref; M.S(FB_CS_SEG_H_REF) = h_s;
         M.S(FB_CS_SEG_HOR_GDC) = hor ? 1.0 : 0.0; M.S(FB_CS_SEG_VRT_GDC) = vrt ? 1.0 : 0.0;
-        M.S(FB_CS_SEG_E_SB) = e_sb; M.S(FB_CS_SEG_S_1B) = s_1b;
+        M.S(FB_CS_SEG_E_SB) = e_sb; M.S(FB_CS_SEG_S_1B) = s_1b; M.S(FB_CS_SEG_S_2B) = s_1b - s_12;
         if (hor) { M.U(FB_CU_CHI_REF) = chi_ref; M.U(FB_CU_LAT_MODE_REQ) = FB_LAT_CHI_BETA; }
         if (vrt) { M.U(FB_CU_H_REF) = h_s; M.U(FB_CU_LON_MODE_REQ) = FB_LON_EAS_ALT; }
     }

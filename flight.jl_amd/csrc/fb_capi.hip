@@ -422,9 +422,18 @@ int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui) {
 }
 
 int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit) {
-    if (!h || !init) return fail("null argument");
+    if (!h || (!init && ninit != 0)) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) return r2_f_init(h, init, ninit);
+    if (is_x2(h) && ninit == 0) {   // f_init!(avionics, vehicle) on the state the host has set
+        if (int32_t rc = check_ready_x2(h)) return rc;
+        fsal_invalidate(h);
+        hipLaunchKernelGGL(k_x2_init, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        HIPCHK(hipGetLastError());
+        h->steps_done = 0;
+        h->t = 0.0;
+        return 0;
+    }
     return fail("fb_f_init: Cessna172Sv0 initialises through fb_trim (TrimParameters) or fb_set_state");
 }
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost) {

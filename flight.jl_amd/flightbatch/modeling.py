@@ -241,6 +241,10 @@ class BatchedWorld:
 # ---- the verbs (all return None) ---------------------------------------------------------------------
 def f_init(world: BatchedWorld, init, trim_state: np.ndarray | None = None) -> None:
     """f_init!(world, trim_params): FP/world.jl:49-57 -> FA/c172/c172.jl:883-942."""
+    if init is None:   # Cessna172Xv2: the avionics half of f_init!(aircraft, C172.Init(...)) on the state already set by the host
+        check(lib.fb_f_init(world._h, None, 0))
+        world.t = 0.0
+        return None
     if hasattr(init, "pack") and not isinstance(init, TrimParameters):   # plain per-instance initializer (Robot2D.InitParameters)
         ip = init.pack(world.n)
         check(lib.fb_f_init(world._h, _pd(ip), ip.shape[0]))

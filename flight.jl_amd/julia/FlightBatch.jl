@@ -42,7 +42,7 @@ check(rc::Integer) = rc == 0 || error(unsafe_string(ccall((:fb_last_error, lib),
 const MODEL_C172S0, MODEL_C172X2, MODEL_ROBOT2D = Cint(0), Cint(1), Cint(2)
 const KIN = Dict(WA => Cint(0), ECEF => Cint(1), NED => Cint(2))        # FB_KIN_*: the vehicle's kinematic descriptor
 const TABLE_CTL_GAINS = Cint(5)
-const NCU, NCS = 28, 65                                                 # FB_NCU, FB_NCS (Cessna172Xv2 control laws)
+const NCU, NCS = 28, 66                                                 # FB_NCU, FB_NCS (Cessna172Xv2 control laws)
 
 "N instances of SimpleWorld(aircraft) resident on one GPU (the batched counterpart of a root Model).
 `aircraft` is `Cessna172Sv0(kin)` (kin = WA(), ECEF() or NED()) or `Cessna172Xv2()`; its type picks the model id."

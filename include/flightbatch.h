@@ -147,8 +147,8 @@ enum {
     FB_CS_P2PHI_INT = 49, FB_CS_P2PHI_PID = 51, FB_CS_CHI2PHI_PID = 54,
     /* guidance outputs (gdc.y.mode, gdc.seg.y: c172x_gdc.jl:212-220, 285-289) */
     FB_CS_GDC_MODE = 57, FB_CS_SEG_DCHI = 58, FB_CS_SEG_CHI_REF = 59, FB_CS_SEG_H_REF = 60, FB_CS_SEG_HOR_GDC = 61,
-    FB_CS_SEG_VRT_GDC = 62, FB_CS_SEG_E_SB = 63, FB_CS_SEG_S_1B = 64,
-    FB_NCS = 65
+    FB_CS_SEG_VRT_GDC = 62, FB_CS_SEG_E_SB = 63, FB_CS_SEG_S_1B = 64, FB_CS_SEG_S_2B = 65,
+    FB_NCS = 66
 };
 /* FB_TABLE_CTL_GAINS blob: ten lookups in the order te2te, tv2te, vh2te (LQR, NX = 8, 8, 9), q2e, c2theta, v2t (PID),
  * ar2ar, phibeta2ar (LQR, NX = 8), p2phi, chi2phi (PID)  [files FA/c172/c172x/control/data/{te2te,tv2te,vh2te,q2e,c2θ,v2t,
@@ -235,7 +235,10 @@ int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui);
 int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int32_t* success, double* cost);
 
 /* f_init!(mdl, init) with a plain per-instance initializer: Robot2D InitParameters [N x 3] = (u_m, w, eta),
- * FA/robot2d/robot2d.jl:208-228,563-570. (C172 initialises through fb_trim or fb_set_state.) */
+ * FA/robot2d/robot2d.jl:208-228,563-570. (C172 initialises through fb_trim or fb_set_state.)
+ * Cessna172Xv2 with init = NULL, ninit = 0: the avionics half of f_init!(aircraft, C172.Init(...)) (aircraftbase.jl:255-265) on the
+ * state already set with fb_set_state / fb_set_inputs — actuator states = the commands in u (c172x.jl:253-271), brakes released,
+ * then f_init!(avionics, vehicle). */
 int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit);
 
 /* f_ode!(world) : FP/world.jl:26-32. Uses current x, u, s; writes xdot [N x FB_NX] (may be NULL)

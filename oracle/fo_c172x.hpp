@@ -312,7 +312,7 @@ inline void gdc_periodic(const CtlIn& v, double* cu, double* cs) {
         const bool hor = cu[FB_CU_SEG_HOR_REQ] != 0;
         const bool vrt = std::fabs(d.e_sb) < e_thr ? (cu[FB_CU_SEG_VRT_REQ] != 0) : false;
         cs[FB_CS_SEG_DCHI] = dchi; cs[FB_CS_SEG_CHI_REF] = chi_ref; cs[FB_CS_SEG_H_REF] = d.h_s;
-        cs[FB_CS_SEG_HOR_GDC] = hor; cs[FB_CS_SEG_VRT_GDC] = vrt; cs[FB_CS_SEG_E_SB] = d.e_sb; cs[FB_CS_SEG_S_1B] = d.s_1b;
+        cs[FB_CS_SEG_HOR_GDC] = hor; cs[FB_CS_SEG_VRT_GDC] = vrt; cs[FB_CS_SEG_E_SB] = d.e_sb; cs[FB_CS_SEG_S_1B] = d.s_1b; cs[FB_CS_SEG_S_2B] = d.s_2b;
         if (hor) { cu[FB_CU_CHI_REF] = chi_ref; cu[FB_CU_LAT_MODE_REQ] = FB_LAT_CHI_BETA; }
         if (vrt) { cu[FB_CU_H_REF] = d.h_s; cu[FB_CU_LON_MODE_REQ] = FB_LON_EAS_ALT; }
     }

@@ -22,3 +22,19 @@ def test_crosswind_landing_batch(fb):
     assert np.isfinite(td).all() and (td[1] > -50).all() and (td[1] < 300).all()       # on the runway, near the aiming point
     assert np.abs(td[2]).max() < 3.0                                                    # on the centreline in a 6 m/s crosswind
     assert out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2         # stopped, sitting on its wheels
+
+
+def test_traffic_pattern_batch(fb):
+    """c172_demos.jl:502-645: cold start on the runway, engine start, takeoff, four guided legs, final, flare, landing, full stop."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import traffic_pattern as demo
+    out = demo.run(n=16, t_end=420.0, seed=1)
+    e = out["entered"]
+    assert (out["status"] == 0).all(), "an aircraft crashed or left the envelope"
+    assert (out["phase"] == demo.GROUND).all(), "every aircraft must complete the pattern"
+    assert np.isfinite(e[1:]).all() and (np.diff(e[1:], axis=0) > 0).all()            # every phase visited, in order
+    assert (e[demo.TAKEOFF] - e[demo.STARTUP] < 3).all()                              # the starter brings the engine up within seconds
+    assert (e[demo.DEPARTURE] - e[demo.TAKEOFF] < 30).all()                           # airborne after a ground roll at full throttle
+    td = out["touchdown"]
+    assert (td[0] > -100).all() and (td[0] < 400).all() and np.abs(td[1]).max() < 5   # touchdown near the runway point, on the centreline
+    assert out["v_gnd"].max() < 0.5                                                   # braked to a stop
