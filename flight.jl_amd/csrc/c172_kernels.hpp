@@ -425,7 +425,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     for (int k = 0; k < FB_NX; k++) {
         const double v = a.x[(int64_t)k * a.n + i];
         if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) to_ground = to_ground || (v != 0.0);
-        else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; }
+        else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
     }
     if (to_ground) { a.redo[i] = 1; return; }
     Inputs in;
@@ -433,63 +433,86 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     in.u_glob = nullptr;   // ground-only inputs are never read here
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a
+    // scalar branch (2 SALU instructions) and not an exec-mask dance (14 scalar instructions per emitted row when the stage
+    // was per-lane). The price: when f_step! modifies a lane's state (renormalisation, stall flag, engine state) and k1 has to
+    // be re-evaluated for it, the other lanes of its wave sit out that one evaluation (`run` false) instead of moving on.
     int stage = 0, step = 0;
-    bool pending_cb = false, dead = false;
+    bool pending_cb = false, redoing = false;      // uniform
+    bool alive = true, dead = false, run = true, handoff = false;   // per lane
 #pragma unroll 1
     while (true) {
         StepAux aux;
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));   // see k_step: keeps loop-invariant LDS loads inside the loop
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
-        Inputs inl = in;                    // and keeps products of the per-lane inputs from being hoisted out of it
-        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
-        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
-        const double cdt = (stage == 2) ? dt : hdt;
-        auto emit = [&](int j, double kj) {
-            if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
-            const int idx = SV::row(j) * B + t;
-            const double xs = xs_l[idx];
-            if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = xs + cdt * kj; }
-            else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = xs + cdt * kj; }
-            else { const double v = xs + dt6 * (acc_l[idx] + kj); xs_l[idx] = v; xc_l[idx] = v; }
-        };
-        const SV xv = {(lds_cptr)xc_l + t + lds_off};
-        int32_t bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-        if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
-        if (stage == 0 && pending_cb) {
+        const bool last = stage == 3;
+        const double eb = (stage == 1 || stage == 2) ? 2.0 : 1.0, ee = last ? dt6 : (stage == 2 ? dt : hdt), em = last ? 0.0 : 1.0;
+        const lds_ptr xsel_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
+        int32_t bits = 0;
+        if (run) {
+            Inputs inl = in;                // and keeps products of the per-lane inputs from being hoisted out of it
+            asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
+            asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+            // One branch-free body for all four stages (the stage only enters through wave-uniform operands):
+            //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 when stage 0 starts (zeroed below and by every stage 3)
+            //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_eval <- x_n + dt/6 A
+            // Bit-identical to the branched form: acc + 1 k = k exactly at stage 0, A 1 = A, and the fma's are the same ones.
+            auto emit = [&](int j, double kj) {
+                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+                const int idx = SV::row(j) * B + t;
+                const double xs = xs_l[idx];
+                const double A = __builtin_fma(eb, kj, acc_l[idx]);
+                const double v = __builtin_fma(ee, last ? A : kj, xs);
+                acc_l[idx] = A * em;
+                xc_l[idx] = v;
+                xsel_l[idx] = v;   // stage 3: x_n; otherwise the evaluation panel once more
+            };
+            const SV xv = {(lds_cptr)xc_l + t + lds_off};
+            bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
+        }
+        if (redoing) { redoing = false; run = alive; }   // the lanes that sat out the re-evaluation of k1 join again
+        else if (stage == 0 && pending_cb) {
             // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
             pending_cb = false;
             step++;
             bool mod = false;
-            auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
-                double q[4] = {0, 0, 0, 0}, n2 = 0;
+            if (run) {
+                auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
+                    double q[4] = {0, 0, 0, 0}, n2 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (k < len) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
-                const double nr = sqrt(n2);
-                if (fabs(nr - 1.0) > 1e-8) {
+                    for (int k = 0; k < 4; k++) if (k < len) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
+                    const double nr = ::sqrt(n2);
+                    if (fabs(nr - 1.0) > 1e-8) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (k < len) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
-                    mod = true;
+                        for (int k = 0; k < 4; k++) if (k < len) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
+                        mod = true;
+                    }
+                };
+                if constexpr (KIN == FB_KIN_WA) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4); }
+                else if constexpr (KIN == FB_KIN_ECEF) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_WB + 4, 3); }
+                const int stall0 = stall, eng0 = eng;
+                if (aux.alpha > c172::alpha_stall_hi) stall = 1;
+                else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
+                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
+                const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
+                const bool fuel = aux.m_avail > 0;
+                const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
+                if (eng == 0) { if (start) eng = 1; }
+                else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
+                else if (stop || w < c172::w_stall || !fuel) eng = 0;
+                mod = mod || stall != stall0 || eng != eng0;
+                if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
+                if (dead) { alive = false; run = false; mod = false; }
+            }
+            if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
+            if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+                if (mod) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) { xc_l[r * B + t] = xs_l[r * B + t]; acc_l[r * B + t] = 0.0; }   // (acc held the discarded k1)
                 }
-            };
-            if constexpr (KIN == FB_KIN_WA) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4); }
-            else if constexpr (KIN == FB_KIN_ECEF) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_WB + 4, 3); }
-            const int stall0 = stall, eng0 = eng;
-            if (aux.alpha > c172::alpha_stall_hi) stall = 1;
-            else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
-            if (aux.crash) bits |= FB_ST_GROUND_CRASH;
-            const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
-            const bool fuel = aux.m_avail > 0;
-            const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
-            if (eng == 0) { if (start) eng = 1; }
-            else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
-            else if (stop || w < c172::w_stall || !fuel) eng = 0;
-            mod = mod || stall != stall0 || eng != eng0;
-            if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
-            if (dead || step == nsteps) break;
-            if (mod) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
-#pragma unroll
-                for (int r = 0; r < NR; r++) xc_l[r * B + t] = xs_l[r * B + t];
+                run = mod; redoing = true;
                 continue;
             }
         }
@@ -497,6 +520,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
+    if (handoff) { a.redo[i] = 1; return; }
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
