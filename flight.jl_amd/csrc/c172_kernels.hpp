@@ -428,9 +428,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
     }
     if (to_ground) { a.redo[i] = 1; return; }
-    Inputs in;
+    InputsAgg in;
     load_inputs(a, i, in);
     in.u_glob = nullptr;   // ground-only inputs are never read here
+    in.sum_payload();
+    in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a
@@ -451,9 +453,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         const lds_ptr xsel_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
         if (run) {
-            Inputs inl = in;                // and keeps products of the per-lane inputs from being hoisted out of it
-            asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
-            asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
+            InputsAgg inl = in;             // and keeps products of the per-lane inputs from being hoisted out of it
+            asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             // One branch-free body for all four stages (the stage only enters through wave-uniform operands):
             //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 when stage 0 starts (zeroed below and by every stage 3)
             //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_eval <- x_n + dt/6 A
