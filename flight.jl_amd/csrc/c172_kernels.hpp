@@ -549,7 +549,8 @@ __device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const 
     const double h_o = p.h_e - geoid_height(T, p.n_e);
     double T_air, p_air;
     int32_t st = 0;
-    isa_data(h_o * wgs::a / (wgs::a + h_o), env.T_sl, env.p_sl, T_air, p_air, st);
+    double lnp_air;
+    isa_data(h_o * wgs::a / (wgs::a + h_o), env.T_sl, env.p_sl, T_air, p_air, lnp_air, st);
     const double rho = p_air / (isa::R * T_air);
     const double TAS = p.EAS * sqrt(isa::rho_std / rho);
     const double cb = cos(p.beta_a);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
         in.ui = in_r.ui; in.u_glob = nullptr; in.n = 0;
     }
     int stall = a.s[i], eng = a.s[a.n + i];
-    const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface};
+    const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface, (float)a.env.ln_p_sl};
     const float dt = (float)a.dt, hdt = (float)(a.dt / 2), dt6 = (float)(a.dt / 6);
     const double dtd = a.dt, hdtd = a.dt / 2, dt6d = a.dt / 6;
     int stage = 0, step = 0;
