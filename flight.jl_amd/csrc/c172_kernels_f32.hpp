@@ -59,11 +59,12 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
         if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) { to_ground = to_ground || (v != 0.0); continue; }
         const int r = SV::row(k);
         xc_l[r * B + t] = (float)v;
+        acc_l[r * B + t] = 0.0f;
         if (k >= XP0 && k < XP0 + XPN) xp_l[(k - XP0) * B + t] = v;
         else xs_l[xsrow(r) * B + t] = (float)v;
     }
     if (to_ground) { a.redo[i] = 1; return; }
-    Inputs in;
+    InputsAgg in;
     {
         fbd::Inputs in_r;
         fbd::load_inputs(a, i, in_r);
@@ -72,86 +73,104 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
 #pragma unroll
         for (int k = 0; k < 5; k++) in.m_pld[k] = (float)in_r.m_pld[k];
         in.ui = in_r.ui; in.u_glob = nullptr; in.n = 0;
+        in.sum_payload();
+        in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
     int stall = a.s[i], eng = a.s[a.n + i];
     const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface, (float)a.env.ln_p_sl};
     const float dt = (float)a.dt, hdt = (float)(a.dt / 2), dt6 = (float)(a.dt / 6);
     const double dtd = a.dt, hdtd = a.dt / 2, dt6d = a.dt / 6;
+    // wave-uniform stage machine and branch-free emit, as in fbd::k_step_air (see there)
     int stage = 0, step = 0;
-    bool pending_cb = false, dead = false;
+    bool pending_cb = false, redoing = false;
+    bool alive = true, dead = false, run = true, handoff = false;
 #pragma unroll 1
     while (true) {
         StepAux aux;
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step)
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables_f32 + lds_off};
-        Inputs inl = in;
-        asm volatile("" : "+v"(inl.de), "+v"(inl.da), "+v"(inl.dr), "+v"(inl.df), "+v"(inl.throttle), "+v"(inl.mixture));
-        asm volatile("" : "+v"(inl.m_pld[0]), "+v"(inl.m_pld[1]), "+v"(inl.m_pld[2]), "+v"(inl.m_pld[3]), "+v"(inl.m_pld[4]));
-        const float cdt = (stage == 2) ? dt : hdt;
-        const double cdtd = (stage == 2) ? dtd : hdtd;
-        auto emit = [&](int j, float kj) {
-            if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
-            const int r = SV::row(j), idx = r * B + t;
-            if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position states (j is a compile-time constant at every call)
-                const int ip = (j - XP0) * B + t;
-                const double xs = xp_l[ip];
-                if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = (float)(xs + cdtd * (double)kj); }
-                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = (float)(xs + cdtd * (double)kj); }
-                else { const double v = xs + dt6d * ((double)acc_l[idx] + (double)kj); xp_l[ip] = v; xc_l[idx] = (float)v; }
-            } else {
-                const int ix = xsrow(r) * B + t;
-                const float xs = xs_l[ix];
-                if (stage == 0) { acc_l[idx] = kj; xc_l[idx] = xs + cdt * kj; }
-                else if (stage < 3) { acc_l[idx] = acc_l[idx] + 2 * kj; xc_l[idx] = xs + cdt * kj; }
-                else { const float v = xs + dt6 * (acc_l[idx] + kj); xs_l[ix] = v; xc_l[idx] = v; }
-            }
-        };
-        const SV xv = {(lds_cptr)xc_l + t + lds_off};
-        int32_t bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
-        if (bits & FB_ST_INTERNAL_REDO) { a.redo[i] = 1; return; }   // within reach of the ground: the fp64 kernel takes this lane over
-        if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} = the x_n panels (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
+        const bool last = stage == 3;
+        const float eb = (stage == 1 || stage == 2) ? 2.0f : 1.0f, ee = last ? dt6 : (stage == 2 ? dt : hdt), em = last ? 0.0f : 1.0f;
+        const double eed = last ? dt6d : (stage == 2 ? dtd : hdtd);
+        int32_t bits = 0;
+        if (run) {
+            InputsAgg inl = in;
+            asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
+            auto emit = [&](int j, float kj) {
+                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+                const int r = SV::row(j), idx = r * B + t;
+                if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position states (j is a compile-time constant at every call)
+                    const int ip = (j - XP0) * B + t;
+                    const double A = (double)acc_l[idx] + (double)eb * (double)kj;
+                    const double v = xp_l[ip] + eed * (last ? A : (double)kj);
+                    acc_l[idx] = (float)A * em;
+                    xc_l[idx] = (float)v;
+                    if (last) xp_l[ip] = v;
+                } else {
+                    const int ix = xsrow(r) * B + t;
+                    const float A = __builtin_fmaf(eb, kj, acc_l[idx]);
+                    const float v = __builtin_fmaf(ee, last ? A : kj, xs_l[ix]);
+                    acc_l[idx] = A * em;
+                    xc_l[idx] = v;
+                    if (last) xs_l[ix] = v;
+                }
+            };
+            const SV xv = {(lds_cptr)xc_l + t + lds_off};
+            bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
+            if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // within reach of the ground: the fp64 kernel takes this lane over
+        }
+        if (redoing) { redoing = false; run = alive; }
+        else if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} = the x_n panels (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
             pending_cb = false;
             step++;
             bool mod = false;
-            {   // q_wb: renormalised every step, silently (fp32 drift); its copy in the evaluation panel has already moved on by
-                // this evaluation's emits (x + dt/2 k1): rescaling it by the same factor keeps the two consistent to O(ulp)
-                float q[4], n2 = 0;
+            if (run) {
+                {   // q_wb: renormalised every step, silently (fp32 drift); its copy in the evaluation panel has already moved on by
+                    // this evaluation's emits (x + dt/2 k1): rescaling it by the same factor keeps the two consistent to O(ulp)
+                    float q[4], n2 = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) { q[k] = xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t]; n2 += q[k] * q[k]; }
-                const float inr = rsqrtf(n2);
+                    for (int k = 0; k < 4; k++) { q[k] = xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t]; n2 += q[k] * q[k]; }
+                    const float inr = rsqrtf(n2);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t] = q[k] * inr;
-                    xc_l[SV::row(FB_X_Q_WB + k) * B + t] *= inr;
+                    for (int k = 0; k < 4; k++) {
+                        xs_l[xsrow(SV::row(FB_X_Q_WB + k)) * B + t] = q[k] * inr;
+                        xc_l[SV::row(FB_X_Q_WB + k) * B + t] *= inr;
+                    }
+                    double n2d = 0;   // q_ew: the reference's rule, on the fp64 values
+#pragma unroll
+                    for (int k = 0; k < 4; k++) n2d += xp_l[k * B + t] * xp_l[k * B + t];
+                    const double nr = ::sqrt(n2d);
+                    if (fabs(nr - 1.0) > 1e-8) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) xp_l[k * B + t] = xp_l[k * B + t] / nr;
+                        mod = true;
+                    }
                 }
-                double n2d = 0;   // q_ew: the reference's rule, on the fp64 values
-#pragma unroll
-                for (int k = 0; k < 4; k++) n2d += xp_l[k * B + t] * xp_l[k * B + t];
-                const double nr = sqrt(n2d);
-                if (fabs(nr - 1.0) > 1e-8) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) xp_l[k * B + t] = xp_l[k * B + t] / nr;
-                    mod = true;
-                }
+                const int stall0 = stall, eng0 = eng;
+                if (aux.alpha > c172::alpha_stall_hi) stall = 1;
+                else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
+                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
+                const float w = xs_l[xsrow(SV::row(FB_X_ENG_OMEGA)) * B + t];
+                const bool fuel = aux.m_avail > 0;
+                const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
+                if (eng == 0) { if (start) eng = 1; }
+                else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
+                else if (stop || w < c172::w_stall || !fuel) eng = 0;
+                mod = mod || stall != stall0 || eng != eng0;
+                if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
+                if (dead) { alive = false; run = false; mod = false; }
             }
-            const int stall0 = stall, eng0 = eng;
-            if (aux.alpha > c172::alpha_stall_hi) stall = 1;
-            else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
-            if (aux.crash) bits |= FB_ST_GROUND_CRASH;
-            const float w = xs_l[xsrow(SV::row(FB_X_ENG_OMEGA)) * B + t];
-            const bool fuel = aux.m_avail > 0;
-            const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
-            if (eng == 0) { if (start) eng = 1; }
-            else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
-            else if (stop || w < c172::w_stall || !fuel) eng = 0;
-            mod = mod || stall != stall0 || eng != eng0;
-            if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
-            if (dead || step == nsteps) break;
-            if (mod) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+            if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
+            if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+                if (mod) {
 #pragma unroll
-                for (int r = 0; r < NRF; r++)
-                    xc_l[r * B + t] = (r >= RP0 && r < RP0 + XPN) ? (float)xp_l[(r - RP0) * B + t] : xs_l[xsrow(r) * B + t];
+                    for (int r = 0; r < NRF; r++) {
+                        xc_l[r * B + t] = (r >= RP0 && r < RP0 + XPN) ? (float)xp_l[(r - RP0) * B + t] : xs_l[xsrow(r) * B + t];
+                        acc_l[r * B + t] = 0.0f;   // (it held the discarded k1)
+                    }
+                }
+                run = mod; redoing = true;
                 continue;
             }
         }
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
+    if (handoff) { a.redo[i] = 1; return; }
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
