@@ -247,7 +247,7 @@ def main():
                        "aircraft_per_gpu": n, "rk4_steps_per_launch": (2 if x2 else args.inner), "rk4_steps_per_contract_step": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
                        "trim_success_fraction": trim_ok, "terminated_aircraft": status_bad},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("fbd::k_step_air<0>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": ("fbd::k_step_air<0, false>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "
                                  "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,

@@ -406,10 +406,15 @@ struct StateLds {
     __device__ __forceinline__ static constexpr int row(int k) { return k < FB_X_LDG_FRC ? k : k - 6; }
     __device__ __forceinline__ double operator[](int k) const { return (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : p[row(k) * STRIDE]; }
 };
-template <int KIN>
+// X = Cessna172X: the seven first-order actuators (ẋ = (cmd - x)/τ, commands constant during a launch) are linear, so classic
+// RK4 on them has a closed form — stage values cmd + (x_n - cmd) m_s with m = 1, 1 - z/2, 1 - z/2 + z²/4, 1 - z + z²/2 - z³/4 and
+// x_{n+1} = cmd + (x_n - cmd)(1 - z + z²/2 - z³/6 + z⁴/24), z = dt/τ — equal to the stage-by-stage evaluation up to rounding.
+// They therefore need no panel rows at all (x_n and the commands ride in registers), and the Sv0 LDS budget holds for Xv2.
+template <int KIN, bool X = false>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     constexpr int B = STEP_BLOCK, NR = FB_NX - 6;
     using SV = StateLds<B>;
+    using InT = typename std::conditional<X, InputsXAgg, InputsAgg>::type;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
@@ -428,13 +433,22 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
     }
     if (to_ground) { a.redo[i] = 1; return; }
-    InputsAgg in;
-    load_inputs(a, i, in);
-    in.u_glob = nullptr;   // ground-only inputs are never read here
-    in.sum_payload();
-    in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
+    InT in;
+    double xa[X ? FB_NACT : 1], ca[X ? FB_NACT : 1];   // actuator positions x_n and commands
+    if constexpr (X) {
+#pragma unroll
+        for (int k = 0; k < FB_NACT; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+        in.xa = nullptr; in.u_glob = a.u + i; in.n = a.n; in.ui = a.ui[i];
+        sum_payload_of(in);
+    } else {
+        load_inputs(a, i, in);
+        in.u_glob = nullptr;   // ground-only inputs are never read here
+        in.sum_payload();
+        in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
+    }
     int stall = a.s[i], eng = a.s[a.n + i];
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    const double z = dt / ACT_TAU;
     // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a
     // scalar branch (2 SALU instructions) and not an exec-mask dance (14 scalar instructions per emitted row when the stage
     // was per-lane). The price: when f_step! modifies a lane's state (renormalisation, stall flag, engine state) and k1 has to
@@ -442,6 +456,23 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false;      // uniform
     bool alive = true, dead = false, run = true, handoff = false;   // per lane
+    if constexpr (X) {
+        // FSAL across launches (see k_step): the previous launch's last evaluation sat at this very state. A wave whose lanes all
+        // hold a valid k1 starts at stage 1; otherwise the lanes without one evaluate it first while the others sit out.
+        const bool have_k1 = a.k1 && a.k1_valid[i];
+        if (have_k1) {
+#pragma unroll
+            for (int j = 0; j < FB_NX; j++) {
+                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) continue;
+                const int idx = SV::row(j) * B + t;
+                const double kj = a.k1[(int64_t)j * a.n + i];
+                acc_l[idx] = kj;
+                xc_l[idx] = xs_l[idx] + hdt * kj;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(!have_k1) == 0) stage = 1;
+        else { run = !have_k1; redoing = true; }
+    }
 #pragma unroll 1
     while (true) {
         StepAux aux;
@@ -453,8 +484,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         const lds_ptr xsel_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
         if (run) {
-            InputsAgg inl = in;             // and keeps products of the per-lane inputs from being hoisted out of it
-            asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
+            InT inl = in;                   // and keeps products of the per-lane inputs from being hoisted out of it
+            double xa_s[X ? FB_NACT : 1];
+            if constexpr (X) {
+                const double ms = stage == 0 ? 1.0 : (stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+#pragma unroll
+                for (int k = 0; k < FB_NACT; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                inl.xa = xa_s;
+                inl.u_glob = in.u_glob + lds_off;
+            } else {
+                asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
+            }
             // One branch-free body for all four stages (the stage only enters through wave-uniform operands):
             //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 when stage 0 starts (zeroed below and by every stage 3)
             //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_eval <- x_n + dt/6 A
@@ -472,6 +512,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             const SV xv = {(lds_cptr)xc_l + t + lds_off};
             bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
+            if constexpr (X) {
+                if (last) {
+                    const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
+#pragma unroll
+                    for (int k = 0; k < FB_NACT; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * P;
+                }
+            }
         }
         if (redoing) { redoing = false; run = alive; }   // the lanes that sat out the re-evaluation of k1 join again
         else if (stage == 0 && pending_cb) {
@@ -480,6 +527,12 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             step++;
             bool mod = false;
             if (run) {
+                if constexpr (X) {
+                    if (step == nsteps && a.q_pre) {   // what the control laws will see: the attitude of THIS evaluation, before f_step!
+#pragma unroll
+                        for (int k = 0; k < 8; k++) a.q_pre[(int64_t)k * a.n + i] = xs_l[SV::row(FB_X_Q_WB + k) * B + t];
+                    }
+                }
                 auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
                     double q[4] = {0, 0, 0, 0}, n2 = 0;
 #pragma unroll
@@ -505,6 +558,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 else if (stop || w < c172::w_stall || !fuel) eng = 0;
                 mod = mod || stall != stall0 || eng != eng0;
                 if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
+                if constexpr (X) {
+                    if (a.k1 && (dead || step == nsteps)) {   // this evaluation's derivatives (acc = k at stage 0) are the next launch's k1 unless something changed
+                        const bool keep = !dead && !mod;
+                        if (keep) {
+#pragma unroll
+                            for (int j = 0; j < FB_NX; j++)
+                                a.k1[(int64_t)j * a.n + i] = (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) ? 0.0 : acc_l[SV::row(j) * B + t];
+                        }
+                        a.k1_valid[i] = keep ? 1 : 0;
+                    }
+                }
                 if (dead) { alive = false; run = false; mod = false; }
             }
             if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
@@ -529,6 +593,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         const double v = xs_l[SV::row(k) * B + t];
         bad = bad || !isfinite(v);
         a.x[(int64_t)k * a.n + i] = v;
+    }
+    if constexpr (X) {
+#pragma unroll
+        for (int k = 0; k < FB_NACT; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + i] = xa[k]; }
     }
     if (bad) a.status[i] |= FB_ST_NAN;
     a.s[i] = stall;
