@@ -133,7 +133,8 @@ FBD void stage_tables(double* lds, double* rk, const double* tables) {
     for (int k = threadIdx.x; k < PR_NJ * PR_NM * NC; k += blockDim.x) lds[LDS_PROP + k] = tables[LDS_PROP + (k / NC) * PR_NC + (k % NC)];
     __syncthreads();
     // reciprocal knot spacings for every position of the aero|piston blob (only knot positions are ever read)
-    for (int k = threadIdx.x; k < LDS_RK_DOUBLES; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
+    for (int k = threadIdx.x; k < LDS_RK_KNOTS; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
+    for (int k = threadIdx.x; k < ATAN_N; k += blockDim.x) rk[LDS_ATAN + k] = atan(k * (1.0 / 32));   // atan2_tab()'s table
     __syncthreads();
 }
 FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
     for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = a.tables_f32[k];
     for (int k = threadIdx.x; k < PR_NJ * PR_NM * PR_NC_STEP; k += blockDim.x)
         lds[LDS_PROP + k] = a.tables_f32[LDS_PROP + (k / PR_NC_STEP) * PR_NC + (k % PR_NC_STEP)];
-    for (int k = threadIdx.x; k < LDS_RK_DOUBLES; k += blockDim.x) rk[k] = (float)(1.0 / (a.tables[k + 1] - a.tables[k]));
+    for (int k = threadIdx.x; k < LDS_RK_KNOTS; k += blockDim.x) rk[k] = (float)(1.0 / (a.tables[k + 1] - a.tables[k]));
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
