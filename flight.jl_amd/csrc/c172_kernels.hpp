@@ -435,10 +435,15 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     }
     if (to_ground) { a.redo[i] = 1; return; }
     InT in;
-    double xa[X ? FB_NACT : 1], ca[X ? FB_NACT : 1];   // actuator positions x_n and commands
+    // actuator positions x_n and commands. Only the five the airborne RHS reads are tracked through the stages; the two brake
+    // actuators are advanced at the end, over the steps this lane completed, with the same closed form.
+    constexpr int NAL = FB_ACT_BRAKE_LEFT;
+    static_assert(FB_ACT_BRAKE_LEFT == 5 && FB_ACT_BRAKE_RIGHT == 6 && FB_NACT == 7, "brakes are the last two actuators");
+    double xa[X ? NAL : 1], ca[X ? NAL : 1];
+    int steps_alive = 0;
     if constexpr (X) {
 #pragma unroll
-        for (int k = 0; k < FB_NACT; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+        for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
         in.xa = nullptr; in.u_glob = a.u + i; in.n = a.n; in.ui = a.ui[i];
         sum_payload_of(in);
     } else {
@@ -490,7 +495,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             if constexpr (X) {
                 const double ms = stage == 0 ? 1.0 : (stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
 #pragma unroll
-                for (int k = 0; k < FB_NACT; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
                 inl.xa = xa_s;
                 inl.u_glob = in.u_glob + lds_off;
             } else {
@@ -517,7 +523,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 if (last) {
                     const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
 #pragma unroll
-                    for (int k = 0; k < FB_NACT; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * P;
+                    for (int k = 0; k < NAL; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * P;
+                    steps_alive++;
                 }
             }
         }
@@ -597,7 +604,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     }
     if constexpr (X) {
 #pragma unroll
-        for (int k = 0; k < FB_NACT; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + i] = xa[k]; }
+        for (int k = 0; k < NAL; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + i] = xa[k]; }
+        const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
+#pragma unroll
+        for (int k = NAL; k < FB_NACT; k++) {
+            const double c = x2_command(a, i, k), x0 = a.x[(int64_t)(X2_ACT + k) * a.n + i];
+            double v = x0;
+            for (int m = 0; m < steps_alive; m++) v = c + (v - c) * P;   // step by step: bit-identical to the per-step update
+            bad = bad || !isfinite(v);
+            a.x[(int64_t)(X2_ACT + k) * a.n + i] = v;
+        }
+
     }
     if (bad) a.status[i] |= FB_ST_NAN;
     a.s[i] = stall;
