@@ -17,7 +17,7 @@ import flightbatch as fb  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 block_s = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-DT, RATIO = 0.01, 2
+DT, RATIO = 0.01, int(os.environ.get("FB_X2_RATIO", "2"))   # (the config is RATIO = 2; other values only to separate per-launch from per-step cost)
 w = fb.Cessna172Xv2World(n)
 w.set_params(wind_ned=(1.0, 0.5, 0.0))
 sim = fb.Simulation(w, dt=DT, Δt=DT * RATIO, save_on=False, steps_per_launch=RATIO)
