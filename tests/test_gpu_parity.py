@@ -524,3 +524,39 @@ def test_takeoff_ground_to_air_handover(fb, oracle):
     print("take-off, max scaled error after 35 s: %.2e" % err.max())
     assert err.max() < 1e-3 and np.abs(w.x[20] - xo[20])[ok].max() < 1e-2
     w.close()
+
+
+@pytest.mark.parametrize("eps, tol", [(0.0, 2e-12), (1e-8, 2e-12), (1e-6, 2e-9)])
+def test_gravity_at_com_with_off_norm_states(fb, oracle, eps, tol):
+    """The kernels get the gravity vector at the centre of mass from a first-order expansion about the body origin instead of the
+    reference's ECEF->geodetic conversion and local-level quaternion, carrying the state quaternions' norm errors
+    (~1e-8 at RK stages) to first order: g_c and the accelerations must match the oracle to rounding at eps = 1e-8, and to
+    O(eps^2 g) at a norm error a hundred times larger than any that occurs."""
+    n = 16384
+    rng = np.random.default_rng(77)
+    x = np.zeros((27, n))
+    x[0] = rng.uniform(-0.1, 0.3, n); x[1] = rng.uniform(-0.1, 0.1, n)
+    x[8] = rng.uniform(0, 1, n)
+    x[9] = rng.uniform(150, 280, n)
+    q = rng.normal(size=(4, n)); q /= np.linalg.norm(q, axis=0); x[12:16] = q * (1 + rng.uniform(-eps, eps, n))
+    qe = rng.normal(size=(4, n)); qe /= np.linalg.norm(qe, axis=0); x[16:20] = qe * (1 + rng.uniform(-eps, eps, n))
+    x[20] = rng.uniform(100, 10000, n)
+    x[21:24] = rng.normal(0, 0.3, (3, n))
+    x[24:27] = rng.normal(0, 1, (3, n)); x[24:27] *= rng.uniform(20, 80, n) / np.linalg.norm(x[24:27], axis=0)
+    s = np.stack([np.zeros(n), np.full(n, 2)]).astype(np.int32)
+    u = np.zeros((16, n)); u[0] = 0.6; u[9] = 0.5; u[11:16] = rng.uniform(0, 100, (5, n))
+    ui = np.full(n, fb.K["FB_UI_MIXTURE_AUTO"], dtype=np.int32)
+    env = oracle.default_env(h_trn=-600.0)
+    w = fb.BatchedWorld(n)
+    w.set_params(h_terrain=-600.0)
+    w.set_state(x, s); w.u = u; w.ui = ui
+    xd = np.zeros((27, n)); fb.f_ode(w, xd)
+    xdo, yo, sto = oracle.f_ode(x, u, ui, s, env)
+    ok = (sto == 0) & (w.status == 0)
+    assert ok.mean() > 0.99
+    k = fb.K["FB_Y_DYN"] + 37
+    eg = np.abs(w.y[k:k + 3] - yo[k:k + 3])[:, ok].max()
+    ev = np.abs(xd[24:27] - xdo[24:27])[:, ok].max()
+    print("eps %.0e: |g_c - oracle| <= %.2e m/s^2, |vdot - oracle| <= %.2e" % (eps, eg, ev))
+    assert eg < tol and ev < 5 * tol
+    w.close()
