@@ -1,0 +1,21 @@
+import sys, os, time, numpy as np, ctypes as C
+sys.path.insert(0, "flight.jl_amd"); sys.path.insert(0, "tests")
+import flightbatch as fb
+n = 262144
+w = fb.BatchedWorld(n)
+fb.f_init(w, fb.TrimParameters(EAS=np.full(n, 45.0), h_e=np.full(n, 1000.0)))
+x = w.x; s = w.s
+x[21:27] = 0; x[12:16] = np.array([1.0, 0, 0, 0])[:, None]
+fb.f_ode(w); K = fb.K
+# put on the ground: h such that wheels slightly compressed, terrain at 0
+y = w.y
+x[20] += 1.85 - y[K["FB_Y_KIN"] + 21]
+x[9] = 0; s[1] = 0
+w.set_state(x, s)
+u = w.u; u[0] = 0.0; w.u = u
+sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+fb.step(sim, 1.0); w.sync()
+fb.f_ode(w); y = w.y
+print("on ground frac", ((y[K["FB_Y_LDG"]+1] + y[K["FB_Y_LDG"]+12] + y[K["FB_Y_LDG"]+23]) > 0).mean(), "status", (w.status != 0).sum())
+t0 = time.time(); fb.step(sim, 2.0); w.sync(); dt = time.time() - t0
+print(f"ground: {n*200/dt:.3e} aircraft-steps/s")
