@@ -33,7 +33,9 @@ constexpr int NRF = FB_NX - 6;                              // 21 panel rows
 constexpr int RP0 = XP0 - 6;                                // panel row of the first fp64-integrated state
 FBD constexpr int xsrow(int r) { return r < RP0 ? r : r - XPN; }   // panel row -> row of the fp32 x_n panel (r outside [RP0, RP0+5))
 
-__global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, int nsteps) {
+// no v_pk_*_f32 in this kernel: the SLP vectoriser pairs fp32 operations at the price of more register shuffles than it saves
+// (2 576 -> 2 411 instructions per RHS, scratch 56 B -> 0)
+__global__ __launch_bounds__(fbd::STEP_BLOCK, 2) __attribute__((target("no-packed-fp32-ops"))) void k_step_f32(fbd::KArgs a, int nsteps) {
     constexpr int B = fbd::STEP_BLOCK;
     using SV = StateLdsF<B>;
     __shared__ float lds[LDS_TABLE_DOUBLES_STEP];
@@ -91,29 +93,27 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) void k_step_f32(fbd::KArgs a, i
         asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step)
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables_f32 + lds_off};
         const bool last = stage == 3;
-        const float eb = (stage == 1 || stage == 2) ? 2.0f : 1.0f, ee = last ? dt6 : (stage == 2 ? dt : hdt), em = last ? 0.0f : 1.0f;
+        const float eb = (stage == 1 || stage == 2) ? 2.0f : 1.0f, ee = last ? dt6 : (stage == 2 ? dt : hdt);
         const double eed = last ? dt6d : (stage == 2 ? dtd : hdtd);
         int32_t bits = 0;
         if (run) {
             InputsAgg inl = in;
             asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
+            // the stage enters through wave-uniform scalar branches here (not through selects as in the fp64 kernel): with two
+            // waves per SIMD the SALU work of one wave hides behind the other's VALU, and VALU issue is what bounds this kernel
             auto emit = [&](int j, float kj) {
                 if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
                 const int r = SV::row(j), idx = r * B + t;
                 if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position states (j is a compile-time constant at every call)
                     const int ip = (j - XP0) * B + t;
                     const double A = (double)acc_l[idx] + (double)eb * (double)kj;
-                    const double v = xp_l[ip] + eed * (last ? A : (double)kj);
-                    acc_l[idx] = (float)A * em;
-                    xc_l[idx] = (float)v;
-                    if (last) xp_l[ip] = v;
+                    if (last) { const double v = xp_l[ip] + eed * A; acc_l[idx] = 0.0f; xc_l[idx] = (float)v; xp_l[ip] = v; }
+                    else { acc_l[idx] = (float)A; xc_l[idx] = (float)(xp_l[ip] + eed * (double)kj); }
                 } else {
                     const int ix = xsrow(r) * B + t;
                     const float A = __builtin_fmaf(eb, kj, acc_l[idx]);
-                    const float v = __builtin_fmaf(ee, last ? A : kj, xs_l[ix]);
-                    acc_l[idx] = A * em;
-                    xc_l[idx] = v;
-                    if (last) xs_l[ix] = v;
+                    if (last) { const float v = __builtin_fmaf(ee, A, xs_l[ix]); acc_l[idx] = 0.0f; xc_l[idx] = v; xs_l[ix] = v; }
+                    else { acc_l[idx] = A; xc_l[idx] = __builtin_fmaf(ee, kj, xs_l[ix]); }
                 }
             };
             const SV xv = {(lds_cptr)xc_l + t + lds_off};
