@@ -142,7 +142,7 @@ mutable struct BatchedSimulation
 end
 "f_init!(world) for a Cessna172Xv2 batch whose state and inputs the host has set (C172.Init-style initial condition): the avionics half of f_init!."
 function f_init!(w::BatchedWorld)
-    check(ccall((:fb_f_init, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), w.h, C_NULL, 0))
+    check(ccall((:fb_f_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), w.handle, C_NULL, 0))
     nothing
 end
 init!(sim::BatchedSimulation, args...) = (f_init!(sim.mdl, args...); sim.nstep = 0; nothing)
