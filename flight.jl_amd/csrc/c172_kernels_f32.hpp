@@ -35,7 +35,12 @@ FBD constexpr int xsrow(int r) { return r < RP0 ? r : r - XPN; }   // panel row 
 
 // no v_pk_*_f32 in this kernel: the SLP vectoriser pairs fp32 operations at the price of more register shuffles than it saves
 // (2 576 -> 2 411 instructions per RHS, scratch 56 B -> 0)
-__global__ __launch_bounds__(fbd::STEP_BLOCK, 2) __attribute__((target("no-packed-fp32-ops"))) void k_step_f32(fbd::KArgs a, int nsteps) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of the same translation unit does not know the gfx950 feature name)
+#define FB_NO_PK32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define FB_NO_PK32
+#endif
+__global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd::KArgs a, int nsteps) {
     constexpr int B = fbd::STEP_BLOCK;
     using SV = StateLdsF<B>;
     __shared__ float lds[LDS_TABLE_DOUBLES_STEP];
