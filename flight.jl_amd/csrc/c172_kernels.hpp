@@ -431,7 +431,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     for (int k = 0; k < FB_NX; k++) {
         const double v = a.x[(int64_t)k * a.n + i];
         if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) to_ground = to_ground || (v != 0.0);
-        else { xs_l[SV::row(k) * B + t] = v; xc_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
+        else { xs_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
     }
     if (to_ground) { a.redo[i] = 1; return; }
     InT in;
@@ -487,7 +487,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
         const bool last = stage == 3;
         const double eb = (stage == 1 || stage == 2) ? 2.0 : 1.0, ee = last ? dt6 : (stage == 2 ? dt : hdt), em = last ? 0.0 : 1.0;
-        const lds_ptr xsel_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
+        // panel roles: stage 0 evaluates x_n straight from xs_l, stages 1-3 the state the previous stage left in xc_l; stages 0-2
+        // write the next evaluation state to xc_l, stage 3 the new x_n to xs_l (each row read before it is overwritten)
+        const lds_cptr xrd_l = stage == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
+        const lds_ptr xwr_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
         if (run) {
             InT inl = in;                   // and keeps products of the per-lane inputs from being hoisted out of it
@@ -503,20 +506,20 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             }
             // One branch-free body for all four stages (the stage only enters through wave-uniform operands):
-            //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 when stage 0 starts (zeroed below and by every stage 3)
-            //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_eval <- x_n + dt/6 A
-            // Bit-identical to the branched form: acc + 1 k = k exactly at stage 0, A 1 = A, and the fma's are the same ones.
+            //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 whenever a stage 0 starts (zeroed at load and by every stage 3)
+            //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_n + dt/6 A
+            // Bit-identical to the branched form (acc + 1 k = k exactly at stage 0, A 1 = A, same fma's) and to the ground-capable
+            // kernel's: near the ground a one-ulp difference in this combination is amplified to 1e-6 within a few hundred steps
+            // (tried: x_n + dt/6 acc + dt/6 k4 saves the select and fails test_approach_crosses_the_air_ground_handover).
             auto emit = [&](int j, double kj) {
                 if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
                 const int idx = SV::row(j) * B + t;
                 const double xs = xs_l[idx];
                 const double A = __builtin_fma(eb, kj, acc_l[idx]);
-                const double v = __builtin_fma(ee, last ? A : kj, xs);
                 acc_l[idx] = A * em;
-                xc_l[idx] = v;
-                xsel_l[idx] = v;   // stage 3: x_n; otherwise the evaluation panel once more
+                xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
             };
-            const SV xv = {(lds_cptr)xc_l + t + lds_off};
+            const SV xv = {xrd_l + t + lds_off};
             bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
             if constexpr (X) {
@@ -580,10 +583,10 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 if (dead) { alive = false; run = false; mod = false; }
             }
             if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
-            if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
+            if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
                 if (mod) {
 #pragma unroll
-                    for (int r = 0; r < NR; r++) { xc_l[r * B + t] = xs_l[r * B + t]; acc_l[r * B + t] = 0.0; }   // (acc held the discarded k1)
+                    for (int r = 0; r < NR; r++) acc_l[r * B + t] = 0.0;   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
                 }
                 run = mod; redoing = true;
                 continue;
