@@ -203,7 +203,7 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
     HIPCHK(hipMalloc(&h->status, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->redo, sizeof(int32_t) * n));
     HIPCHK(hipMemsetAsync(h->redo, 0, sizeof(int32_t) * n, h->stream));
-    HIPCHK(hipMalloc(&h->tables, sizeof(double) * LDS_TABLE_DOUBLES));
+    HIPCHK(hipMalloc(&h->tables, sizeof(double) * TABLE_BUF_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
     h->x = h->x_own; h->s = h->s_own;
     HIPCHK(hipMemsetAsync(h->x, 0, sizeof(double) * nx * n, h->stream));
@@ -297,6 +297,16 @@ int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev) {
     return 0;
 }
 
+// the coarse-knot copy of one table behind the blob (csrc/tables.h: LDS_AUX)
+static int32_t put_coarse_knots(fb_handle h, int slot, const double* k, int n) {
+    const int S = n >= 20 ? 4 : 3, G = (n - 2) / S;
+    double buf[AUX_STRIDE];
+    for (int e = 0; e < AUX_STRIDE; e++) buf[e] = HUGE_VAL;
+    buf[0] = k[0]; buf[1] = k[n - 1];
+    for (int m = 1; m <= G; m++) buf[1 + m] = k[S * m];
+    HIPCHK(hipMemcpy(h->tables + LDS_AUX + AUX_STRIDE * slot, buf, sizeof(buf), hipMemcpyHostToDevice));
+    return 0;
+}
 int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t* dims, int32_t ndims) {
     if (h) fsal_invalidate(h);
     if (!h || !data || !dims) return fail("null argument");
@@ -350,10 +360,15 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
         case FB_TABLE_PISTON:
             if (count != PT_SIZE) return fail("piston blob must hold PT_SIZE doubles (csrc/tables.h)");
             HIPCHK(hipMemcpy(h->tables + LDS_PISTON, data, sizeof(double) * PT_SIZE, hipMemcpyHostToDevice));
+            if (int32_t rc = put_coarse_knots(h, AUX_N13, (const double*)data + PT_PISTD_N_K, 13)) return rc;
+            if (int32_t rc = put_coarse_knots(h, AUX_F11, (const double*)data + PT_F_K, 11)) return rc;
             break;
         case FB_TABLE_AERO:
             if (count != AT_SIZE) return fail("aero blob must hold AT_SIZE doubles (csrc/tables.h)");
             HIPCHK(hipMemcpy(h->tables + LDS_AERO, data, sizeof(double) * AT_SIZE, hipMemcpyHostToDevice));
+            if (int32_t rc = put_coarse_knots(h, AUX_GE, (const double*)data + AT_GE_K, 13)) return rc;
+            if (int32_t rc = put_coarse_knots(h, AUX_AL26, (const double*)data + AT_CD_ALPHA_K, 26)) return rc;
+            if (int32_t rc = put_coarse_knots(h, AUX_AL17, (const double*)data + AT_CL_ALPHA_K, 17)) return rc;
             break;
         default: return fail("unknown table kind");
     }
@@ -573,11 +588,11 @@ int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
 static int32_t step_raw(fb_handle h, int64_t nsteps) {
     if (h->model == FB_MODEL_ROBOT2D) return r2_step(h, nsteps);
     if (h->dtype == FB_F32 && h->tables_f32_stale) {   // fp32 mirror of the table blob for the fp32 stepper
-        std::vector<double> d(LDS_TABLE_DOUBLES);
-        HIPCHK(hipMemcpy(d.data(), h->tables, sizeof(double) * LDS_TABLE_DOUBLES, hipMemcpyDeviceToHost));
+        std::vector<double> d(TABLE_BUF_DOUBLES);
+        HIPCHK(hipMemcpy(d.data(), h->tables, sizeof(double) * TABLE_BUF_DOUBLES, hipMemcpyDeviceToHost));
         std::vector<float> f(d.begin(), d.end());
-        if (!h->tables_f32) HIPCHK(hipMalloc(&h->tables_f32, sizeof(float) * LDS_TABLE_DOUBLES));
-        HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * LDS_TABLE_DOUBLES, hipMemcpyHostToDevice));
+        if (!h->tables_f32) HIPCHK(hipMalloc(&h->tables_f32, sizeof(float) * TABLE_BUF_DOUBLES));
+        HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * TABLE_BUF_DOUBLES, hipMemcpyHostToDevice));
         h->tables_f32_stale = false;
     }
     const KArgs a = make_args(h);

@@ -75,4 +75,10 @@ enum { PR_NC_STEP = 4, PR_SIZE_STEP = 21 * 21 * 4 };
 enum { LDS_AERO = 0, LDS_PISTON = AT_SIZE, LDS_PROP = AT_SIZE + PT_SIZE, LDS_TABLE_DOUBLES = AT_SIZE + PT_SIZE + PR_SIZE,
        LDS_TABLE_DOUBLES_STEP = AT_SIZE + PT_SIZE + PR_SIZE_STEP };
 
+/* Behind the blob in the device buffer: contiguous copies of the knots the two-level scans (grid_locate) compare from SGPRs —
+ * per table AUX_STRIDE doubles [k_0, k_{N-1}, k_S, k_2S, ..., k_GS, +inf ...], S = 4 for N >= 20 else 3, G = (N-2)/S — so that one
+ * scalar load brings what six strided ones did. Written by the host whenever the aero / piston blob is uploaded. */
+enum { AUX_GE = 0, AUX_AL26 = 1, AUX_AL17 = 2, AUX_N13 = 3, AUX_F11 = 4, AUX_TABLES = 5, AUX_STRIDE = 8,
+       LDS_AUX = LDS_TABLE_DOUBLES, TABLE_BUF_DOUBLES = LDS_TABLE_DOUBLES + AUX_TABLES * AUX_STRIDE };
+
 #endif
