@@ -411,6 +411,44 @@ struct StateLds {
 // RK4 on them has a closed form — stage values cmd + (x_n - cmd) m_s with m = 1, 1 - z/2, 1 - z/2 + z²/4, 1 - z + z²/2 - z³/4 and
 // x_{n+1} = cmd + (x_n - cmd)(1 - z + z²/2 - z³/6 + z⁴/24), z = dt/τ — equal to the stage-by-stage evaluation up to rounding.
 // They therefore need no panel rows at all (x_n and the commands ride in registers), and the Sv0 LDS budget holds for Xv2.
+// The airborne kernels' emit: one branch-free body for all four stages (the stage only enters through wave-uniform operands):
+//   A = acc + b k        b = 1, 2, 2, 1; acc is 0 whenever a stage 0 starts (zeroed at load and by every stage 3)
+//   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_n + dt/6 A
+// Bit-identical to the branched form (acc + 1 k = k exactly at stage 0, A 1 = A, same fma's) and to the ground-capable kernel's:
+// near the ground a one-ulp difference in this combination is amplified to 1e-6 within a few hundred steps (tried:
+// x_n + dt/6 acc + dt/6 k4 saves the select and fails test_approach_crosses_the_air_ground_handover).
+template <int B>
+struct AirEmit {
+    typedef void batched_tag;
+    lds_cptr xs_l;            // x_n panel
+    lds_ptr acc_l, xwr_l;     // stage sum; the panel this stage writes (evaluation panel, at stage 3 x_n itself)
+    double eb, ee, em;
+    bool last;
+    int t;
+    using SV = StateLds<B>;
+    __device__ __forceinline__ void operator()(int j, double kj) const {
+        if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+        const int idx = SV::row(j) * B + t;
+        const double xs = xs_l[idx];
+        const double A = __builtin_fma(eb, kj, acc_l[idx]);
+        acc_l[idx] = A * em;
+        xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
+    }
+    template <int NE>
+    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {   // NE consecutive non-contact rows
+        double xs[NE], A[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) { const int idx = SV::row(j0 + e) * B + t; xs[e] = xs_l[idx]; A[e] = acc_l[idx]; }
+#pragma unroll
+        for (int e = 0; e < NE; e++) A[e] = __builtin_fma(eb, k[e], A[e]);
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int idx = SV::row(j0 + e) * B + t;
+            acc_l[idx] = A[e] * em;
+            xwr_l[idx] = __builtin_fma(ee, last ? A[e] : k[e], xs[e]);
+        }
+    }
+};
 template <int KIN, bool X = false>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     constexpr int B = STEP_BLOCK, NR = FB_NX - 6;
@@ -505,20 +543,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             } else {
                 asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             }
-            // One branch-free body for all four stages (the stage only enters through wave-uniform operands):
-            //   A = acc + b k        b = 1, 2, 2, 1; acc is 0 whenever a stage 0 starts (zeroed at load and by every stage 3)
-            //   stage 0-2: acc <- A, x_eval <- x_n + c dt k;      stage 3: acc <- 0, x_n <- x_n + dt/6 A
-            // Bit-identical to the branched form (acc + 1 k = k exactly at stage 0, A 1 = A, same fma's) and to the ground-capable
-            // kernel's: near the ground a one-ulp difference in this combination is amplified to 1e-6 within a few hundred steps
-            // (tried: x_n + dt/6 acc + dt/6 k4 saves the select and fails test_approach_crosses_the_air_ground_handover).
-            auto emit = [&](int j, double kj) {
-                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
-                const int idx = SV::row(j) * B + t;
-                const double xs = xs_l[idx];
-                const double A = __builtin_fma(eb, kj, acc_l[idx]);
-                acc_l[idx] = A * em;
-                xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
-            };
+            const AirEmit<B> emit = {(lds_cptr)xs_l, (lds_ptr)acc_l, xwr_l, eb, ee, em, last, t};
             const SV xv = {xrd_l + t + lds_off};
             bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
