@@ -133,8 +133,7 @@ static row_map_t row_map_of(fb_handle h) {
 #define FB_LAUNCH_STEP(GRID, A, K)                                                                                                    \
     do {                                                                                                                              \
         if (is_x2(h)) {                                                                                                               \
-            if (getenv("FB_OLD_AIR_KERNEL")) hipLaunchKernelGGL((k_step<true, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K); \
-            else hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
             hipLaunchKernelGGL((k_step<true, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                         \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
             hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
@@ -146,8 +145,7 @@ static row_map_t row_map_of(fb_handle h) {
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         } else {                                                                                                                      \
-            if (getenv("FB_OLD_AIR_KERNEL")) hipLaunchKernelGGL((k_step<false, FB_KIN_WA, false>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K); \
-            else hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
+            hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                   \
             hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
         }                                                                                                                             \
     } while (0)
