@@ -35,6 +35,50 @@ FBD constexpr int xsrow(int r) { return r < RP0 ? r : r - XPN; }   // panel row 
 
 // no v_pk_*_f32 in this kernel: the SLP vectoriser pairs fp32 operations at the price of more register shuffles than it saves
 // (2 576 -> 2 411 instructions per RHS, scratch 56 B -> 0)
+// emit of the fp32 stepper. The stage enters through wave-uniform scalar branches (not through selects as in the fp64 kernel: with
+// two waves per SIMD the SALU work of one wave hides behind the other's VALU, and VALU issue is what bounds this kernel), one
+// branch per BATCH of consecutive rows: all panel reads first, then the updates and writes, so the LDS round trips of a batch overlap.
+template <int B>
+struct F32Emit {
+    typedef void batched_tag;
+    typedef __attribute__((address_space(3))) float* lf_ptr;
+    typedef __attribute__((address_space(3))) double* ld_ptr;
+    using SV = StateLdsF<B>;
+    lf_ptr xs_l; ld_ptr xp_l; lf_ptr acc_l, xc_l;
+    float eb, ee; double eed; bool last; int t;
+    static __device__ __forceinline__ constexpr bool wide(int j) { return j >= XP0 && j < XP0 + XPN; }   // integrated in fp64
+    template <int NE>
+    __device__ __forceinline__ void batch(int j0, const float (&k)[NE]) const {   // NE consecutive non-contact rows
+        float xsf[NE], ac[NE]; double xsd[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int j = j0 + e, r = SV::row(j);
+            ac[e] = acc_l[r * B + t];
+            if (wide(j)) { xsd[e] = xp_l[(j - XP0) * B + t]; xsf[e] = 0; } else { xsf[e] = xs_l[xsrow(r) * B + t]; xsd[e] = 0; }
+        }
+        if (last) {
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int j = j0 + e, r = SV::row(j), idx = r * B + t;
+                acc_l[idx] = 0.0f;
+                if (wide(j)) { const double v = xsd[e] + eed * ((double)ac[e] + (double)eb * (double)k[e]); xc_l[idx] = (float)v; xp_l[(j - XP0) * B + t] = v; }
+                else { const float v = __builtin_fmaf(ee, __builtin_fmaf(eb, k[e], ac[e]), xsf[e]); xc_l[idx] = v; xs_l[xsrow(r) * B + t] = v; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const int j = j0 + e, r = SV::row(j), idx = r * B + t;
+                if (wide(j)) { acc_l[idx] = (float)((double)ac[e] + (double)eb * (double)k[e]); xc_l[idx] = (float)(xsd[e] + eed * (double)k[e]); }
+                else { acc_l[idx] = __builtin_fmaf(eb, k[e], ac[e]); xc_l[idx] = __builtin_fmaf(ee, k[e], xsf[e]); }
+            }
+        }
+    }
+    __device__ __forceinline__ void operator()(int j, float kj) const {
+        if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
+        const float k1[1] = {kj};
+        batch<1>(j, k1);
+    }
+};
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of the same translation unit does not know the gfx950 feature name)
 #define FB_NO_PK32 __attribute__((target("no-packed-fp32-ops")))
 #else
@@ -104,23 +148,8 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
         if (run) {
             InputsAgg inl = in;
             asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
-            // the stage enters through wave-uniform scalar branches here (not through selects as in the fp64 kernel): with two
-            // waves per SIMD the SALU work of one wave hides behind the other's VALU, and VALU issue is what bounds this kernel
-            auto emit = [&](int j, float kj) {
-                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
-                const int r = SV::row(j), idx = r * B + t;
-                if (j >= XP0 && j < XP0 + XPN) {   // fp64 integration of the position states (j is a compile-time constant at every call)
-                    const int ip = (j - XP0) * B + t;
-                    const double A = (double)acc_l[idx] + (double)eb * (double)kj;
-                    if (last) { const double v = xp_l[ip] + eed * A; acc_l[idx] = 0.0f; xc_l[idx] = (float)v; xp_l[ip] = v; }
-                    else { acc_l[idx] = (float)A; xc_l[idx] = (float)(xp_l[ip] + eed * (double)kj); }
-                } else {
-                    const int ix = xsrow(r) * B + t;
-                    const float A = __builtin_fmaf(eb, kj, acc_l[idx]);
-                    if (last) { const float v = __builtin_fmaf(ee, A, xs_l[ix]); acc_l[idx] = 0.0f; xc_l[idx] = v; xs_l[ix] = v; }
-                    else { acc_l[idx] = A; xc_l[idx] = __builtin_fmaf(ee, kj, xs_l[ix]); }
-                }
-            };
+            const F32Emit<B> emit = {(typename F32Emit<B>::lf_ptr)xs_l, (typename F32Emit<B>::ld_ptr)xp_l, (typename F32Emit<B>::lf_ptr)acc_l,
+                                     (typename F32Emit<B>::lf_ptr)xc_l, eb, ee, eed, last, t};
             const SV xv = {(lds_cptr)xc_l + t + lds_off};
             bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
             if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // within reach of the ground: the fp64 kernel takes this lane over
