@@ -128,7 +128,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
     int stall = a.s[i], eng = a.s[a.n + i];
-    const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface, (float)a.env.ln_p_sl};
+    const Env env = {(float)a.env.T_sl, (float)a.env.p_sl, (float)a.env.wind_n, (float)a.env.wind_e, (float)a.env.wind_d, (float)a.env.h_trn, a.env.surface, (float)a.env.ln_p_sl, (float)a.env.k_rt};
     const float dt = (float)a.dt, hdt = (float)(a.dt / 2), dt6 = (float)(a.dt / 6);
     const double dtd = a.dt, hdtd = a.dt / 2, dt6d = a.dt / 6;
     // wave-uniform stage machine and branch-free emit, as in fbd::k_step_air (see there)

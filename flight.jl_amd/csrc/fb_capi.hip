@@ -78,7 +78,8 @@ static KArgs make_args(fb_handle h) {
     a.x = h->x; a.s = h->s; a.u = h->u; a.ui = h->ui; a.status = h->status; a.tables = h->tables; a.tables_f32 = h->tables_f32; a.egm96 = h->egm96;
     a.n = h->n;
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface,
-             log(h->params.p_sl / 101325.0)};
+             log(h->params.p_sl / 101325.0),
+             exp(0.5 * 6.5e-3 * 287.05287 / 9.80665 * log(h->params.p_sl / 101325.0)) / sqrt(h->params.T_sl)};
     a.dt = h->params.dt;
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
