@@ -33,7 +33,7 @@ DT = 0.01
 BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flags, C172Sv0 fp64
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r01o_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r01p_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
 
 
 def lattice(rank: int):
