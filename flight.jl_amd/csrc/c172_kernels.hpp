@@ -731,10 +731,196 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
     r[6] = xd[FB_X_ENG_OMEGA] / c172::w_rated;
 }
-// One lane trims one aircraft. The reference minimises cost = Σ r² with NLopt's BOBYQA until
-// cost <= 1e-16 inside box bounds (c172.jl:901-934); here the same zero-residual point is found by a
-// bounded, damped Newton iteration on the 7 residuals with a central-difference Jacobian — a batched,
-// branch-light solver that maps onto one lane per aircraft.
+// ---- the trim solver ---------------------------------------------------------------------------------------------
+// The reference minimises cost = Σ r² with NLopt's :LN_BOBYQA inside box bounds, initial_step 0.05, stopval 1e-16,
+// maxeval 1e5 (c172.jl:883-942). NLopt is a third-party optimiser; what is kept of it is its behaviour on this
+// zero-residual problem — a trust region that starts at the initial step, never leaves the box and walks a continuous
+// descent path from TrimState() — implemented as a bound-constrained Gauss-Newton trust-region iteration, one lane per
+// aircraft:
+//   * box trust region |dz|∞ <= D (D0 = 0.05) intersected with the bounds; inside it |r + J dz|² is minimised by an
+//     active set (a variable that would leave the box is held at the face it hits and released when the model
+//     gradient there points back inside), so an iterate slides along a bound instead of being clamped onto it;
+//   * J by central differences (one-sided at a bound). The engine and aerodynamic maps are piecewise linear: where
+//     the forward and backward differences of a column disagree (a knot within one difference step of the iterate,
+//     e.g. n_eng = 1.074, piston.jl:110,140) the column is replaced by the pure one-sided slopes one step further
+//     out, the step uses the side it moves to (semismooth Newton), and the mirror choice is tried too;
+//   * D doubles after a well-predicted step, shrinks after a rejected one; iteration continues to the rounding
+//     floor (cost <= 1e-27) so that the trim does not depend on the path; success <=> cost <= stopval = 1e-16.
+// If the descent from TrimState() ends above stopval (a V-shaped minimum of the cost on a table knot), the solve is
+// repeated by continuation in the trim PARAMETERS from the reference's default TrimParameters() (EAS 50, h 1050, ...:
+// c172.jl:806-818, whose trim from TrimState() the reference's own test pins) towards the requested ones.
+constexpr int TRIM_N = 7;
+__device__ __noinline__ void trim_box_gauss_newton(const double (&H)[TRIM_N][TRIM_N], const double (&g)[TRIM_N], const double* dl, const double* du,
+                                                   double ridge, double* d) {
+    constexpr int N = TRIM_N;
+    int fixed[N];
+    for (int k = 0; k < N; k++) { d[k] = 0; fixed[k] = 0; }
+#pragma unroll 1
+    for (int pass = 0; pass < 4 * N; pass++) {
+        int idx[N], nf = 0;
+        for (int k = 0; k < N; k++) if (!fixed[k]) idx[nf++] = k;
+        double A[N][N + 1];
+        for (int a = 0; a < nf; a++) {   // H_FF d_F = -(g_F + H_FB d_B)
+            double rhs = -g[idx[a]];
+            for (int k = 0; k < N; k++) if (fixed[k]) rhs -= H[idx[a]][k] * d[k];
+            for (int b = 0; b < nf; b++) A[a][b] = H[idx[a]][idx[b]] + (a == b ? ridge : 0.0);
+            A[a][nf] = rhs;
+        }
+#pragma unroll 1
+        for (int c = 0; c < nf; c++) {   // Gaussian elimination, partial pivoting
+            int pv = c;
+            for (int q = c + 1; q < nf; q++) if (fabs(A[q][c]) > fabs(A[pv][c])) pv = q;
+            if (pv != c) for (int q = 0; q <= nf; q++) { const double t = A[pv][q]; A[pv][q] = A[c][q]; A[c][q] = t; }
+            const double piv = A[c][c] != 0 ? A[c][c] : 1e-300;
+            for (int q = c + 1; q < nf; q++) {
+                const double f = A[q][c] / piv;
+                for (int w = c; w <= nf; w++) A[q][w] -= f * A[c][w];
+            }
+        }
+        double sol[N];
+        for (int q = nf - 1; q >= 0; q--) {
+            double sum = A[q][nf];
+            for (int w = q + 1; w < nf; w++) sum -= A[q][w] * sol[w];
+            sol[q] = sum / (A[q][q] != 0 ? A[q][q] : 1e-300);
+        }
+        double t = 1.0;   // longest feasible fraction of the move towards the free minimum
+        int hit = -1, side = 0;
+        for (int a = 0; a < nf; a++) {
+            const int k = idx[a];
+            const double delta = sol[a] - d[k];
+            if (delta > 0 && d[k] + delta > du[k]) { const double tt = (du[k] - d[k]) / delta; if (tt < t) { t = tt; hit = k; side = 1; } }
+            if (delta < 0 && d[k] + delta < dl[k]) { const double tt = (dl[k] - d[k]) / delta; if (tt < t) { t = tt; hit = k; side = -1; } }
+        }
+        for (int a = 0; a < nf; a++) { const int k = idx[a]; d[k] += t * (sol[a] - d[k]); }
+        if (hit >= 0) { fixed[hit] = side; d[hit] = side > 0 ? du[hit] : dl[hit]; continue; }
+        int rel = -1;
+        double best = 0;
+        for (int k = 0; k < N; k++) if (fixed[k]) {
+            double gm = g[k];
+            for (int b = 0; b < N; b++) gm += H[k][b] * d[b];
+            const double inward = fixed[k] > 0 ? gm : -gm;   // at the upper face a positive gradient wants to come back
+            if (inward > best) { best = inward; rel = k; }
+        }
+        if (rel < 0 || best <= 1e-14 * (fabs(g[rel]) + 1e-300)) break;
+        fixed[rel] = 0;
+    }
+}
+// minimises |r(z)|² inside [lo, hi]; returns the final cost, z updated in place
+__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double* lo, const double* hi, double* z, int max_iter) {
+    constexpr int N = TRIM_N;
+    const double fd = 1e-6, cost_floor = 1e-27;
+    double r[N];
+    for (int k = 0; k < N; k++) z[k] = fmin(fmax(z[k], lo[k]), hi[k]);
+    trim_resid(p, z, env, T, r);
+    double cost = 0;
+    for (int k = 0; k < N; k++) cost += r[k] * r[k];
+    double D = 0.05;   // the reference's initial_step (c172.jl:919)
+#pragma unroll 1
+    for (int it = 0; it < max_iter && cost > cost_floor && D > 1e-13; it++) {
+        double Jc[N][N], Jf[N][N], Jb[N][N];
+        bool kink[N], any_kink = false;
+#pragma unroll 1
+        for (int j = 0; j < N; j++) {
+            double zz[N], rp[N], rm[N];
+            for (int k = 0; k < N; k++) zz[k] = z[k];
+            const double zp = fmin(z[j] + fd, hi[j]), zm = fmax(z[j] - fd, lo[j]);
+            zz[j] = zp; trim_resid(p, zz, env, T, rp);
+            zz[j] = zm; trim_resid(p, zz, env, T, rm);
+            const double ic = 1.0 / (zp - zm);
+            const double ifw = zp > z[j] ? 1.0 / (zp - z[j]) : 0.0, ibw = z[j] > zm ? 1.0 / (z[j] - zm) : 0.0;
+            double dmax = 0, cmax = 0;
+            for (int i = 0; i < N; i++) {
+                Jc[i][j] = (rp[i] - rm[i]) * ic;
+                Jf[i][j] = ifw != 0 ? (rp[i] - r[i]) * ifw : Jc[i][j];
+                Jb[i][j] = ibw != 0 ? (r[i] - rm[i]) * ibw : Jc[i][j];
+                dmax = fmax(dmax, fabs(Jf[i][j] - Jb[i][j]));
+                cmax = fmax(cmax, fabs(Jc[i][j]));
+            }
+            kink[j] = dmax > 1e-3 * cmax;   // smooth: |Jf - Jb| ~ fd |r''| ~ 1e-6 of the column
+            if (kink[j]) {
+                any_kink = true;
+                double r2[N];
+                if (zp + fd <= hi[j]) { zz[j] = zp + fd; trim_resid(p, zz, env, T, r2); for (int i = 0; i < N; i++) Jf[i][j] = (r2[i] - rp[i]) / (zp + fd - zp); }
+                if (zm - fd >= lo[j]) { zz[j] = zm - fd; trim_resid(p, zz, env, T, r2); for (int i = 0; i < N; i++) Jb[i][j] = (rm[i] - r2[i]) / (zm - (zm - fd)); }
+            }
+        }
+        bool accepted = false;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 40 && !accepted && D > 1e-13; attempt++) {
+            double dl[N], du[N];
+            for (int k = 0; k < N; k++) { dl[k] = fmax(lo[k] - z[k], -D); du[k] = fmin(hi[k] - z[k], D); }
+            double best_cn = 0, best_pred = 0, best_dinf = 0, best_zn[N], best_rn[N];
+            bool have = false;
+            int side0[N];
+#pragma unroll 1
+            for (int cand = 0; cand < (any_kink ? 2 : 1); cand++) {
+                double J[N][N], H[N][N], g[N], d[N];
+                int side[N];
+                for (int j = 0; j < N; j++) {
+                    side[j] = cand == 0 ? 0 : (kink[j] ? (side0[j] > 0 ? -1 : 1) : 0);
+                    for (int i = 0; i < N; i++) J[i][j] = side[j] == 0 ? Jc[i][j] : side[j] > 0 ? Jf[i][j] : Jb[i][j];
+                }
+#pragma unroll 1
+                for (int round = 0; round < (cand == 0 ? 3 : 1); round++) {
+                    double tr = 0;
+                    for (int a = 0; a < N; a++) {
+                        g[a] = 0;
+                        for (int i = 0; i < N; i++) g[a] += J[i][a] * r[i];
+                        for (int b = 0; b < N; b++) {
+                            double sum = 0;
+                            for (int i = 0; i < N; i++) sum += J[i][a] * J[i][b];
+                            H[a][b] = sum;
+                        }
+                        tr += H[a][a];
+                    }
+                    trim_box_gauss_newton(H, g, dl, du, 1e-14 * tr + 1e-300, d);
+                    if (cand != 0) break;
+                    bool changed = false;
+                    for (int j = 0; j < N; j++) if (kink[j]) {
+                        const int want = d[j] > 0 ? 1 : d[j] < 0 ? -1 : (side[j] != 0 ? side[j] : 1);
+                        if (want != side[j]) {
+                            side[j] = want; changed = true;
+                            for (int i = 0; i < N; i++) J[i][j] = want > 0 ? Jf[i][j] : Jb[i][j];
+                        }
+                    }
+                    if (!changed) break;
+                }
+                if (cand == 0) for (int j = 0; j < N; j++) side0[j] = side[j];
+                double pred = 0, dinf = 0;
+                for (int a = 0; a < N; a++) {
+                    double Hd = 0;
+                    for (int b = 0; b < N; b++) Hd += H[a][b] * d[b];
+                    pred -= d[a] * (2 * g[a] + Hd);
+                    dinf = fmax(dinf, fabs(d[a]));
+                }
+                if (!(pred > 0) || dinf == 0) continue;
+                double zn[N], rn[N];
+                for (int k = 0; k < N; k++) zn[k] = fmin(fmax(z[k] + d[k], lo[k]), hi[k]);
+                trim_resid(p, zn, env, T, rn);
+                double cn = 0;
+                for (int k = 0; k < N; k++) cn += rn[k] * rn[k];
+                if (!have || cn < best_cn) {
+                    have = true; best_cn = cn; best_pred = pred; best_dinf = dinf;
+                    for (int k = 0; k < N; k++) { best_zn[k] = zn[k]; best_rn[k] = rn[k]; }
+                }
+            }
+            if (!have) { D *= 0.25; continue; }
+            const double rho = (cost - best_cn) / best_pred;
+            if (best_cn < cost) {
+                for (int k = 0; k < N; k++) { z[k] = best_zn[k]; r[k] = best_rn[k]; }
+                cost = best_cn;
+                accepted = true;
+                if (rho > 0.75 && best_dinf > 0.9 * D) D = fmin(2 * D, 1.0);
+                else if (rho < 0.25) D = fmax(0.5 * best_dinf, 1e-14);
+            } else {
+                D = 0.25 * fmin(D, best_dinf);
+            }
+        }
+        if (!accepted) break;
+    }
+    return cost;
+}
+// One lane trims one aircraft: f_init!(vehicle, TrimParameters) (c172.jl:883-942).
 __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
@@ -750,65 +936,40 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     p.theta_wb_dot = tp[(int64_t)FB_TP_THETA_WB_DOT * n + i]; p.beta_a = tp[(int64_t)FB_TP_BETA_A * n + i];
     p.fuel_load = tp[(int64_t)FB_TP_FUEL_LOAD * n + i]; p.mixture = tp[(int64_t)FB_TP_MIXTURE * n + i]; p.flaps = tp[(int64_t)FB_TP_FLAPS * n + i];
     for (int k = 0; k < 5; k++) p.payload[k] = tp[(int64_t)(FB_TP_PAYLOAD + k) * n + i];
-    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};
-    const double hi[7] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};
-    double z[7], r[7];
-    for (int k = 0; k < 7; k++) z[k] = ts[(int64_t)k * n + i];
-    trim_resid(p, z, a.env, T, r);
-    double cost = 0;
-    for (int k = 0; k < 7; k++) cost += r[k] * r[k];
+    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                 // c172.jl:901-908
+    const double hi[7] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
+    double z0[7], z[7];
+    for (int k = 0; k < 7; k++) { z0[k] = ts[(int64_t)k * n + i]; z[k] = z0[k]; }
+    double cost = trim_tr_minimize(p, a.env, T, lo, hi, z, 500);
+    if (cost > 1e-16) {
+        // continuation from TrimParameters() (c172.jl:806-818); location and heading as requested (the trim barely depends on them)
+        const double d0[15] = {1050.0, 50.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 75.0, 75.0, 0.0, 0.0, 50.0, 0.0};
+        auto blend = [&](double t) {
+            TrimP q = p;
+            q.h_e = d0[0] + t * (p.h_e - d0[0]); q.EAS = d0[1] + t * (p.EAS - d0[1]); q.gamma_wb_n = d0[2] + t * (p.gamma_wb_n - d0[2]);
+            q.psi_wb_dot = d0[3] + t * (p.psi_wb_dot - d0[3]); q.theta_wb_dot = d0[4] + t * (p.theta_wb_dot - d0[4]);
+            q.beta_a = d0[5] + t * (p.beta_a - d0[5]); q.fuel_load = d0[6] + t * (p.fuel_load - d0[6]); q.mixture = d0[7] + t * (p.mixture - d0[7]);
+            q.flaps = d0[8] + t * (p.flaps - d0[8]);
+            for (int k = 0; k < 5; k++) q.payload[k] = d0[9 + k] + t * (p.payload[k] - d0[9 + k]);
+            return q;
+        };
+        double zc[7];
+        for (int k = 0; k < 7; k++) zc[k] = z0[k];
+        double t = 0, dt = 0.125;
+        TrimP q = blend(0.0);
+        double c = trim_tr_minimize(q, a.env, T, lo, hi, zc, 200);
+        bool good = c <= 1e-16;
 #pragma unroll 1
-    for (int it = 0; it < 60 && cost > 1e-26; it++) {
-        double A[7][8];
-#pragma unroll 1
-        for (int j = 0; j < 7; j++) {
-            const double h = 1e-6;
-            double zz[7], rp[7], rm[7];
-            for (int k = 0; k < 7; k++) zz[k] = z[k];
-            zz[j] = z[j] + h;
-            trim_resid(p, zz, a.env, T, rp);
-            zz[j] = z[j] - h;
-            trim_resid(p, zz, a.env, T, rm);
-            for (int k = 0; k < 7; k++) A[k][j] = (rp[k] - rm[k]) / (2 * h);
+        while (good && t < 1.0) {
+            const double tn = fmin(1.0, t + dt);
+            double zt[7];
+            for (int k = 0; k < 7; k++) zt[k] = zc[k];
+            q = blend(tn);
+            c = trim_tr_minimize(q, a.env, T, lo, hi, zt, 60);
+            if (c <= 1e-16) { t = tn; for (int k = 0; k < 7; k++) zc[k] = zt[k]; dt = fmin(2 * dt, 0.25); }
+            else { dt *= 0.5; if (dt < 1.0 / 1024) good = false; }
         }
-        for (int k = 0; k < 7; k++) A[k][7] = -r[k];
-        bool singular = false;
-#pragma unroll 1
-        for (int c = 0; c < 7; c++) {
-            int pv = c;
-            for (int q = c + 1; q < 7; q++) if (fabs(A[q][c]) > fabs(A[pv][c])) pv = q;
-            if (fabs(A[pv][c]) < 1e-300) { singular = true; break; }
-            if (pv != c) for (int q = 0; q < 8; q++) { const double t = A[pv][q]; A[pv][q] = A[c][q]; A[c][q] = t; }
-            for (int q = c + 1; q < 7; q++) {
-                const double f = A[q][c] / A[c][c];
-                for (int w = c; w < 8; w++) A[q][w] -= f * A[c][w];
-            }
-        }
-        if (singular) break;
-        double dz[7];
-        for (int q = 6; q >= 0; q--) {
-            double sum = A[q][7];
-            for (int w = q + 1; w < 7; w++) sum -= A[q][w] * dz[w];
-            dz[q] = sum / A[q][q];
-        }
-        double lam = 1.0;
-        bool improved = false;
-#pragma unroll 1
-        for (int ls = 0; ls < 20; ls++) {
-            double zn[7], rn[7];
-            for (int k = 0; k < 7; k++) zn[k] = fmin(fmax(z[k] + lam * dz[k], lo[k]), hi[k]);
-            trim_resid(p, zn, a.env, T, rn);
-            double cn = 0;
-            for (int k = 0; k < 7; k++) cn += rn[k] * rn[k];
-            if (cn < cost) {
-                for (int k = 0; k < 7; k++) { z[k] = zn[k]; r[k] = rn[k]; }
-                cost = cn;
-                improved = true;
-                break;
-            }
-            lam *= 0.5;
-        }
-        if (!improved) break;
+        if (good && c < cost) { cost = c; for (int k = 0; k < 7; k++) z[k] = zc[k]; }
     }
     // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s
     double x[FB_NX], uraw[FB_NU];
@@ -821,7 +982,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     a.s[i] = 0;        // stall = false
     a.s[n + i] = 2;    // EngineState.running
     for (int k = 0; k < 7; k++) ts[(int64_t)k * n + i] = z[k];
-    if (success) success[i] = cost <= 1e-16;
+    if (success) success[i] = cost <= 1e-16;   // the reference's criterion: STOPVAL_REACHED, stopval = 1e-16 (c172.jl:926,934)
     if (cost_out) cost_out[i] = cost;
 }
 

@@ -10,6 +10,7 @@
 #pragma once
 #include "fo_propulsion.hpp"
 #include "fo_landinggear.hpp"
+#include "fo_trim.hpp"
 
 namespace fo {
 
@@ -437,72 +438,49 @@ inline double trim_cost(const C172Model& M, const TrimParams& tp, const TrimStat
     for (int i = 0; i < 7; i++) c += r[i] * r[i];
     return c;
 }
-// Solves the same problem as the reference's NLopt BOBYQA run (minimise cost to <= 1e-16 within the
-// bounds of c172.jl:901-917) with a bounded damped Newton iteration on the 7 residuals (finite-
-// difference Jacobian). The reference optimiser itself (NLopt 1.2.1) is third-party and not restated;
-// any point with cost <= stopval is an accepted trim by the reference's own criterion (:926, :934).
-inline bool trim_solve(const C172Model& M, const TrimParams& tp, const Env& env, TrimState& ts, double* cost_out = nullptr) {
-    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};
-    const double hi[7] = {M.aero.alpha_stall[1], PI / 3, 1.1, 1, 1, 1, 1};
-    double z[7] = {ts.alpha_a, ts.phi_nb, ts.n_eng, ts.throttle, ts.aileron, ts.elevator, ts.rudder};
+// f_init!(vehicle, TrimParameters) (c172.jl:883-942): see fo_trim.hpp for what is and is not restated of the
+// reference's NLopt BOBYQA run. `ts` in: the initial guess (the reference always starts from TrimState()); out: the trim.
+inline bool trim_solve(const C172Model& M, const TrimParams& tp, const Env& env, TrimState& ts, double* cost_out = nullptr,
+                       TrimSolveStats* stats = nullptr, bool allow_continuation = true) {
+    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                    // c172.jl:901-908
+    const double hi[7] = {M.aero.alpha_stall[1], PI / 3, 1.1, 1, 1, 1, 1};          // c172.jl:910-917
     auto unpack = [](const double* v) { return TrimState{v[0], v[1], v[2], v[3], v[4], v[5], v[6]}; };
-    double r[7];
-    trim_residuals(M, tp, unpack(z), env, r);
-    double cost = 0;
-    for (int i = 0; i < 7; i++) cost += r[i] * r[i];
-    for (int it = 0; it < 60 && cost > 1e-26; it++) {
-        double Jm[7][7];
-        for (int j = 0; j < 7; j++) {
-            const double h = 1e-6;
-            double zp[7], zm[7], rp[7], rm[7];
-            for (int k = 0; k < 7; k++) { zp[k] = z[k]; zm[k] = z[k]; }
-            zp[j] += h; zm[j] -= h;
-            trim_residuals(M, tp, unpack(zp), env, rp);
-            trim_residuals(M, tp, unpack(zm), env, rm);
-            for (int i = 0; i < 7; i++) Jm[i][j] = (rp[i] - rm[i]) / (2 * h);
+    const double z0[7] = {ts.alpha_a, ts.phi_nb, ts.n_eng, ts.throttle, ts.aileron, ts.elevator, ts.rudder};
+    double z[7];
+    for (int k = 0; k < 7; k++) z[k] = z0[k];
+    double cost = trim_tr_minimize([&](const double* v, double* r) { trim_residuals(M, tp, unpack(v), env, r); }, lo, hi, z, 500, stats);
+    if (cost > 1e-16 && allow_continuation) {
+        // continuation in the parameters from TrimParameters() (its trim from TrimState() is pinned by test_c172s.jl:22-38)
+        const TrimParams d0{};
+        auto blend = [&](double t) {
+            TrimParams p = tp;
+            auto mix = [t](double a, double b) { return a + t * (b - a); };
+            p.h_e = mix(d0.h_e, tp.h_e); p.EAS = mix(d0.EAS, tp.EAS); p.gamma_wb_n = mix(d0.gamma_wb_n, tp.gamma_wb_n);
+            p.psi_wb_dot = mix(d0.psi_wb_dot, tp.psi_wb_dot); p.theta_wb_dot = mix(d0.theta_wb_dot, tp.theta_wb_dot);
+            p.beta_a = mix(d0.beta_a, tp.beta_a); p.fuel_load = mix(d0.fuel_load, tp.fuel_load); p.mixture = mix(d0.mixture, tp.mixture);
+            p.flaps = mix(d0.flaps, tp.flaps);
+            for (int k = 0; k < 5; k++) p.payload[k] = mix(d0.payload[k], tp.payload[k]);
+            return p;   // location and heading are taken as requested: the trim barely depends on them
+        };
+        double zc[7];
+        for (int k = 0; k < 7; k++) zc[k] = z0[k];
+        double t = 0, dt = 0.125;
+        double c = trim_tr_minimize([&](const double* v, double* r) { trim_residuals(M, blend(0.0), unpack(v), env, r); }, lo, hi, zc, 200, stats);
+        bool good = c <= 1e-16;
+        while (good && t < 1.0) {
+            const double tn = std::min(1.0, t + dt);
+            double zt[7];
+            for (int k = 0; k < 7; k++) zt[k] = zc[k];
+            const TrimParams p = blend(tn);
+            c = trim_tr_minimize([&](const double* v, double* r) { trim_residuals(M, p, unpack(v), env, r); }, lo, hi, zt, 60, stats);
+            if (c <= 1e-16) { t = tn; for (int k = 0; k < 7; k++) zc[k] = zt[k]; dt = std::min(2 * dt, 0.25); }
+            else { dt *= 0.5; if (dt < 1.0 / 1024) good = false; }
         }
-        // solve J dz = -r by Gaussian elimination with partial pivoting
-        double A[7][8];
-        for (int i = 0; i < 7; i++) { for (int j = 0; j < 7; j++) A[i][j] = Jm[i][j]; A[i][7] = -r[i]; }
-        bool singular = false;
-        for (int c = 0; c < 7; c++) {
-            int p = c;
-            for (int i = c + 1; i < 7; i++) if (std::fabs(A[i][c]) > std::fabs(A[p][c])) p = i;
-            if (std::fabs(A[p][c]) < 1e-300) { singular = true; break; }
-            if (p != c) for (int j = 0; j < 8; j++) std::swap(A[p][j], A[c][j]);
-            for (int i = c + 1; i < 7; i++) {
-                const double f = A[i][c] / A[c][c];
-                for (int j = c; j < 8; j++) A[i][j] -= f * A[c][j];
-            }
-        }
-        if (singular) break;
-        double dz[7];
-        for (int i = 6; i >= 0; i--) {
-            double sum = A[i][7];
-            for (int j = i + 1; j < 7; j++) sum -= A[i][j] * dz[j];
-            dz[i] = sum / A[i][i];
-        }
-        // damped step with bound clamping
-        double lam = 1.0;
-        bool improved = false;
-        for (int ls = 0; ls < 20; ls++) {
-            double zn[7], rn[7];
-            for (int k = 0; k < 7; k++) zn[k] = std::clamp(z[k] + lam * dz[k], lo[k], hi[k]);
-            trim_residuals(M, tp, unpack(zn), env, rn);
-            double cn = 0;
-            for (int i = 0; i < 7; i++) cn += rn[i] * rn[i];
-            if (cn < cost) {
-                for (int k = 0; k < 7; k++) { z[k] = zn[k]; r[k] = rn[k]; }
-                cost = cn; improved = true;
-                break;
-            }
-            lam *= 0.5;
-        }
-        if (!improved) break;
+        if (good && c < cost) { cost = c; for (int k = 0; k < 7; k++) z[k] = zc[k]; if (stats) stats->continued = true; }
     }
     ts = unpack(z);
     if (cost_out) *cost_out = cost;
-    return cost <= 1e-16;  // reference success criterion: STOPVAL_REACHED with stopval = 1e-16
+    return cost <= 1e-16;  // reference success criterion: STOPVAL_REACHED with stopval = 1e-16 (c172.jl:926,934)
 }
 
 }  // namespace fo

@@ -203,13 +203,20 @@ int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, i
     }
     return 0;
 }
+// diagnostics of the trim solver (tests only): 0 = descent from the initial guess only, 1 = with the continuation fallback
+static int g_trim_continuation = 1;
+void fo_set_trim_continuation(int32_t on) { g_trim_continuation = on; }
+static int64_t g_trim_evals = 0, g_trim_continued = 0;
+int64_t fo_trim_evals(void) { return g_trim_evals; }
+int64_t fo_trim_continued(void) { return g_trim_continued; }
 // f_init!(world, TrimParameters) for n aircraft. tp [n x FB_NTP], ts [n x FB_NTS] in/out.
 int32_t fo_c172_trim(int64_t n, const double* tp, double* ts, const double* env, double* x, double* u, int32_t* ui, int32_t* s,
                      int32_t* success, double* cost, int32_t threads) {
     const Env e = env_from(env);
+    int64_t evals = 0, continued = 0;
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
-#pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 16) reduction(+ : evals, continued)
 #endif
     for (int64_t i = 0; i < n; i++) {
         auto TP = [&](int k) { return tp[k * n + i]; };
@@ -221,7 +228,9 @@ int32_t fo_c172_trim(int64_t n, const double* tp, double* ts, const double* env,
         for (int k = 0; k < 5; k++) p.payload[k] = TP(FB_TP_PAYLOAD + k);
         TrimState t{ts[0 * n + i], ts[1 * n + i], ts[2 * n + i], ts[3 * n + i], ts[4 * n + i], ts[5 * n + i], ts[6 * n + i]};
         double c = 0;
-        const bool ok = trim_solve(*g_model, p, e, t, &c);
+        TrimSolveStats stats;
+        const bool ok = trim_solve(*g_model, p, e, t, &c, &stats, g_trim_continuation != 0);
+        evals += stats.evals; continued += stats.continued;
         const double tv[7] = {t.alpha_a, t.phi_nb, t.n_eng, t.throttle, t.aileron, t.elevator, t.rudder};
         for (int k = 0; k < 7; k++) ts[k * n + i] = tv[k];
         double xi[NX];
@@ -233,6 +242,7 @@ int32_t fo_c172_trim(int64_t n, const double* tp, double* ts, const double* env,
         if (success) success[i] = ok;
         if (cost) cost[i] = c;
     }
+    g_trim_evals = evals; g_trim_continued = continued;
     return 0;
 }
 double fo_c172_trim_cost(const double* tp18, const double* ts7, const double* env) {

@@ -50,16 +50,72 @@ def test_trim_default_matches_oracle(fb, oracle):
 
 
 def test_trim_lattice_matches_oracle(fb, oracle):
+    """randomised TrimParameters (location, altitude, EAS, heading, flight-path angle, turn rate, flaps, fuel): the device
+    solver and the oracle's must make the same success / failure call on every aircraft and land on the same trim."""
     n = 2048
     tp = lattice_trim_params(fb, n)
     w = fb.BatchedWorld(n)
     fb.f_init(w, tp)
     ref = oracle.trim(tp.pack(n), fb.TrimState(n), oracle.default_env())
-    # some corners of the lattice are not trimmable (throttle or rpm bound reached): both solvers must agree on which
-    assert (ref["ok"] == w.trim_success).mean() > 0.995
+    assert (ref["ok"] == w.trim_success).all(), f"{(ref['ok'] != w.trim_success).sum()} aircraft with different success flags"
+    ok = ref["ok"]
+    assert ok.mean() > 0.99          # the few that fail ask for a climb at high EAS and altitude with flaps out: no power left
+    assert (w.trim_cost[ok] <= 1e-16).all() and (w.trim_cost[~ok] > 1e-16).all()
+    assert np.max(np.abs(w.trim_state[:, ok] - ref["ts"][:, ok])) < 1e-9
+    assert np.max(np.abs(w.x[:, ok] - ref["x"][:, ok]) / state_scale(ref["x"][:, ok])) < 1e-9
+    w.close()
+
+
+def test_trim_bench_lattice_all_succeed(fb, oracle):
+    """The 32 x 32 (EAS, h) cells of bench.py's config-3 lattice at 16 headings: every aircraft has a trim (throttle <= 0.88)
+    and the solver must find it from TrimState() — including the band EAS 50.5 m/s, h = 1735 ... 2187 m, throttle ~0.70,
+    where round 1's clamped Newton ran into the throttle = 1 corner."""
+    i, j, k = np.meshgrid(np.arange(32), np.arange(32), np.arange(16), indexing="ij")
+    n = i.size
+    EAS = (35.0 + 20.0 * i / 31.0).ravel(); h = (200.0 + 2800.0 * j / 31.0).ravel(); psi = (-np.pi + 2 * np.pi * k / 16.0).ravel()
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+    assert w.trim_success.all(), f"{(~w.trim_success).sum()} of {n} aircraft failed to trim"
+    assert w.trim_cost.max() < 1e-20
+    ts = w.trim_state.reshape(7, 32, 32, 16)
+    band = ts[:, 24, 17:23, :]
+    assert (band[3] > 0.66).all() and (band[3] < 0.75).all() and (band[2] > 0.89).all() and (band[2] < 0.95).all()
+    assert ts[3].max() < 0.9 and ts[2].max() < 1.05
+    sel = np.arange(0, n, 37)
+    ref = oracle.trim(fb.TrimParameters(EAS=EAS[sel], h_e=h[sel], ψ_nb=psi[sel]).pack(len(sel)), fb.TrimState(len(sel)), oracle.default_env())
+    assert ref["ok"].all()
+    assert np.max(np.abs(w.trim_state[:, sel] - ref["ts"])) < 1e-9
+    w.close()
+
+
+def test_trim_wide_envelope_and_hard_cases(fb, oracle):
+    """An envelope wider than the aircraft can fly (28 % of the points have no trim: below the stall speed, beyond the power
+    available) plus the five knot-trapped cases of tests/golden/trim_hard_cases.npz: same success set as the oracle, same
+    trims; failed aircraft stay inside the bounds of c172.jl:901-917."""
+    import os
+    n = 8192
+    rng = np.random.default_rng(23)
+    lat = rng.uniform(-1.4, 1.4, n); lon = rng.uniform(-np.pi, np.pi, n)
+    tp = fb.TrimParameters(n_e=np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)]),
+                           h_e=rng.uniform(150.0, 4000.0, n), ψ_nb=rng.uniform(-np.pi, np.pi, n), EAS=rng.uniform(28.0, 62.0, n),
+                           γ_wb_n=rng.uniform(-0.08, 0.06, n), ψ_wb_dot=rng.uniform(-0.1, 0.1, n), θ_wb_dot=rng.uniform(-0.02, 0.02, n),
+                           β_a=rng.uniform(-0.1, 0.1, n), fuel_load=rng.uniform(0.05, 1.0, n), flaps=rng.choice([0.0, 0.0, 0.33, 0.66, 1.0], n),
+                           payload=rng.uniform(0.0, 90.0, (5, n)))
+    packed = tp.pack(n)
+    hard = np.load(os.path.join(os.path.dirname(__file__), "golden", "trim_hard_cases.npz"))["trim_params"]
+    packed[:, : hard.shape[1]] = hard
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, fb.TrimParameters(n_e=packed[0:3], h_e=packed[3], ψ_nb=packed[4], EAS=packed[5], γ_wb_n=packed[6], ψ_wb_dot=packed[7],
+                                   θ_wb_dot=packed[8], β_a=packed[9], fuel_load=packed[10], mixture=packed[11], flaps=packed[12], payload=packed[13:18]))
+    ref = oracle.trim(packed, fb.TrimState(n), oracle.default_env())
+    assert w.trim_success[: hard.shape[1]].all() and ref["ok"][: hard.shape[1]].all()
+    agree = ref["ok"] == w.trim_success
+    assert agree.mean() >= 0.9995, f"{(~agree).sum()} aircraft with different success flags"
+    assert 0.6 < ref["ok"].mean() < 0.8
     both = ref["ok"] & w.trim_success
-    assert both.mean() > 0.8
-    assert np.max(np.abs(w.trim_state[:, both] - ref["ts"][:, both])) < 1e-7
+    assert np.max(np.abs(w.trim_state[:, both] - ref["ts"][:, both])) < 1e-8
+    lo = np.array([-np.pi / 12, -np.pi / 3, 0.4, 0, -1, -1, -1])[:, None]; hi = np.array([0.36, np.pi / 3, 1.1, 1, 1, 1, 1])[:, None]
+    assert (w.trim_state >= lo - 1e-15).all() and (w.trim_state <= hi + 1e-15).all()
     w.close()
 
 
