@@ -4,22 +4,29 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE.json configs[2] — 1 048 576 Cessna172Sv0 per GPU, randomised trim on the
-32 x 32 x 1024 (EAS x altitude x heading) lattice of SURVEY.md §8(d), order permuted by a fixed LCG
-(seed 172), fp64, dt = 0.01. Synthetic: no recorded data exists for this path.
+Workload (config.workload): BASELINE.json configs[2] — 1 048 576 Cessna172Sv0, randomised trim on the 32 x 32 x 1024
+(EAS x altitude x heading) lattice of SURVEY.md §8(d), order permuted by a fixed LCG (seed 172), fp64, dt = 0.01.
+Synthetic: no recorded data exists for this path.
 
-One "step" of the contract = one pass of the hot path over the batch = ONE launch of the fused stepping
-kernel advancing every aircraft by `--inner` RK4 steps (default 50, i.e. 0.5 s of flight), including all
-RK stages, the output evaluation at the new state and f_step!. Trim, table generation and upload are
-outside the timed region; state is resident in HBM when timing starts.
+One "step" of the contract = one pass of the hot path over the batch = ONE launch of the fused stepping kernel advancing
+every aircraft by `--inner` RK4 steps (default 50, i.e. 0.5 s of flight), including all RK stages, the output evaluation
+at the new state and f_step!. Trim, table generation and upload are outside the timed region; state is resident in HBM
+when timing starts.
 
-Multi-GPU: the batch shards embarrassingly (aircraft are independent): every rank owns its own
-1 048 576 aircraft (weak scaling), no data-path collective; one RCCL all-gather of the final states
-collects the trajectory endpoint after the timed region (reported as gather_ms, not part of `value`).
+Multi-GPU (one process per GPU, aircraft are independent, NO data-path collective). BASELINE's metric is quoted for the
+whole node at N = 1 M, so for --gpus > 1 the default is `--scaling strong`: the SAME 1 048 576 aircraft cut into contiguous
+shards (flightbatch.sharding.shard_range); the weak-scaling figure (1 048 576 aircraft per rank) is measured in the same
+run and attached as "weak_scaling". One RCCL all-gather of the final states collects the trajectory endpoint after the
+timed region (gather_ms, not part of `value`). At --gpus 1 the two coincide.
+
+On one GPU the line also carries, under "extra", one GPU's share of configs[3] (524 288 Cessna172Xv2 with the autopilot at
+Δt = 0.02) and configs[4] (mixed fp32 fleet, 50 % Cessna172Sv0 / 50 % Robot2D), each with its own timing and parity sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,28 +35,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flight.jl_amd"))
 
-N_PER_GPU = 1 << 20
+N_TOTAL = 1 << 20
 DT = 0.01
 BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flags, C172Sv0 fp64
+BYTES_PER_X2_STEP = 756.0         # Cessna172Xv2
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r01p_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r02_counters.json"   # rocprofv3 PMC summary of the CURRENT k_step_air (tools/collect_profile.sh)
 
 
-def lattice(rank: int):
+def lattice(seed_offset: int = 0, n: int = N_TOTAL):
     """config 3 of SURVEY.md §8(d): EAS_i = 35 + 20 i/31, h_j = 200 + 2800 j/31, ψ_k = -π + 2π k/1024,
-    aircraft order permuted by a fixed LCG so neighbouring lanes hold different table cells."""
-    n = N_PER_GPU
+    aircraft order permuted by a fixed LCG so neighbouring lanes hold different table cells. Returns (EAS, h, ψ, cell)
+    with cell = 32 i + j."""
     idx = np.arange(n, dtype=np.uint64)
     a, c = np.uint64(1664525), np.uint64(1013904223)       # full-period LCG modulo 2^20 (a ≡ 1 mod 4, c odd)
-    perm = (a * idx + c + np.uint64(172 + 7919 * rank)) & np.uint64(n - 1)
+    perm = (a * idx + c + np.uint64(172 + 7919 * seed_offset)) & np.uint64(N_TOTAL - 1)
     i = (perm >> np.uint64(15)) & np.uint64(31)
     j = (perm >> np.uint64(10)) & np.uint64(31)
     k = perm & np.uint64(1023)
     EAS = 35.0 + 20.0 * i.astype(np.float64) / 31.0
     h = 200.0 + 2800.0 * j.astype(np.float64) / 31.0
     psi = -np.pi + 2 * np.pi * k.astype(np.float64) / 1024.0
-    return EAS, h, psi
+    return EAS, h, psi, (i * np.uint64(32) + j).astype(np.int64)
+
+
+def stratified_sample(cell: np.ndarray, per_cell: int = 4, seed: int = 2) -> np.ndarray:
+    """indices drawn over the WHOLE permuted batch, `per_cell` from every (EAS, h) cell present (1024 cells x 4 = 4096)"""
+    rng = np.random.default_rng(seed)
+    order = np.argsort(cell, kind="stable")
+    bounds = np.flatnonzero(np.diff(cell[order])) + 1
+    groups = np.split(order, bounds)
+    return np.sort(np.concatenate([rng.choice(g, size=min(per_cell, g.size), replace=False) for g in groups]))
 
 
 def usable_cores() -> int:
@@ -72,13 +89,17 @@ def usable_cores() -> int:
     return min(n, 16) if n > 64 else n   # no quota visible on a 128-CPU host: stay within the documented 16-core share
 
 
-def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
-    """The CPU oracle (a C++ port of the reference path) timed on this box's host cores on a bounded
-    sample of the same workload. Reference-like arithmetic: 6 RHS evaluations per step, as
-    OrdinaryDiffEq's RK4 does with Flight.jl's state-modifying step callback (BASELINE.md B0/B1)."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import Oracle
-    orc = Oracle()
+    return Oracle()
+
+
+def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
+    """The CPU oracle (a C++ port of the reference path — NOT the Julia reference, which cannot run here) timed on this box's
+    host cores on a bounded sample of the same workload. Reference-like arithmetic: 6 RHS evaluations per step, as
+    OrdinaryDiffEq's RK4 does with Flight.jl's state-modifying step callback (BASELINE.md B0/B1)."""
+    orc = _oracle()
     threads = min(orc.max_threads(), usable_cores())   # the cores this process may actually use
     env = orc.default_env()
     m = min(16384, x0.shape[1])
@@ -100,88 +121,60 @@ def cpu_baseline(x0, u0, ui0, s0, budget_s=15.0):
     el1 = time.perf_counter() - t1
     return {"value": m * nsteps / el, "unit": "aircraft-steps/s", "cores": threads, "kind": "port",
             "sample": f"{m} aircraft of the same lattice x {nsteps} RK4 steps, OpenMP over aircraft, 6 RHS evaluations/step "
-                      f"(reference-like), {el:.1f} s",
+                      f"(reference-like), {el:.1f} s; the port is oracle/ (C++), the Julia reference cannot run on this box",
             "single_core_value": m1 * 100 / el1}
 
 
-def parity_sample(fb, x0, u0, ui0, s0, dtype, m=256, nsteps=1000):
-    """The second half of BASELINE.json's metric ("fp64 rel-err vs CPU"): the first m aircraft of the benchmark batch stepped
-    nsteps times on the GPU and by the CPU oracle from the same initial condition; max over aircraft and states of
-    |x_gpu - x_cpu| / max(|x_cpu|, floor) with the floors of SURVEY.md §8(d) (quaternions 1, rates 1e-3 rad/s, ...)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_binding import Oracle
-    orc = Oracle()
-    sel = slice(0, m)
+def state_floor(xo):
+    """per-state scale max(|xo|, floor) with the floors of SURVEY.md §8(d) (quaternions 1, rates 1e-3 rad/s, ...)"""
+    sc = np.maximum(np.abs(xo), 1e-3)
+    sc[12:20] = 1.0; sc[2:8] = 1.0; sc[10:12] = 1.0; sc[0:2] = np.maximum(np.abs(xo[0:2]), 1e-2); sc[24:27] = np.maximum(np.abs(xo[24:27]), 1.0)
+    return sc
+
+
+def scaled_error(x, xo):
+    return np.abs(x - xo) / state_floor(xo)
+
+
+def parity_sample(fb, x0, u0, ui0, s0, cell, dtype, nsteps=1000):
+    """The second half of BASELINE.json's metric ("fp64 rel-err vs CPU"): a stratified sample of the benchmark batch — four
+    aircraft from every one of the 1024 (EAS, h) cells, drawn over the whole permuted order — stepped nsteps times on the GPU
+    and by the CPU oracle (the C++ port) from the same initial condition."""
+    orc = _oracle()
+    sel = stratified_sample(cell)
     xs, us, uis, ss = (np.ascontiguousarray(x0[:, sel]), np.ascontiguousarray(u0[:, sel]), np.ascontiguousarray(ui0[sel]), np.ascontiguousarray(s0[:, sel]))
+    m = len(sel)
     w = fb.BatchedWorld(m, dtype=dtype)
     w.set_state(xs, ss); w.u = us; w.ui = uis
     sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=50)
     fb.step(sim, nsteps * DT); w.sync()
-    xo, so, sto = orc.step(xs, us, uis, ss, orc.default_env(), DT, nsteps)
+    xo, so, sto = orc.step(xs, us, uis, ss, orc.default_env(), DT, nsteps, threads=min(orc.max_threads(), usable_cores()))
     ok = (sto == 0) & (w.status == 0)
-    sc = np.maximum(np.abs(xo), 1e-3)
-    sc[12:20] = 1.0; sc[2:8] = 1.0; sc[10:12] = 1.0; sc[0:2] = np.maximum(np.abs(xo[0:2]), 1e-2); sc[24:27] = np.maximum(np.abs(xo[24:27]), 1.0)
-    err = float((np.abs(w.x - xo) / sc)[:, ok].max())
+    err = float(scaled_error(w.x, xo)[:, ok].max())
     w.close()
-    return {"max_scaled_error": err, "sample": f"{int(ok.sum())} aircraft x {nsteps} RK4 steps vs the CPU oracle (fp64)", "tolerance": 1e-6 if dtype == "f64" else None}
+    return {"max_scaled_error": err, "against": "oracle/ (C++ port of the reference path; the Julia reference cannot run here)",
+            "sample": f"{int(ok.sum())} aircraft (4 per (EAS, h) cell over the whole batch) x {nsteps} RK4 steps, fp64 oracle",
+            "cells_covered": int(np.unique(cell[sel]).size), "tolerance": 1e-6 if dtype == "f64" else None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("c172s0", "c172x2"), default="c172s0",
-                    help="c172s0: BASELINE.json configs[2] (default, the headline metric). c172x2: configs[3] — 524 288 Cessna172Xv2 per GPU "
-                         "with the autopilot at Δt = 0.02 in the README-example-2 scenario (fp64 only)")
-    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
-                    help="f64: the parity path (default, BASELINE.json's metric). f32: the fp32 airborne stepper (config 5's dtype)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libflightbatch has no CPU path")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import ctypes as C
-    import flightbatch as fb
-
-    x2 = args.workload == "c172x2"
-    if x2 and args.dtype != "f64":
-        raise SystemExit("--workload c172x2 is fp64 only")
-    n = N_PER_GPU // 2 if x2 else N_PER_GPU
-    nrows = fb.K["FB_X2_NX"] if x2 else fb.K["FB_NX"]
-    w = fb.Cessna172Xv2World(n, device=local_rank) if x2 else fb.BatchedWorld(n, device=local_rank, dtype=args.dtype)
+# ---------------------------------------------------------------------------------------------------------------------
+def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
+    """trim + warm-up + the timed region for one shard of the Cessna172Sv0 batch. Returns a dict of measurements (and the
+    initial condition on the host, for the CPU legs)."""
+    n = len(EAS)
+    w = fb.BatchedWorld(n, device=local_rank, dtype=args.dtype)
     # the state lives in a torch tensor so that RCCL can gather it without a host round trip
-    x_dev = torch.zeros((nrows, n), dtype=torch.float64, device="cuda")
+    x_dev = torch.zeros((fb.K["FB_NX"], n), dtype=torch.float64, device="cuda")
     s_dev = torch.zeros((fb.K["FB_NS"], n), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     fb._lib.check(fb.lib.fb_attach_state(w._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(s_dev.data_ptr())))
-    if x2:   # README example 2: default trim, wind N = 1, E = 0.5 m/s, EAS + climb rate (2 m/s), bank + sideslip (30 deg)
-        w.set_params(wind_ned=(1.0, 0.5, 0.0))
-        sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=2)
-        fb.init(sim, fb.TrimParameters())
-        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
-        w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
-    else:
-        EAS, h, psi = lattice(rank)
-        fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
-        sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=args.inner)
-    trim_ok = float(w.trim_success.mean())
-    if not x2:
-        x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+    t0 = time.perf_counter()
+    fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+    trim_s = time.perf_counter() - t0
+    trim_ok = int(w.trim_success.sum())
+    sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=args.inner)
+    ic = (w.x, w.s, w.u, w.ui)
+    fuel0 = ic[0][8].copy()
 
     def barrier():
         if world > 1:
@@ -200,70 +193,290 @@ def main():
     elapsed = time.perf_counter() - t0
     ms = C.c_float(); nl = C.c_int64()
     fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
-    kernel_ms = ms.value / max(nl.value, 1)   # average launch duration of k_step, HIP events on its stream
-
+    out = {"n": n, "elapsed": elapsed, "kernel_ms": ms.value / max(nl.value, 1), "trim_ok": trim_ok, "trim_s": trim_s, "ic": ic}
+    # full-size invariants over ALL aircraft of the shard
+    st = w.status
+    xf = w.x
+    out["status_bad"] = int((st != 0).sum())
+    out["fuel_not_decreasing"] = int((xf[8] >= fuel0).sum())
+    out["quat_off_unit"] = int(((np.abs(np.sqrt((xf[12:16] ** 2).sum(0)) - 1) > 1.1e-8) | (np.abs(np.sqrt((xf[16:20] ** 2).sum(0)) - 1) > 1.1e-8)).sum())
+    out["non_finite"] = int((~np.isfinite(xf)).any(axis=0).sum())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        every = [float(e.item()) for e in every]
+        out["elapsed"] = max(every); out["elapsed_per_rank"] = every
+        cnt = torch.tensor([out["trim_ok"], out["status_bad"], out["fuel_not_decreasing"], out["quat_off_unit"], out["non_finite"], n],
+                           dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt)
+        out["trim_ok"], out["status_bad"], out["fuel_not_decreasing"], out["quat_off_unit"], out["non_finite"], out["n_total"] = [int(v) for v in cnt.tolist()]
         # trajectory collection: ONE RCCL all-gather of the final states over xGMI (north star)
-        torch.cuda.synchronize(); g0 = time.perf_counter()
-        gathered = fb.sharding.all_gather_state(x_dev, n * world)
-        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - g0) * 1e3
-        assert gathered.shape == (nrows, n * world)
+        torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
+        gathered = fb.sharding.all_gather_state(x_dev, out["n_total"])
+        torch.cuda.synchronize(); out["gather_ms"] = (time.perf_counter() - g0) * 1e3
+        assert gathered.shape == (fb.K["FB_NX"], out["n_total"])
+        del gathered
     else:
-        gather_ms = None
+        out["n_total"] = n
+    w.close()
+    del x_dev, s_dev
+    return out
 
-    status_bad = int((w.status != 0).sum())
-    if status_bad > n // 1000:
-        raise SystemExit(f"INVALID RUN: {status_bad} of {n} aircraft terminated (status != 0) — they do no work; refusing to report a throughput")
-    total_units = float(n) * world * args.inner * args.steps
-    value = total_units / elapsed
 
+def check_valid(m, what):
+    n = m["n_total"]
+    if m["trim_ok"] != n:
+        raise SystemExit(f"INVALID RUN ({what}): {n - m['trim_ok']} of {n} aircraft failed to trim; every cell of the lattice has a trim")
+    for key in ("status_bad", "fuel_not_decreasing", "quat_off_unit", "non_finite"):
+        if m[key]:
+            raise SystemExit(f"INVALID RUN ({what}): {key} = {m[key]} of {n} aircraft — refusing to report a throughput")
+
+
+def extra_x2(fb, C, args):
+    """BASELINE.json configs[3], one GPU's share: 524 288 Cessna172Xv2, autopilot every 2 steps, README example 2 scenario."""
+    n = N_TOTAL // 2
+    w = fb.Cessna172Xv2World(n)
+    w.set_params(wind_ned=(1.0, 0.5, 0.0))
+    sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=args.x2_inner)
+    fb.init(sim, fb.TrimParameters())
+    assert w.trim_success.all()
+    w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+    w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+    block = 0.5
+    fb.step(sim, 2 * block); w.sync()
+    fb.lib.fb_timing_begin(w._h)
+    t0 = time.perf_counter()
+    blocks = 6
+    for _ in range(blocks):
+        fb.step(sim, block)
+    w.sync()
+    el = time.perf_counter() - t0
+    ms = C.c_float(); nl = C.c_int64()
+    fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
+    steps = int(round(block / DT)) * blocks
+    bad = int((w.status != 0).sum())
+    w.close()
+    value = n * steps / el
+    gbs = BYTES_PER_X2_STEP * value / 1e9
+    out = {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64",
+           "config": {"workload": f"N={n} Cessna172Xv2 (one GPU's share of configs[3]: 4 194 304 over 8), default trim, README example 2 scenario "
+                                  "(wind, EAS + climb-rate and bank + sideslip modes), autopilot every 2 steps (Δt = 0.02), fp64, dt = 0.01",
+                      "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
+           "stepping_launches": int(nl.value), "kernel_ms": ms.value / max(nl.value, 1), "stream_ms_per_rk4_step": ms.value / steps,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "note": "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d)"}}
+    # parity sample: 512 aircraft on randomised trims, every aircraft in its own pair of modes, 500 closed-loop steps vs the oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleX
+    K = fb.K
+    m = 512
+    rng = np.random.default_rng(31)
+    tp = fb.TrimParameters(h_e=rng.uniform(300.0, 2800.0, m), EAS=rng.uniform(38.0, 52.0, m), ψ_nb=rng.uniform(-np.pi, np.pi, m))
+    gains = fb.ctl_gains.ctl_gains_blob()
+    ws = fb.Cessna172Xv2World(m, gains=gains)
+    sims = fb.Simulation(ws, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=args.x2_inner)
+    fb.init(sims, tp)
+    orc = _oracle()
+    X = OracleX(orc, gains)
+    env = orc.default_env()
+    o = X.trim_init(tp.pack(m), fb.TrimState(m), env, 2 * DT)
+    o["status"] = np.zeros(m, np.int32); o["nstep"] = 0
+    cu = ws.cu
+    cu[K["FB_CU_LON_MODE_REQ"]] = rng.integers(0, 9, m); cu[K["FB_CU_LAT_MODE_REQ"]] = rng.integers(0, 5, m)
+    cu[K["FB_CU_EAS_REF"]] += rng.uniform(-3, 3, m); cu[K["FB_CU_CLM_REF"]] += rng.uniform(-1.5, 1.5, m)
+    cu[K["FB_CU_PHI_REF"]] += rng.uniform(-0.3, 0.3, m); cu[K["FB_CU_CHI_REF"]] += rng.uniform(-0.5, 0.5, m)
+    ws.cu = cu
+    perm = np.array([k if k < K["FB_X2_ACT"] else (27 + k - K["FB_X2_ACT"] if k < K["FB_X2_KIN"] else k - K["FB_NACT"]) for k in range(34)])
+    o["cu"] = np.ascontiguousarray(o["cu"]); o["cu"][:] = cu
+    o["x"][perm] = ws.x; o["cs"] = ws.cs; o["u"] = ws.u; o["ui"] = ws.ui; o["s"] = ws.s
+    fb.step(sims, 5.0); ws.sync()
+    X.step(o, env, DT, 2, 500, threads=min(orc.max_threads(), usable_cores()))
+    ok = (ws.status == 0) & (o["status"] == 0)
+    xo = o["x"][perm]                                   # oracle rows (27 Sv0 rows, then the actuators) in the C ABI's reference order
+    sc = np.ones_like(o["x"]); sc[:27] = state_floor(o["x"][:27])
+    err = (np.abs(ws.x - xo) / sc[perm])[:, ok]
+    out["rel_err_vs_cpu"] = {"max_scaled_error": float(err.max()),
+                             "sample": f"{int(ok.sum())} aircraft, randomised trims and control modes x 500 closed-loop RK4 steps, fp64 oracle (C++ port)",
+                             "tolerance": 1e-6}
+    ws.close()
+    return out
+
+
+def extra_fleet(fb, C, args):
+    """BASELINE.json configs[4] on one GPU: N = 1 M vehicles, 50 % Cessna172Sv0 / 50 % Robot2D interleaved, fp32, dt = 0.01, Δt = 0.02."""
+    n = N_TOTAL
+    KC, KR = fb.K["FB_MODEL_C172S0"], fb.K["FB_MODEL_ROBOT2D"]
+    types = np.where(np.arange(n) % 2 == 0, KC, KR)
+    fleet = fb.MixedFleet(types, {KC: lambda m: fb.BatchedWorld(m, dtype="f32"), KR: lambda m: fb.Robot2DWorld(m, dtype="f32")})
+    fleet.simulate(dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=50)
+    nc = fleet.index[KC].size
+    EAS, h, psi, _ = lattice(1)
+    fleet.init({KC: fb.TrimParameters(EAS=EAS[:nc], h_e=h[:nc], ψ_nb=psi[:nc]), KR: fb.InitParameters()})
+    assert fleet.worlds[KC].trim_success.all()
+    rw = fleet.worlds[KR]
+    u = rw.u; u[0] = 1; u[2] = 0.3; rw.u = u
+    fleet.step(1.0); fleet.sync()
+    T = 3.0
+    cw = fleet.worlds[KC]
+    fb.lib.fb_timing_begin(cw._h)
+    t0 = time.perf_counter(); fleet.step(T); fleet.sync(); el = time.perf_counter() - t0
+    ms = C.c_float(); nl = C.c_int64()
+    fb.lib.fb_timing_end(cw._h, C.byref(ms), C.byref(nl))
+    steps = int(round(T / DT))
+    st = fleet.gather("status", fill=-1)
+    value = n * steps / el
+    # algorithmic bytes per vehicle-step (SURVEY §8d, fp32 rows: the position block of the aircraft stays fp64): see DESIGN.md §5
+    bytes_c, bytes_r = 2 * (27 * 4 + 5 * 4) + 8, 44.0
+    gbs = (bytes_c * nc + bytes_r * (n - nc)) * steps / el / 1e9
+    out = {"metric": "vehicle-steps/sec", "value": value, "unit": "vehicle-steps/s", "dtype": "f32",
+           "config": {"workload": f"mixed fleet N={n}: 50% Cessna172Sv0 (fp32 airborne stepper, randomised trims) / 50% Robot2D (fp32), interleaved input order, "
+                                  "packed by model onto two HIP streams, dt=0.01, Δt=0.02 (BASELINE.json configs[4] on one GPU)", "terminated": int((st != 0).sum())},
+           "kernel_ms": ms.value / max(nl.value, 1), "kernel": "fbf::k_step_f32 (50 steps of 524 288 aircraft per launch)",
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "note": f"algorithmic bytes: {bytes_c} B per fp32 aircraft-step, {bytes_r:.0f} B per fp32 robot-step"}}
+    fleet.close()
+    # parity sample of the fp32 aircraft kernel against the fp64 oracle (physical units: fp32 cannot meet 1e-6)
+    orc = _oracle()
+    m = 1024
+    sel = np.arange(0, nc, nc // m)[:m]
+    w = fb.BatchedWorld(m, dtype="f32")
+    fb.f_init(w, fb.TrimParameters(EAS=EAS[sel], h_e=h[sel], ψ_nb=psi[sel]))
+    x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+    sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=50)
+    fb.step(sim, 10.0); w.sync()
+    xo, so, sto = orc.step(x0, u0, ui0, s0, orc.default_env(), DT, 1000, threads=min(orc.max_threads(), usable_cores()))
+    ok = (sto == 0) & (w.status == 0)
+    d = np.abs(w.x - xo)[:, ok]
+    out["rel_err_vs_cpu"] = {"max_scaled_error": float(scaled_error(w.x, xo)[:, ok].max()), "tolerance": None,
+                             "absolute": {"rates_rad_s": float(d[21:24].max()), "velocity_m_s": float(d[24:27].max()), "altitude_m": float(d[20].max()),
+                                          "q_wb": float(d[12:16].max()), "q_ew": float(d[16:20].max())},
+                             "sample": f"{int(ok.sum())} fp32 aircraft of the fleet's lattice x 1000 RK4 steps vs the fp64 oracle (C++ port)"}
+    w.close()
+    return out
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this process has not touched the GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd).returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
+    ap.add_argument("--x2-inner", type=int, default=50, help="RK4 steps per launch of the Cessna172Xv2 stepper (control laws run inside the launch)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="N > 1: strong (default) = the same 1 048 576 aircraft sharded over the ranks (BASELINE's whole-node metric); "
+                         "weak = 1 048 576 per rank. The other mode is measured too and attached as an extra key")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] legs (1-GPU runs)")
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="f64: the parity path (default, BASELINE.json's metric). f32: the fp32 airborne stepper (config 5's dtype)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+
+    import torch
+    import torch.distributed as dist
+    if torch.cuda.device_count() == 0:      # (does not initialise the GPU)
+        raise SystemExit("bench.py needs a GPU: libflightbatch has no CPU path")
+    if world > 1:   # the process group first: nothing of this process has touched a device before RCCL binds this rank to its GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import ctypes as C
+    import flightbatch as fb
+
+    scaling = args.scaling or "strong"
+    results = {}
+    for mode in ((scaling, "weak" if scaling == "strong" else "strong") if world > 1 else ("weak",)):
+        if mode == "strong":
+            EAS, h, psi, cell = lattice(0)
+            lo, hi = fb.sharding.shard_range(N_TOTAL, rank, world)
+            EAS, h, psi, cell = EAS[lo:hi], h[lo:hi], psi[lo:hi], cell[lo:hi]
+        else:
+            EAS, h, psi, cell = lattice(rank)
+        m = time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world)
+        m["cell"] = cell
+        check_valid(m, mode)
+        results[mode] = m
+    head = results[scaling if world > 1 else "weak"]
+
+    line = None
     if rank == 0:
-        units_per_launch = float(n) * (2 if x2 else args.inner)   # c172x2: one launch group = one control period = 2 RK4 steps
-        bytes_per_unit = 756.0 if x2 else BYTES_PER_AIRCRAFT_STEP
-        achieved_gbs = bytes_per_unit * units_per_launch / (kernel_ms * 1e-3) / 1e9
+        n = head["n"]
+        kernel_ms = head["kernel_ms"]
+        value = float(head["n_total"]) * args.inner * args.steps / head["elapsed"]
+        units_per_launch = float(n) * args.inner
+        achieved_gbs = BYTES_PER_AIRCRAFT_STEP * units_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         valu = None
         prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
-        if os.path.exists(prof) and args.dtype == "f64" and not x2:   # the committed counters describe the fp64 kernel
+        if os.path.exists(prof) and args.dtype == "f64":   # the committed counters describe the fp64 kernel
             pj = json.load(open(prof))
-            if pj.get("n") == n and pj.get("inner") == args.inner:
-                traffic = pj.get("hbm_bytes_per_launch")
+            if pj.get("inner") == args.inner and pj.get("n"):
+                scale = n / pj["n"]                        # counters are per launch of pj["n"] aircraft; traffic and flops are proportional to n
+                traffic = pj.get("hbm_bytes_per_launch") * scale if pj.get("hbm_bytes_per_launch") else None
                 if pj.get("fp64_flops_per_launch"):
-                    tf = pj["fp64_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
+                    tf = pj["fp64_flops_per_launch"] * scale / (kernel_ms * 1e-3) / 1e12
                     valu = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_aircraft_step": pj["fp64_flops_per_launch"] / units_per_launch,
+                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_aircraft_step": pj["fp64_flops_per_launch"] / (pj["n"] * pj["inner"]),
+                            "valu_insts_per_aircraft_step": pj.get("valu_insts_per_aircraft_step"),
                             "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS}
         line = {
             "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True,
+            "scaling": scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("N=524288 Cessna172Xv2 per GPU, default trim, README example 2 scenario (wind, EAS + climb-rate and bank + sideslip "
-                                    "modes), autopilot every 2 steps, fp64, dt=0.01 (BASELINE.json configs[3])") if x2 else
-                                   "N=1048576 Cessna172Sv0 per GPU, randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, "
-                                   "LCG-permuted), " + ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])",
-                       "aircraft_per_gpu": n, "rk4_steps_per_launch": (2 if x2 else args.inner), "rk4_steps_per_contract_step": args.inner, "dt": DT, "parallelism": f"batch-sharded x{world}",
-                       "trim_success_fraction": trim_ok, "terminated_aircraft": status_bad},
+            "config": {"workload": (f"N={head['n_total']} Cessna172Sv0 " + (f"over {world} GPUs (contiguous shards of {n}), " if world > 1 and scaling == "strong" else
+                                                                            ("per GPU, " if world > 1 else "")) +
+                                    "randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, LCG-permuted), " +
+                                    ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])"),
+                       "aircraft_total": head["n_total"], "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "rk4_steps_per_contract_step": args.inner, "dt": DT,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "trim_success_fraction": head["trim_ok"] / head["n_total"], "trim_seconds": head["trim_s"], "terminated_aircraft": head["status_bad"],
+                       "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= 1e-8 (q_wb, q_ew), all states finite"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("fbd::k_step_air<0, false>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "
                                  "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,
         }
-        if gather_ms is not None:
-            line["gather_ms"] = gather_ms
-        if x2:
-            line["roofline"]["kernel"] = "fbd::k_step<true, 0, false> + k_x2_ctl per control period"
-            line["roofline"]["note"] = "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d); kernel_ms = one control period: the 2-step stepping launch, its ground pass and the control-law kernel"
-        if not args.no_cpu_baseline and world == 1 and not x2:
-            line["cpu_baseline"] = cpu_baseline(x0, u0, ui0, s0)
-            line["rel_err_vs_cpu"] = parity_sample(fb, x0, u0, ui0, s0, args.dtype)
-        print(json.dumps(line), flush=True)
+        if world > 1:
+            per = head["elapsed_per_rank"]
+            line["gather_ms"] = head["gather_ms"]
+            line["ms_per_step_ranks"] = {"min": min(per) / args.steps * 1e3, "max": max(per) / args.steps * 1e3}
+            other = results["weak" if scaling == "strong" else "strong"]
+            line[("weak" if scaling == "strong" else "strong") + "_scaling"] = {
+                "value": float(other["n_total"]) * args.inner * args.steps / other["elapsed"], "unit": "aircraft-steps/s",
+                "aircraft_total": other["n_total"], "aircraft_per_gpu": other["n"], "ms_per_step": other["elapsed"] / args.steps * 1e3,
+                "kernel_ms": other["kernel_ms"], "gather_ms": other["gather_ms"]}
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
-    w.close()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            x0, s0, u0, ui0 = head["ic"]
+            line["cpu_baseline"] = cpu_baseline(x0, u0, ui0, s0)
+            line["rel_err_vs_cpu"] = parity_sample(fb, x0, u0, ui0, s0, head["cell"], args.dtype)
+        if world == 1 and not args.no_extra and args.dtype == "f64":
+            head.pop("ic", None)
+            line["extra"] = {"x2": extra_x2(fb, C, args), "fleet": extra_fleet(fb, C, args)}
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

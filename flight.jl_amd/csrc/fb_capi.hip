@@ -310,6 +310,9 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
     if (h) fsal_invalidate(h);
     if (!h || !data || !dims) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
+    // fb_step is asynchronous on the handle's non-blocking stream: the uploads below (null-stream copies, a re-allocated gains
+    // blob) must not overtake stepping kernels that are still queued or running with the old tables
+    HIPCHK(hipStreamSynchronize(h->stream));
     int64_t count = 1;
     for (int k = 0; k < ndims; k++) count *= dims[k];
     if ((kind == FB_TABLE_ROBOT2D) != (h->model == FB_MODEL_ROBOT2D)) return fail("table kind does not belong to this model");
@@ -388,26 +391,26 @@ int32_t fb_get_params(fb_handle h, fb_params* p) {
     return 0;
 }
 
-int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) {
+static int32_t set_state_impl(fb_handle h, const double* x, const int32_t* s, bool init) {
     if (h) fsal_invalidate(h);
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) {
         if (x) { if (int32_t rc = r2_upload(h, h->r2, h->r2->r, x, FB_R2_NX)) return rc; }
-        HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));
+        if (init) HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        h->r2->steps_done = 0;
-        h->t = 0.0;
+        if (init) { h->r2->steps_done = 0; h->t = 0.0; }
         return 0;
     }
     if (x) { if (int32_t rc = copy_rows(h, h->x, x, nullptr, nx_of(h), row_map_of(h))) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
+    if (init) HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->t = 0.0;
-    h->steps_done = 0;
+    if (init) { h->t = 0.0; h->steps_done = 0; }
     return 0;
 }
+int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s) { return set_state_impl(h, x, s, true); }
+int32_t fb_assign_state(fb_handle h, const double* x, const int32_t* s) { return set_state_impl(h, x, s, false); }
 int32_t fb_get_state(fb_handle h, double* x, int32_t* s) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
@@ -576,6 +579,23 @@ int32_t fb_get_outputs(fb_handle h, double* y) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+int32_t fb_get_output_fields(fb_handle h, uint32_t field_mask, double* y) {
+    if (!h || !y) return fail("null argument");
+    if (h->model == FB_MODEL_ROBOT2D) return fail("fb_get_output_fields: Robot2D's output record has no blocks (use fb_get_outputs)");
+    if (!h->y) return fail("no outputs yet: call fb_f_ode first");
+    if (field_mask == 0 || (field_mask & ~(uint32_t)FB_YF_ALL)) return fail("fb_get_output_fields: unknown bits in field_mask 0x%x", field_mask);
+    static const int first[8] = {FB_Y_KIN, FB_Y_AIR, FB_Y_AERO, FB_Y_LDG, FB_Y_PWP, FB_Y_FUEL, FB_Y_DYN, FB_NY};
+    HIPCHK(hipSetDevice(h->device));
+    double* dst = y;
+    for (int b = 0; b < 7; b++) {
+        if (!(field_mask & (1u << b))) continue;
+        const size_t rows = (size_t)(first[b + 1] - first[b]);   // a block's rows are contiguous in the [FB_NY][n] device record
+        HIPCHK(hipMemcpyAsync(dst, h->y + (size_t)first[b] * h->n, sizeof(double) * rows * h->n, hipMemcpyDeviceToHost, h->stream));
+        dst += rows * h->n;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
 
 int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
     if (!h) return fail("null handle");
@@ -587,6 +607,7 @@ int32_t fb_set_steps_per_launch(fb_handle h, int32_t k) {
 static int32_t step_raw(fb_handle h, int64_t nsteps) {
     if (h->model == FB_MODEL_ROBOT2D) return r2_step(h, nsteps);
     if (h->dtype == FB_F32 && h->tables_f32_stale) {   // fp32 mirror of the table blob for the fp32 stepper
+        HIPCHK(hipStreamSynchronize(h->stream));       // kernels already queued still read the old mirror
         std::vector<double> d(TABLE_BUF_DOUBLES);
         HIPCHK(hipMemcpy(d.data(), h->tables, sizeof(double) * TABLE_BUF_DOUBLES, hipMemcpyDeviceToHost));
         std::vector<float> f(d.begin(), d.end());

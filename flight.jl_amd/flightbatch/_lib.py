@@ -39,6 +39,7 @@ def _load():
         "fb_set_params": ([H, C.POINTER(fb_params)], C.c_int32),
         "fb_get_params": ([H, C.POINTER(fb_params)], C.c_int32),
         "fb_set_state": ([H, D, I32], C.c_int32),
+        "fb_assign_state": ([H, D, I32], C.c_int32),
         "fb_get_state": ([H, D, I32], C.c_int32),
         "fb_set_inputs": ([H, D, I32], C.c_int32),
         "fb_get_inputs": ([H, D, I32], C.c_int32),
@@ -47,6 +48,7 @@ def _load():
         "fb_f_step": ([H], C.c_int32),
         "fb_f_periodic": ([H], C.c_int32),
         "fb_get_outputs": ([H, D], C.c_int32),
+        "fb_get_output_fields": ([H, C.c_uint32, D], C.c_int32),
         "fb_set_ctl_inputs": ([H, D], C.c_int32),
         "fb_get_ctl_inputs": ([H, D], C.c_int32),
         "fb_set_ctl_state": ([H, D], C.c_int32),

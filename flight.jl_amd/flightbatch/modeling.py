@@ -155,9 +155,9 @@ class BatchedWorld:
         return x
 
     @x.setter
-    def x(self, v):
+    def x(self, v):   # `mdl.x .= v`: a plain assignment (no init! semantics: clock, periodic phase and status words stay; see set_state)
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.nx, self.n)
-        check(lib.fb_set_state(self._h, _pd(v), None))
+        check(lib.fb_assign_state(self._h, _pd(v), None))
 
     @property
     def s(self) -> np.ndarray:
@@ -168,9 +168,9 @@ class BatchedWorld:
     @s.setter
     def s(self, v):
         v = np.ascontiguousarray(v, dtype=np.int32).reshape(K["FB_NS"], self.n)
-        check(lib.fb_set_state(self._h, None, _pi(v)))
+        check(lib.fb_assign_state(self._h, None, _pi(v)))
 
-    def set_state(self, x, s):
+    def set_state(self, x, s):   # an INITIAL condition: clears the status words, restarts the clock and the periodic phase (fb_set_state)
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.nx, self.n)
         s = np.ascontiguousarray(s, dtype=np.int32).reshape(K["FB_NS"], self.n)
         check(lib.fb_set_state(self._h, _pd(x), _pi(s)))
@@ -204,6 +204,18 @@ class BatchedWorld:
         check(lib.fb_get_outputs(self._h, _pd(y)))
         return y
 
+    def y_fields(self, *blocks: str) -> np.ndarray:
+        """mdl.y.<block>... of the last f_ode!: only the named blocks ("KIN", "AIR", "AERO", "LDG", "PWP", "FUEL", "DYN") are
+        copied from the device, stacked in FB_Y_* order: [sum of widths, n]."""
+        mask = 0
+        for b in blocks:
+            mask |= K["FB_YF_" + b.upper()]
+        first = [K[k] for k in ("FB_Y_KIN", "FB_Y_AIR", "FB_Y_AERO", "FB_Y_LDG", "FB_Y_PWP", "FB_Y_FUEL", "FB_Y_DYN")] + [K["FB_NY"]]
+        rows = sum(first[i + 1] - first[i] for i in range(7) if mask & (1 << i))
+        y = np.empty((rows, self.n))
+        check(lib.fb_get_output_fields(self._h, mask, _pd(y)))
+        return y
+
     @property
     def status(self) -> np.ndarray:
         st = np.empty(self.n, dtype=np.int32)
@@ -228,7 +240,7 @@ class BatchedWorld:
         if "s" in self._CKPT_ARRAYS:
             self.set_state(ck["x"], ck["s"])
         else:
-            self.x = ck["x"]
+            self.set_state(ck["x"], None)
         for k in self._CKPT_ARRAYS:
             if k not in ("x", "s"):
                 setattr(self, k, ck[k])
@@ -320,11 +332,22 @@ class Simulation:
         self._rows = np.array(rows + ([K["FB_LOG_X0"] + k for k in range(nx)] if save_x else []), dtype=np.int32)
         k = steps_per_launch or (self.save_every if save_on else 50)
         check(lib.fb_set_steps_per_launch(mdl._h, int(k)))
+        self._manual_save = False
         if save_on and self._rows.size:
             want = int(np.ceil((self.t_end - self.t_start) / (self.save_every * self.dt))) + 2
             budget = int(log_capacity) if log_capacity else max(2, int(8e9 // (8 * self._rows.size * mdl.n)))   # <= 8 GB by default
+            if log_capacity is None and budget < want:
+                # the reference's defaults (save_on, t_end = 10000) would need more device memory than the 8 GB default budget for a
+                # batch this large: refuse now instead of failing half-way through a step! with "log capacity exhausted"
+                raise ValueError(f"Simulation: saving {self._rows.size} rows of {mdl.n} vehicles every {self.save_every} steps until t_end = {self.t_end} "
+                                 f"needs {want} samples, the default 8 GB log holds {budget}; pass t_end / saveat / save_x=False / save_rows, "
+                                 f"log_capacity=<samples> (explicit), or save_on=False")
             self.capacity = min(want, budget)
-            check(lib.fb_log_configure(mdl._h, self.save_every, self.capacity, _pi(self._rows), int(self._rows.size)))
+            # with a user callback the sample must be taken AFTER it (CallbackSet order cb_step, cb_periodic, cb_user, cb_save: FC/sim.jl:204-218):
+            # the device log is then driven from step() instead of from inside fb_step
+            self._manual_save = user_callback is not None
+            every = (1 << 62) if self._manual_save else self.save_every
+            check(lib.fb_log_configure(mdl._h, every, self.capacity, _pi(self._rows), int(self._rows.size)))
         else:
             self.save_on = False
             check(lib.fb_log_configure(mdl._h, 0, 0, None, 0))
@@ -373,17 +396,44 @@ def step(sim: Simulation, Δt_total: float | None = None, stop_at_tdt: bool = Tr
     """step!(sim) / step!(sim, Δt_total, true): FC/sim.jl:386 (OrdinaryDiffEq step!). Asynchronous: the launches (and the
     device-side saves between them) are queued on the world's stream."""
     n = 1 if Δt_total is None else int(round(Δt_total / sim.dt))
+    def _count():
+        cnt = C.c_int64()
+        check(lib.fb_get_step_count(sim.mdl._h, C.byref(cnt)))   # host-side bookkeeping, no device synchronisation
+        return int(cnt.value)
+
+    before = _count()
+
+    def _resync():   # a failing fb_step (log capacity exhausted, ...) may have advanced part of the steps: follow the device's clock
+        nonlocal before
+        now = _count()
+        sim._nstep += now - before
+        before = now
+        sim.mdl.t = sim.t
+
     if sim.user_callback is None:
-        check(lib.fb_step(sim.mdl._h, n))
+        try:
+            check(lib.fb_step(sim.mdl._h, n))
+        except Exception:
+            _resync()
+            raise
         sim._nstep += n
         sim.mdl.t = sim.t
         return None
-    # cb_user_affect! (FC/sim.jl:331-341) runs on the host after EVERY step: launches are one step long while a callback is set
+    # cb_user_affect! (FC/sim.jl:331-341) runs on the host after EVERY step: launches are one step long while a callback is set;
+    # cb_save comes after it (FC/sim.jl:217), so the saved sample sees the callback's changes. (Remaining difference: the reference
+    # saves the y of the step's last f_ode!, taken before the callbacks; fb_log_record re-evaluates f_ode! at the saved instant.)
     for _ in range(n):
-        check(lib.fb_step(sim.mdl._h, 1))
+        try:
+            check(lib.fb_step(sim.mdl._h, 1))
+        except Exception:
+            _resync()
+            raise
         sim._nstep += 1
+        before += 1
         sim.mdl.t = sim.t
         sim.user_callback(sim.mdl)
+        if sim._manual_save and sim._nstep % sim.save_every == 0:
+            check(lib.fb_log_record(sim.mdl._h))
     return None
 
 

@@ -80,12 +80,13 @@ class Robot2DWorld(BatchedWorld):
         return x
 
     @x.setter
-    def x(self, v):
+    def x(self, v):   # `mdl.x .= v`: a plain assignment (no init! semantics: clock, periodic phase and status words stay; see set_state)
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(self.nx, self.n)
-        check(lib.fb_set_state(self._h, _pd(v), None))
+        check(lib.fb_assign_state(self._h, _pd(v), None))
 
-    def set_state(self, x, s=None):
-        self.x = x
+    def set_state(self, x, s=None):   # an INITIAL condition: clears the status words, restarts the clock (fb_set_state)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.nx, self.n)
+        check(lib.fb_set_state(self._h, _pd(x), None))
 
     @property
     def s(self):

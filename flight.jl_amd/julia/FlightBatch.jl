@@ -24,7 +24,7 @@ module FlightBatch
 using Flight.FlightCore.Modeling: ModelDefinition
 import Flight.FlightCore.Modeling: f_init!, f_ode!, f_step!, f_periodic!
 using Flight.FlightApps: C172
-using Flight.FlightPhysics: Propellers, Piston, Geodesy
+using Flight.FlightPhysics: Propellers, Piston, Geodesy, Control
 
 const lib = get(ENV, "FLIGHTBATCH_LIB", "libflightbatch")
 
@@ -65,7 +65,32 @@ mutable struct BatchedWorld <: ModelDefinition
         return w
     end
 end
-pack_ctl_gains(ctl)::Vector{Float64} = error("see flightbatch/ctl_gains.py: ctl_gains_blob() for the layout to replicate")
+
+# ---- FB_TABLE_CTL_GAINS: the ten gain-scheduling lookups of ControlLawsLon / ControlLawsLat (c172x_ctl.jl:203-213, 814-819), each a
+# PIDData / LQRData of `extrapolate(scale(interpolate(points, BSpline(Linear())), EAS_range, h_range), Flat())` objects
+# (FP/control.jl:950-972). Blob layout (include/flightbatch.h; executed twin: flightbatch/ctl_gains.py `_pack`): per lookup a 6-double
+# header [nE, nH, EAS_lo, EAS_hi, h_lo, h_hi], then for every grid point — h slowest, EAS next — one record:
+#   LQR: vec(K_fbk) (column-major NU x NX), vec(K_fwd), vec(K_int), x_trim, u_trim, z_trim      PID: k_p, k_i, k_d, τ_f
+scaled_coefs(e) = e.itp.itp.coefs            # Extrapolation -> ScaledInterpolation -> BSplineInterpolation (Linear(): coefs == the data array)
+scaled_ranges(e) = e.itp.ranges
+function pack_lookup(fields::Vector)
+    rE, rH = scaled_ranges(fields[1])
+    nE, nH = length(rE), length(rH)
+    blob = Float64[nE, nH, first(rE), last(rE), first(rH), last(rH)]
+    for j in 1:nH, i in 1:nE, f in fields
+        @assert scaled_ranges(f) == (rE, rH)
+        append!(blob, vec(collect(Float64, scaled_coefs(f)[i, j])))      # SMatrix / SVector: column-major; scalar: one value
+    end
+    return blob
+end
+pack_lookup(l::Control.LQRData) = pack_lookup(Any[l.K_fbk, l.K_fwd, l.K_int, l.x_trim, l.u_trim, l.z_trim])
+pack_lookup(l::Control.PIDData) = pack_lookup(Any[l.k_p, l.k_i, l.k_d, l.τ_f])
+"blob order of include/flightbatch.h: te2te, tv2te, vh2te, q2e, c2θ, v2t (lon), ar2ar, φβ2ar, p2φ, χ2φ (lat)"
+function pack_ctl_gains(ctl)::Vector{Float64}
+    (; lon, lat) = ctl
+    vcat(map(pack_lookup, (lon.te2te_lookup, lon.tv2te_lookup, lon.vh2te_lookup, lon.q2e_lookup, lon.c2θ_lookup, lon.v2t_lookup,
+                           lat.ar2ar_lookup, lat.φβ2ar_lookup, lat.p2φ_lookup, lat.χ2φ_lookup))...)
+end
 
 # avionics.ctl.u / avionics.gdc.u and the control laws' record, as N x NCU / N x NCS matrices (columns = FB_CU_* / FB_CS_*)
 ctl_inputs(w::BatchedWorld) = (cu = Matrix{Float64}(undef, w.n, NCU);
@@ -95,16 +120,76 @@ function upload_tables!(w::BatchedWorld)
     set_table!(w, TABLE_AERO, pack_aero(C172.aero_lookup))
 end
 
-# The two packers read the interpolation objects' knots/coefs and lay them out as csrc/tables.h documents
-# (AT_* / PT_* offsets); flightbatch/tables.py is the executed equivalent and serves as their specification.
-pack_piston(lookup)::Vector{Float64} = error("see flightbatch/tables.py: piston_blob() for the layout to replicate")
-pack_aero(lookup)::Vector{Float64} = error("see flightbatch/tables.py: aero_blob() for the layout to replicate")
+# The two packers read the interpolation objects' knots / coefs and lay them out as csrc/tables.h documents (AT_* / PT_* offsets,
+# 0-based, in doubles; 2-D tables column-major like the Julia arrays); flightbatch/tables.py (`piston_blob`, `aero_blob`) is the
+# executed twin and tests/test_host_and_abi.py checks it against the oracle's builders.
+#   linear_interpolation(knots, data, extrapolation_bc = ...) == extrapolate(interpolate(knots, data, Gridded(Linear())), ...):
+#       .itp.knots :: Tuple of knot vectors, .itp.coefs :: the data array
+#   extrapolate(scale(interpolate(A, BSpline(Linear())), ranges...), Line()): .itp.ranges, .itp.itp.coefs (see scaled_coefs above)
+gridded_knots(e) = e.itp.knots
+gridded_coefs(e) = e.itp.coefs
+put!(b::Vector{Float64}, off0::Integer, a) = (v = vec(collect(Float64, a)); b[off0 + 1 : off0 + length(v)] .= v; b)
+
+# csrc/tables.h PT_* offsets
+const PT_DELTA_WOT_V, PT_MU_WOT_V, PT_PISTD_N_K, PT_PISTD_MU_K, PT_PISTD_V, PT_PIWOT_N_K, PT_PIWOT_D_K, PT_PIWOT_V = 0, 18, 36, 49, 52, 91, 96, 99
+const PT_F_K, PT_PI_RATIO_V, PT_SFC_RATIO_V, PT_SFC_N_K, PT_SFC_PI_K, PT_SFC_POW_V, PT_SIZE = 114, 125, 136, 147, 152, 160, 200
+"PistonEngineLookup (FP/piston.jl:60-195) -> the FB_TABLE_PISTON blob"
+function pack_piston(l)::Vector{Float64}
+    b = zeros(PT_SIZE)
+    # δ_wot(n, μ), μ_wot(n, δ): scaled B-splines on fixed ranges the kernels know (piston.jl:78-79, 92-93); only the 2 x 9 samples travel
+    @assert scaled_ranges(l.δ_wot) == (range(0.667, 1, length = 2), range(0.401, 0.936, length = 9))
+    @assert scaled_ranges(l.μ_wot) == (range(0.667, 1, length = 2), range(0.441, 1, length = 9))
+    put!(b, PT_DELTA_WOT_V, scaled_coefs(l.δ_wot)); put!(b, PT_MU_WOT_V, scaled_coefs(l.μ_wot))
+    n13, μ3 = gridded_knots(l.π_std)                       # π_std(n, μ): 13 x 3, Flat (piston.jl:110-133)
+    put!(b, PT_PISTD_N_K, n13); put!(b, PT_PISTD_MU_K, μ3); put!(b, PT_PISTD_V, gridded_coefs(l.π_std))
+    n5, δ3 = gridded_knots(l.π_wot)                        # π_wot(n, δ): 5 x 3 (piston.jl:140-149)
+    put!(b, PT_PIWOT_N_K, n5); put!(b, PT_PIWOT_D_K, δ3); put!(b, PT_PIWOT_V, gridded_coefs(l.π_wot))
+    (f11,) = gridded_knots(l.π_ratio)                      # π_ratio(f), sfc_ratio(f): 11 knots shared (piston.jl:157-172)
+    @assert gridded_knots(l.sfc_ratio)[1] == f11
+    put!(b, PT_F_K, f11); put!(b, PT_PI_RATIO_V, gridded_coefs(l.π_ratio)); put!(b, PT_SFC_RATIO_V, gridded_coefs(l.sfc_ratio))
+    nsfc, πsfc = gridded_knots(l.sfc_pow)                  # sfc_pow(n, π): 5 x 8, Line (piston.jl:179-189)
+    put!(b, PT_SFC_N_K, nsfc); put!(b, PT_SFC_PI_K, πsfc); put!(b, PT_SFC_POW_V, gridded_coefs(l.sfc_pow))
+    return b
+end
+
+# csrc/tables.h AT_* offsets
+const AT_GE_K, AT_CD_GE_V, AT_CL_GE_V, AT_DF4_K, AT_CD_DF_V, AT_CL_DF_V, AT_CM_DF_V, AT_UNIT3_K, AT_CD_DE_V, AT_CD_BETA_V = 0, 13, 26, 39, 43, 47, 51, 55, 58, 61
+const AT_CD_ALPHA_K, AT_CD_ALPHA_DF_V, AT_CY_BETA_K, AT_DF2_K, AT_CY_BETA_DF_V, AT_ALPHA2_K, AT_CY_P_V, AT_CY_R_V, AT_CL_R_V = 64, 90, 194, 197, 199, 205, 207, 211, 215
+const AT_CL_ALPHA_K, AT_CL_ALPHA_V, AT_SCALARS, AT_SIZE = 219, 236, 270, 291
+"C172.aero_lookup (FA/c172/c172.jl:51-205: NamedTuple of scalars and Gridded(Linear()) / Flat() interpolations) -> the FB_TABLE_AERO blob"
+function pack_aero(l)::Vector{Float64}
+    (; C_D, C_Y, C_L, C_l, C_m, C_n) = l
+    b = zeros(AT_SIZE)
+    k1(e) = gridded_knots(e)[1]
+    @assert k1(C_D.ge) == k1(C_L.ge)                        # ground-effect tables share their 13 knots (c172.jl:67, 117)
+    put!(b, AT_GE_K, k1(C_D.ge)); put!(b, AT_CD_GE_V, gridded_coefs(C_D.ge)); put!(b, AT_CL_GE_V, gridded_coefs(C_L.ge))
+    @assert k1(C_D.δf) == k1(C_L.δf) == k1(C_m.δf) == gridded_knots(C_D.α_δf)[2]
+    put!(b, AT_DF4_K, k1(C_D.δf)); put!(b, AT_CD_DF_V, gridded_coefs(C_D.δf)); put!(b, AT_CL_DF_V, gridded_coefs(C_L.δf)); put!(b, AT_CM_DF_V, gridded_coefs(C_m.δf))
+    @assert k1(C_D.δe) == k1(C_D.β)
+    put!(b, AT_UNIT3_K, k1(C_D.δe)); put!(b, AT_CD_DE_V, gridded_coefs(C_D.δe)); put!(b, AT_CD_BETA_V, gridded_coefs(C_D.β))
+    put!(b, AT_CD_ALPHA_K, gridded_knots(C_D.α_δf)[1]); put!(b, AT_CD_ALPHA_DF_V, gridded_coefs(C_D.α_δf))       # 26 x 4
+    put!(b, AT_CY_BETA_K, gridded_knots(C_Y.β_δf)[1]); put!(b, AT_DF2_K, gridded_knots(C_Y.β_δf)[2]); put!(b, AT_CY_BETA_DF_V, gridded_coefs(C_Y.β_δf))   # 3 x 2
+    @assert gridded_knots(C_Y.p) == gridded_knots(C_Y.r) == gridded_knots(C_l.r) && gridded_knots(C_Y.p)[2] == gridded_knots(C_Y.β_δf)[2]
+    put!(b, AT_ALPHA2_K, gridded_knots(C_Y.p)[1]); put!(b, AT_CY_P_V, gridded_coefs(C_Y.p)); put!(b, AT_CY_R_V, gridded_coefs(C_Y.r)); put!(b, AT_CL_R_V, gridded_coefs(C_l.r))
+    put!(b, AT_CL_ALPHA_K, gridded_knots(C_L.α)[1]); put!(b, AT_CL_ALPHA_V, gridded_coefs(C_L.α))                 # 17 x 2 (stall 0 / 1)
+    put!(b, AT_SCALARS, Float64[C_D.z, C_Y.δr, C_Y.δa, C_L.δe, C_L.q, C_L.α_dot, C_l.δa, C_l.δr, C_l.β, C_l.p,          # AS_* order of csrc/tables.h
+                                C_m.z, C_m.δe, C_m.α, C_m.q, C_m.α_dot, C_n.δr, C_n.δa, C_n.β, C_n.p, C_n.r])
+    return b
+end
 
 # ---- the verbs --------------------------------------------------------------------------------------------
 state(w::BatchedWorld) = (x = Matrix{Float64}(undef, w.n, w.nx); s = Matrix{Int32}(undef, w.n, NS);
     check(ccall((:fb_get_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Int32}), w.handle, x, s)); x)
 outputs(w::BatchedWorld) = (y = Matrix{Float64}(undef, w.n, NY);
     check(ccall((:fb_get_outputs, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, y)); y)
+
+"`outputs(world, mask)`: only the blocks of mdl.y named by the FB_YF_* bits (KIN = 1, AIR = 2, AERO = 4, LDG = 8, PWP = 16, FUEL = 32, DYN = 64)"
+function outputs(w::BatchedWorld, mask::Integer)
+    first = (0, 40, 62, 78, 111, 133, 134, NY)
+    rows = sum(first[i + 1] - first[i] for i in 1:7 if mask & (1 << (i - 1)) != 0)
+    y = Matrix{Float64}(undef, w.n, rows)
+    check(ccall((:fb_get_output_fields, lib), Cint, (Ptr{Cvoid}, UInt32, Ptr{Cdouble}), w.handle, mask, y)); y
+end
 
 "f_init!(world, C172.TrimParameters()) — one trim per aircraft, on the device."
 function f_init!(w::BatchedWorld, trim::C172.TrimParameters)

@@ -222,8 +222,12 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
 int32_t fb_set_params(fb_handle h, const fb_params* p);
 int32_t fb_get_params(fb_handle h, fb_params* p);
 
-/* mdl.x / mdl.s / mdl.u access : FC/modeling.jl:89-101 ; property forwarding FC/sim.jl:261-275 */
+/* mdl.x / mdl.s / mdl.u access : FC/modeling.jl:89-101 ; property forwarding FC/sim.jl:261-275.
+ * fb_set_state sets an INITIAL condition: like init! (FC/sim.jl:390-414) it also clears the sticky status words and restarts the
+ * clock and the phase of the periodic update. fb_assign_state is the plain `mdl.x .= v` / `mdl.s = v` of a user callback in the
+ * middle of a run (FC/sim.jl:331-341): t, the step count and the status words stay as they are. */
 int32_t fb_set_state(fb_handle h, const double* x, const int32_t* s);
+int32_t fb_assign_state(fb_handle h, const double* x, const int32_t* s);
 int32_t fb_get_state(fb_handle h, double* x, int32_t* s);
 int32_t fb_set_inputs(fb_handle h, const double* u, const int32_t* ui);
 int32_t fb_get_inputs(fb_handle h, double* u, int32_t* ui);
@@ -257,6 +261,11 @@ int32_t fb_set_ctl_state(fb_handle h, const double* cs);
 int32_t fb_get_ctl_state(fb_handle h, double* cs);
 /* mdl.y of the last fb_f_ode / fb_step : y [N x FB_NY] */
 int32_t fb_get_outputs(fb_handle h, double* y);
+/* The same with SURVEY.md §8(b)'s field mask: only the blocks of the output record named by `field_mask` (FB_YF_* bits) cross
+ * PCIe, packed one after the other in FB_Y_* order: y [N x (sum of the selected blocks' widths)] (reading `mdl.y.vehicle.kinematics`
+ * alone costs 320 B per aircraft instead of 1392). fb_get_outputs(h, y) == fb_get_output_fields(h, FB_YF_ALL, y). */
+enum { FB_YF_KIN = 1, FB_YF_AIR = 2, FB_YF_AERO = 4, FB_YF_LDG = 8, FB_YF_PWP = 16, FB_YF_FUEL = 32, FB_YF_DYN = 64, FB_YF_ALL = 127 };
+int32_t fb_get_output_fields(fb_handle h, uint32_t field_mask, double* y);
 
 /* nsteps x step!(sim) : FC/sim.jl:386 — RK4 (OrdinaryDiffEq, fixed dt) + callbacks in the order
  * cb_step, cb_periodic, cb_user(no-op), FC/sim.jl:204-218. Asynchronous on the handle's stream. */

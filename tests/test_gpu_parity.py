@@ -168,7 +168,7 @@ def test_step_trajectory_matches_oracle(fb, oracle):
     x[24:27] += rng.normal(0, 1.0, (3, n))
     w.set_state(x, w.s)
     x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
-    sim = fb.Simulation(w, dt=0.01, save_on=True, saveat=1.0)
+    sim = fb.Simulation(w, dt=0.01, t_end=10.0, save_on=True, saveat=1.0)
     fb.init(sim)
     fb.step(sim, 10.0)
     ts = fb.TimeSeries(sim)
@@ -538,6 +538,74 @@ def test_rccl_gather_state_single_rank(fb):
         assert "STEPPED_OK" in out, "the child hung before reaching RCCL: " + out[-2000:]
         pytest.skip("RCCL communicator initialisation did not return on this box within 150 s")
     assert "RCCL_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_rccl_gather_state_two_ranks(fb):
+    """fb_comm_init / fb_gather_state with world = 2: two child processes, one GPU each, the unique id handed over through a file.
+    Needs two visible devices (the per-round GPU box has one: skipped there; the 8-GPU node runs it). Rank r trims its own shard
+    (flightbatch.sharding.shard_range of 8192 aircraft) and both must end up with the same gathered [2][27][n] panel."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import textwrap
+    import torch
+    if torch.cuda.device_count() < 2:      # counting devices does not initialise the GPU
+        pytest.skip("fb_gather_state with 2 ranks needs 2 GPUs; this box has %d" % torch.cuda.device_count())
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys, time, numpy as np
+        rank, idfile, outfile = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+        sys.path.insert(0, os.path.join(os.getcwd(), "flight.jl_amd"))
+        import flightbatch as fb
+        hip = C.CDLL("libamdhip64.so")
+        N = 8192
+        lo, hi = fb.sharding.shard_range(N, rank, 2)
+        n = hi - lo
+        w = fb.BatchedWorld(n, device=rank)
+        fb.f_init(w, fb.TrimParameters(EAS=np.linspace(40, 50, N)[lo:hi]))
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=10)
+        fb.step(sim, 0.1); w.sync()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            fb._lib.check(fb.lib.fb_comm_unique_id(uid))
+            open(idfile + ".tmp", "wb").write(uid.raw); os.replace(idfile + ".tmp", idfile)
+        else:
+            t0 = time.time()
+            while not os.path.exists(idfile):
+                assert time.time() - t0 < 60, "rank 0 never published the unique id"
+                time.sleep(0.05)
+            uid = C.create_string_buffer(open(idfile, "rb").read(), 128)
+        comm = C.c_void_p()
+        fb._lib.check(fb.lib.fb_comm_init(w._h, 2, rank, uid, C.byref(comm)))
+        recv = C.c_void_p()
+        assert hip.hipSetDevice(rank) == 0 and hip.hipMalloc(C.byref(recv), C.c_size_t(2 * 27 * n * 8)) == 0
+        fb._lib.check(fb.lib.fb_gather_state(w._h, comm, recv))
+        w.sync()
+        out = np.zeros((2, 27, n))
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), recv, C.c_size_t(out.nbytes), 2) == 0
+        assert np.array_equal(out[rank], w.x), "own shard differs in the gathered panel"
+        np.save(outfile, out)
+        fb._lib.check(fb.lib.fb_comm_destroy(comm))
+        print("RANK_OK", rank)
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        idfile = os.path.join(tmp, "uid")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(r), idfile, os.path.join(tmp, f"out{r}.npy")], cwd=root, env=env,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = []
+        for p_ in procs:
+            try:
+                outs.append(p_.communicate(timeout=240)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+        for r, o in enumerate(outs):
+            assert f"RANK_OK {r}" in o, o[-3000:]
+        g0, g1 = np.load(os.path.join(tmp, "out0.npy")), np.load(os.path.join(tmp, "out1.npy"))
+        assert np.array_equal(g0, g1) and not np.array_equal(g0[0], g0[1])
 
 
 def test_takeoff_ground_to_air_handover(fb, oracle):

@@ -65,6 +65,30 @@ def test_robot2d_reference_closed_loop_scenario(fb):
     w.close()
 
 
+def test_saved_sample_is_taken_after_the_user_callback(fb):
+    """CallbackSet order cb_step, cb_periodic, cb_user, cb_save (FC/sim.jl:204-218): what the user callback changes is in the sample
+    saved at that instant. And the constructor refuses a log that cannot hold the run instead of failing half-way."""
+    n = 64
+    w = fb.Robot2DWorld(n)
+
+    def cb(mdl):
+        x = mdl.x; x[3] = mdl.t; mdl.x = x          # overwrite the position state with the clock
+
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, t_end=0.5, saveat=0.1, user_callback=cb)
+    fb.init(sim, fb.InitParameters())
+    fb.run(sim)
+    ts = fb.TimeSeries(sim)
+    assert len(ts) == 6 and np.allclose(ts.t, 0.1 * np.arange(6))
+    assert np.array_equal(ts.x[1:, 3, :], np.repeat((0.01 * np.arange(10, 51, 10))[:, None], n, axis=1))
+    assert np.array_equal(ts.x[-1], w.x)
+    w.close()
+    big = fb.Robot2DWorld(1 << 20)
+    with pytest.raises(ValueError, match="log"):
+        fb.Simulation(big, dt=0.01)                  # the reference's defaults: save every step until t = 10000
+    fb.Simulation(big, dt=0.01, save_on=False)
+    big.close()
+
+
 def test_robot2d_lost_balance_freezes(fb):
     w = fb.Robot2DWorld(128)
     fb.f_init(w, fb.InitParameters())

@@ -1,8 +1,8 @@
 # Emits true-reference fixtures in this repository's golden format (tests/golden/c172s0_config1.npz keys),
 # for anyone who has Julia 1.12 + Flight.jl. Run from a Flight.jl checkout:
-#     julia --project tools/gen_golden.jl out_dir
-# Writes raw little-endian Float64 files (one per array, column-major) plus a manifest; tests/golden/
-# from_julia.py (not needed until such files exist) would repack them as .npz.
+#     julia --project tools/gen_golden.jl <this repo>/tests/golden/julia
+# Writes raw little-endian Float64 files (one per array, column-major). tests/golden/from_julia.py reads them and
+# tests/test_julia_fixtures.py then checks the CPU oracle AND the GPU path against them at 1e-6 (it skips while they are absent).
 using Flight
 out = length(ARGS) > 0 ? ARGS[1] : "."
 world = SimpleWorld(; aircraft = Cessna172Sv0()) |> Model
