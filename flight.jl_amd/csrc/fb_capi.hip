@@ -759,6 +759,19 @@ int32_t fb_set_status(fb_handle h, const int32_t* status) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+#ifdef FB_STAMP
+// diagnostic builds only (tools/stamp_profile.py): the per-phase cycle accumulators of c172_device_impl.inc
+int32_t fb_debug_stamps(unsigned long long* acc, unsigned long long* cnt, int32_t reset) {
+    if (acc) HIPCHK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(fbd::g_stamp_acc), sizeof(unsigned long long) * 32));
+    if (cnt) HIPCHK(hipMemcpyFromSymbol(cnt, HIP_SYMBOL(fbd::g_stamp_cnt), sizeof(unsigned long long) * 32));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(fbd::g_stamp_acc), z, sizeof z));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(fbd::g_stamp_cnt), z, sizeof z));
+    }
+    return 0;
+}
+#endif
 int32_t fb_sync(fb_handle h) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
