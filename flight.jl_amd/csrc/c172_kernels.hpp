@@ -15,6 +15,7 @@
 // did modify x or s (quaternion renormalisation, stall flip, engine state change).
 #pragma once
 #include "c172_device.hpp"
+#include "c172x_ctl_device.hpp"
 
 namespace fbd {
 
@@ -121,6 +122,14 @@ struct KArgs {
     int32_t* redo;      // [n] set by the airborne pass of k_step for lanes that came within reach of the ground
     double* k1;         // [FB_NX x n] Cessna172X: derivative left by the last evaluation of the previous launch (FSAL across launches)
     int32_t* k1_valid;  // [n] 1 when k1 is the derivative at the current x, s, u
+    // Cessna172X: f_periodic!(avionics, vehicle) runs INSIDE the stepping kernels, after the f_step! of every step n with
+    // (ctl_phase + n) % ctl_ratio == 0 (cb_periodic after cb_step, FC/sim.jl:204-218, 366-381)
+    const double* gains;  // FB_TABLE_CTL_GAINS blob (global memory, read through scalar loads)
+    CtlOffsets ctl_off;
+    double ctl_dT;        // the control laws' sample period
+    int ctl_ratio;        // Δt / dt (0: never)
+    int ctl_phase;        // steps taken since the last init, modulo ctl_ratio, when the launch starts
+    double* ctl_bak;      // [(FB_NCS + FB_NCU) x n] the airborne pass's copy of cs | cu at launch start (restored for lanes it hands over)
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
@@ -157,6 +166,62 @@ FBD double x2_command(const KArgs& a, int64_t i, int k) {
     }
 }
 template <bool X> struct Dims { static constexpr int NXT = X ? (int)FB_X2_NX : (int)FB_NX; };
+
+// vehicle.y as the control laws see it, from the state x (device row order): one RHS evaluation with a partial sink — everything
+// that does not feed the twelve tapped outputs is dead code. GROUND = false: the caller knows the aircraft is clear of the terrain.
+template <bool GROUND, class CmdFn>
+FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double (&x)[FB_X2_NX], int stall, int eng, int ui, CmdFn&& cmd_of) {
+    const InputsX in = {&x[X2_ACT], a.u + i, a.n, ui};
+    StepAux aux;
+    CtlSink tap;
+    rhs<FB_KIN_WA, GROUND>(x, stall, eng, in, a.env, T, [](int, double) {}, aux, tap);
+    CtlIn v;
+    v.lat = tap.lat; v.lon = tap.lon;
+    v.EAS = tap.EAS; v.h_e = x[FB_X_H_E]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
+    v.w_wb_b = {tap.wx, tap.wy, tap.wz};
+    v.w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
+    v.alpha = tap.alpha; v.beta = tap.beta; v.alpha_filt = x[FB_X_ALPHA_FILT]; v.beta_filt = x[FB_X_BETA_FILT];
+    v.n_eng = x[FB_X_ENG_OMEGA] / c172::w_rated;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v.pos[k] = in.pos(k); v.cmd[k] = cmd_of(k); }
+    v.on_gnd = GROUND && aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
+    return v;
+}
+// Avionics f_periodic! inside a stepping kernel (c172x2.jl:27-37): the outputs of the step's last f_ode! tapped from the state x it
+// saw (before f_step! renormalises the quaternions), guidance, then the control laws; gains by scalar loads. OUT OF LINE on
+// purpose: it runs once per control period, and inlined into the stepping loop its ~12 k instructions cost the loop its register
+// allocation (512 registers + 1.7 KB of scratch); as a call, only the call site pays (live registers saved around it).
+// wave-uniform values that reach a function through the call ABI arrive in VGPRs and the compiler must treat them as per-lane:
+// v_readfirstlane turns them back into SGPR values (scalar loads, SGPR base addresses)
+FBD int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+FBD int64_t uni(int64_t v) { return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)(uint64_t)v)); }
+FBD double uni(double v) { return __builtin_bit_cast(double, uni(__builtin_bit_cast(int64_t, v))); }
+template <class P> FBD P* uni(P* p) { return (P*)(uintptr_t)uni((int64_t)(uintptr_t)p); }
+template <bool GROUND>
+__device__ __noinline__ void x2_periodic(const KArgs& a_in, int64_t i, const Tables& T_in, const double (&x)[FB_X2_NX], int stall, int eng, int ui,
+                                         const double (&cmd)[4]) {
+    KArgs a;   // the fields this function reads, wave-uniform again
+    a.u = uni(a_in.u); a.cu = uni(a_in.cu); a.cs = uni(a_in.cs); a.n = uni(a_in.n); a.gains = uni(a_in.gains); a.ctl_dT = uni(a_in.ctl_dT);
+#pragma unroll
+    for (int k = 0; k < 10; k++) a.ctl_off.off[k] = uni(a_in.ctl_off.off[k]);
+    a.ctl_off.total = uni(a_in.ctl_off.total);
+    a.env = {uni(a_in.env.T_sl), uni(a_in.env.p_sl), uni(a_in.env.wind_n), uni(a_in.env.wind_e), uni(a_in.env.wind_d), uni(a_in.env.h_trn),
+             uni(a_in.env.surface), uni(a_in.env.ln_p_sl), uni(a_in.env.k_rt)};
+    const Tables T = {(lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.lds), uni(T_in.egm96), (lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.rk)};
+    // cs / cu rows are read and written where the laws use them (only the rows of the active modes move: the whole record, 1.5 KB
+    // per aircraft and update, was measured slower — HBM traffic) through global pointers with wave-uniform bases; the gains
+    // come by per-lane gather from the L2-resident blob, one table's corner records per burst. (Scalar loads through a
+    // wave-uniform loop over the distinct grid cells, `ctl_lookup(UniPtr, ...)`, were measured 2x slower: every s_load batch is
+    // an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit.)
+    typedef __attribute__((address_space(1))) double* gptr;
+    typedef __attribute__((address_space(1))) const double* gcptr;
+    const CtlIn v = x2_ctl_inputs<GROUND>(a, i, T, x, stall, eng, ui, [&](int k) { return cmd[k]; });
+    const CtlMemT<gptr> M = {(gptr)(uintptr_t)a.cu + i, (gptr)(uintptr_t)a.cs + i, a.n};
+    gdc_update(M, v);
+    const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)a.gains, a.ctl_off};
+    ctl_lon(tab, M, a.ctl_dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
+    ctl_lat(tab, M, a.ctl_dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
+}
 
 // f_ode!(world): xdot (optional) and the output record y
 template <bool X, int KIN>
@@ -337,9 +402,17 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
 #pragma unroll
             for (int k = 0; k < FB_NACT; k++) emit(X2_ACT + k, 1 / ACT_TAU * (x2_command(ao, i, k) - xt[X2_ACT + k]));
             if (stage == 0 && pending_cb) {
-                if (step + 1 == nsteps && a.q_pre) {   // what the control laws will see: the state of THIS evaluation
+                // f_periodic! follows f_step! (FC/sim.jl:204-218) but reads the outputs of the step's last f_ode!, i.e. of THIS
+                // evaluation, taken before f_step! renormalises the quaternions: tap them first
+                // (a lane that f_step! is about to terminate — status bits from this evaluation, a crash flag — gets no update: the
+                // reference throws out of cb_step before cb_periodic runs)
+                const bool ctl_now = a.ctl_ratio > 0 && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
+                if (ctl_now && bits == 0 && !aux.crash) {
+                    const double cmd4[4] = {x2_command(ao, i, 0), x2_command(ao, i, 1), x2_command(ao, i, 2), x2_command(ao, i, 3)};
+                    x2_periodic<GROUND>(ao, i, T, xt, stall, eng, ui, cmd4);
+                    // the actuator commands have changed: this evaluation doubles as k1 of the next step, whose actuator rows must see them
 #pragma unroll
-                    for (int k = 0; k < 8; k++) a.q_pre[(int64_t)k * a.n + i] = xt[FB_X_Q_WB + k];
+                    for (int k = 0; k < FB_NACT; k++) emit(X2_ACT + k, 1 / ACT_TAU * (x2_command(ao, i, k) - xt[X2_ACT + k]));
                 }
                 mod = f_step<KIN>(xt, stall, eng, inl, aux, bits);
             }
@@ -472,6 +545,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         else { xs_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
     }
     if (to_ground) { a.redo[i] = 1; return; }
+    if constexpr (X) {
+        // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass must
+        // find them as they were at launch start
+        if (a.ctl_ratio > 0) {
+#pragma unroll 1
+            for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
+#pragma unroll 1
+            for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+        }
+    }
     InT in;
     // actuator positions x_n and commands. Only the five the airborne RHS reads are tracked through the stages; the two brake
     // actuators are advanced at the end, over the steps this lane completed, with the same closed form.
@@ -562,11 +645,23 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             pending_cb = false;
             step++;
             bool mod = false;
+            // Cessna172X: f_periodic! follows f_step! (FC/sim.jl:204-218) but reads the outputs of the step's last f_ode!, i.e. of this
+            // evaluation at x_{n+1}, taken before f_step! renormalises the quaternions: tap them first
+            // (a lane that f_step! is about to terminate — status bits from this evaluation, a crash flag — gets no update: the reference
+            // throws out of cb_step before cb_periodic runs)
+            const bool ctl_now = X && a.ctl_ratio > 0 && (a.ctl_phase + step) % a.ctl_ratio == 0;   // wave-uniform
             if (run) {
                 if constexpr (X) {
-                    if (step == nsteps && a.q_pre) {   // what the control laws will see: the attitude of THIS evaluation, before f_step!
+                    if (ctl_now && bits == 0 && !aux.crash) {
+                        double xq[FB_X2_NX];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) a.q_pre[(int64_t)k * a.n + i] = xs_l[SV::row(FB_X_Q_WB + k) * B + t];
+                        for (int k = 0; k < FB_NX; k++) xq[k] = (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : xs_l[SV::row(k) * B + t];
+#pragma unroll
+                        for (int k = 0; k < FB_NACT; k++) xq[X2_ACT + k] = k < NAL ? xa[k] : 0.0;   // (the brakes are not tapped)
+                        const double cmd4[4] = {ca[0], ca[1], ca[2], ca[3]};
+                        x2_periodic<false>(a, i, T, xq, stall, eng, in.ui, cmd4);
+#pragma unroll
+                        for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
                     }
                 }
                 auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
@@ -621,7 +716,18 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
-    if (handoff) { a.redo[i] = 1; return; }
+    if (handoff) {
+        if constexpr (X) {
+            if (a.ctl_ratio > 0) {   // nothing of this lane's launch is committed: undo the control-law updates it has made
+#pragma unroll 1
+                for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
+#pragma unroll 1
+                for (int k = 0; k < FB_NCU; k++) const_cast<double*>(a.cu)[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i];
+            }
+        }
+        a.redo[i] = 1;
+        return;
+    }
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {

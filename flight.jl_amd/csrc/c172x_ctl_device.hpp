@@ -24,13 +24,15 @@ struct CtlTabT {
     CtlOffsets o;
     FBD P lk(int k) const { return base + o.off[k]; }
 };
-struct CtlMem {
-    double* cu;        // &cu[0 * n + i]  (guidance rewrites references and mode requests)
-    double* cs;        // &cs[0 * n + i]
+template <class P>
+struct CtlMemT {
+    P cu;              // &cu[0 * n + i]  (guidance rewrites references and mode requests)
+    P cs;              // &cs[0 * n + i]
     int64_t n;
-    FBD double& U(int k) const { return cu[(int64_t)k * n]; }
-    FBD double& S(int k) const { return cs[(int64_t)k * n]; }
+    FBD auto& U(int k) const { return cu[(int64_t)k * n]; }
+    FBD auto& S(int k) const { return cs[(int64_t)k * n]; }
 };
+typedef CtlMemT<double*> CtlMem;
 // what the control laws read from vehicle.y (XLonRed/XLonFull/XLatRed, Zte/Ztv/Zvh/Zφβ/Zar: c172x_ctl.jl:84-199, 745-810)
 struct CtlIn {
     double EAS, h_e, theta, phi, clm, chi, lat, lon;
@@ -87,6 +89,51 @@ FBD void ctl_lookup(P lk, double EAS, double h, double (&out)[REC]) {
     for (int c = 0; c < REC; c++) out[c] = (1 - wE) * ((1 - wH) * a00[c] + wH * a01[c]) + wE * ((1 - wH) * a10[c] + wH * a11[c]);
 }
 
+// The same lookup for the stepping kernels, which have no LDS left for the 46 KB blob: the blob stays in global memory and is read
+// through SCALAR loads. Lanes are grouped by grid cell (a waterfall loop: in a batch flying one scenario all 64 lanes share the
+// cell and the loop runs once); within a group the four corner records have wave-uniform addresses, so they arrive by
+// s_load_dwordx16 and enter the per-lane bilinear blend as SGPR operands — no per-lane gather (64 scattered 8-byte loads per
+// element would cost the TA ~100x the arithmetic).
+struct UniPtr { gk_cptr p; };
+FBD UniPtr operator+(UniPtr a, int o) { return {a.p + o}; }
+template <int REC>
+FBD void ctl_lookup(UniPtr lku, double EAS, double h, double (&out)[REC]) {
+    const gk_cptr lk = lku.p;
+    const int nE = (int)lk[0], nH = (int)lk[1];
+    int i0 = 0, j0 = 0;
+    double wE = 0, wH = 0;
+    if (nE > 1) {
+        const double xi = (fmin(fmax(EAS, (double)lk[2]), (double)lk[3]) - lk[2]) / ((lk[3] - lk[2]) / (nE - 1));
+        i0 = min(max((int)floor(xi), 0), nE - 2); wE = xi - i0;
+    }
+    if (nH > 1) {
+        const double xj = (fmin(fmax(h, (double)lk[4]), (double)lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
+        j0 = min(max((int)floor(xj), 0), nH - 2); wH = xj - j0;
+    }
+    const int cell = i0 + nE * j0;
+    // A loop over the distinct cells of the active lanes, WAVE-UNIFORM in every iteration: `remaining` is an SGPR mask, the cell
+    // of its first lane comes out by v_readlane, and only the blend is predicated on `cell == c`. (The textbook per-lane
+    // `while (todo) { c = readfirstlane(cell); if (cell == c) ... }` does not survive the optimiser here: it substitutes the
+    // per-lane cell for c inside the branch, or sinks the loads out of the divergent loop.)
+    uint64_t remaining = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll 1
+    while (remaining != 0) {
+        const int lane = __builtin_ctzll(remaining);
+        int c = __builtin_amdgcn_readlane(cell, lane);
+        asm volatile("" : "+s"(c));                            // opaque, and truly uniform here
+        const int iu = c % nE, ju = c / nE;
+        const int i1 = nE > 1 ? iu + 1 : iu, j1 = nH > 1 ? ju + 1 : ju;
+        const gk_cptr d = lk + FB_CTL_GRID_HDR;
+        const gk_cptr a00 = d + (iu + nE * ju) * REC, a10 = d + (i1 + nE * ju) * REC, a01 = d + (iu + nE * j1) * REC, a11 = d + (i1 + nE * j1) * REC;
+        const bool mine = cell == c;
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < REC; k++) out[k] = (1 - wE) * ((1 - wH) * (double)a00[k] + wH * (double)a01[k]) + wE * ((1 - wH) * (double)a10[k] + wH * (double)a11[k]);
+        }
+        remaining &= ~__builtin_amdgcn_ballot_w64(mine);
+    }
+}
+
 // ---- compensators; their states are rows of the cs record ------------------------------------------------------
 struct PidGains { double k_p, k_i, k_d, tau_f; };
 template <class P>
@@ -96,7 +143,8 @@ FBD PidGains pid_gains(P lk, double EAS, double h) {
     return {g[0], g[1], g[2], g[3]};
 }
 // PID f_periodic! (β_p = β_d = 1); rows s0 .. s0+2 = x_i0, x_d0, sat_out_0
-FBD double pid_run(const CtlMem& M, int s0, const PidGains& P, double lo, double hi, double dT, double input, double sat_ext) {
+template <class MEM>
+FBD double pid_run(const MEM& M, int s0, const PidGains& P, double lo, double hi, double dT, double input, double sat_ext) {
     const double x_i0 = M.S(s0), x_d0 = M.S(s0 + 1), sat0 = M.S(s0 + 2);
     const double a = 1 / (P.tau_f + dT);
     const bool halted = (sgnd(input * sat0) > 0) || (sgnd(input * sat_ext) > 0);
@@ -107,23 +155,26 @@ FBD double pid_run(const CtlMem& M, int s0, const PidGains& P, double lo, double
     M.S(s0 + 2) = (out_free >= hi ? 1.0 : 0.0) - (out_free <= lo ? 1.0 : 0.0);
     return fmin(fmax(out_free, lo), hi);
 }
-FBD void pid_init(const CtlMem& M, int s0, const PidGains& P, double lo, double hi, double dT) {
+template <class MEM>
+FBD void pid_init(const MEM& M, int s0, const PidGains& P, double lo, double hi, double dT) {
     M.S(s0) = 0; M.S(s0 + 1) = 0; M.S(s0 + 2) = 0;
     pid_run(M, s0, P, lo, hi, dT, 0.0, 0.0);
 }
 // Integrator f_periodic!, unbounded; rows s0, s0+1 = x0, sat_out_0
-FBD double integ_run(const CtlMem& M, int s0, double dT, double input, double sat_ext) {
+template <class MEM>
+FBD double integ_run(const MEM& M, int s0, double dT, double input, double sat_ext) {
     const bool halted = (sgnd(input * M.S(s0 + 1)) > 0) || (sgnd(input * sat_ext) > 0);
     const double x1 = M.S(s0) + dT * input * (halted ? 0.0 : 1.0);
     M.S(s0) = x1;
     M.S(s0 + 1) = (x1 >= CTL_INF ? 1.0 : 0.0) - (x1 <= -CTL_INF ? 1.0 : 0.0);
     return x1;
 }
-FBD void integ_init(const CtlMem& M, int s0, double dT) { M.S(s0) = 0; M.S(s0 + 1) = 0; integ_run(M, s0, dT, 0.0, 0.0); }
+template <class MEM>
+FBD void integ_init(const MEM& M, int s0, double dT) { M.S(s0) = 0; M.S(s0 + 1) = 0; integ_run(M, s0, dT, 0.0, 0.0); }
 // LQR{NX,2,2} f_periodic!; g = [K_fbk 2xNX column-major | K_fwd 2x2 | K_int 2x2 | x_trim | u_trim | z_trim];
 // rows s0 .. s0+3 = int_out_0[2], out_sat_0[2]; sat_ext is never set by the control laws
-template <int NX>
-FBD void lqr_run(const CtlMem& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT, const double (&x)[NX],
+template <int NX, class MEM>
+FBD void lqr_run(const MEM& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT, const double (&x)[NX],
                  const double (&z)[2], const double (&z_ref)[2], double (&out)[2]) {
     const double* K_fbk = g; const double* K_fwd = g + 2 * NX; const double* K_int = K_fwd + 4;
     const double* x_trim = K_int + 4; const double* u_trim = x_trim + NX; const double* z_trim = u_trim + 2;
@@ -143,8 +194,8 @@ FBD void lqr_run(const CtlMem& M, int s0, const double* g, const double (&lo)[2]
         out[i] = fmin(fmax(out_free, lo[i]), hi[i]);
     }
 }
-template <int NX>
-FBD void lqr_init(const CtlMem& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT) {
+template <int NX, class MEM>
+FBD void lqr_init(const MEM& M, int s0, const double* g, const double (&lo)[2], const double (&hi)[2], double dT) {
     double x[NX], out[2];
 #pragma unroll
     for (int k = 0; k < NX; k++) x[k] = 0;
@@ -154,8 +205,8 @@ FBD void lqr_init(const CtlMem& M, int s0, const double* g, const double (&lo)[2
 }
 
 // ---- longitudinal channel ------------------------------------------------------------------------------------------
-template <class TAB>
-FBD void ctl_lon(const TAB& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+template <class TAB, class MEM>
+FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
     double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
     const double EAS_ref = M.U(FB_CU_EAS_REF), clm_ref = M.U(FB_CU_CLM_REF), h_ref = M.U(FB_CU_H_REF);
     const double EAS = v.EAS, h_e = v.h_e, q = v.w_wb_b.y, r = v.w_wb_b.z, theta = v.theta;
@@ -256,7 +307,8 @@ FBD v3 ecef_of(const GeoPt& p) {   // Cartesian(Geographic{LatLon, Ellipsoidal})
     return {(R_E + p.h) * n.x, (R_E + p.h) * n.y, (R_E * (1 - wgs::e2) + p.h) * n.z};
 }
 // Runs before the control laws and may rewrite their inputs (χ_ref + χ_β request, h_ref + EAS_alt request).
-FBD void gdc_update(const CtlMem& M, const CtlIn& v) {
+template <class MEM>
+FBD void gdc_update(const MEM& M, const CtlIn& v) {
     const int mode = v.on_gnd ? (int)FB_GDC_DIRECT : (int)M.U(FB_CU_GDC_MODE_REQ);
     if (mode == FB_GDC_SEGMENT) {
         const GeoPt p1 = {M.U(FB_CU_SEG_P1), M.U(FB_CU_SEG_P1 + 1), M.U(FB_CU_SEG_P1 + 2)};
@@ -287,8 +339,8 @@ FBD void gdc_update(const CtlMem& M, const CtlIn& v) {
 }
 
 // ---- lateral channel -----------------------------------------------------------------------------------------------
-template <class TAB>
-FBD void ctl_lat(const TAB& T, const CtlMem& M, double dT, const CtlIn& v, int mode_req) {
+template <class TAB, class MEM>
+FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
     const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
     double phi_ref = M.U(FB_CU_PHI_REF);
     const double EAS = v.EAS, h_e = v.h_e;

@@ -15,24 +15,10 @@ struct CtlArgs {
     int use_q_pre;    // 1: take q_wb, q_ew from KArgs::q_pre (the state the last f_ode! of the step saw, before f_step!)
 };
 
-// vehicle.y as the control laws see it, from the state x: one RHS evaluation with a partial sink
+// vehicle.y as the control laws see it (the ground-capable form of c172_kernels.hpp's x2_ctl_inputs, discrete states from memory)
 template <class CmdFn>
 FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double (&x)[FB_X2_NX], CmdFn&& cmd_of) {
-    const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-    StepAux aux;
-    CtlSink tap;
-    rhs<FB_KIN_WA>(x, a.s[i], a.s[a.n + i], in, a.env, T, [](int, double) {}, aux, tap);
-    CtlIn v;
-    v.lat = tap.lat; v.lon = tap.lon;
-    v.EAS = tap.EAS; v.h_e = x[FB_X_H_E]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
-    v.w_wb_b = {tap.wx, tap.wy, tap.wz};
-    v.w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
-    v.alpha = tap.alpha; v.beta = tap.beta; v.alpha_filt = x[FB_X_ALPHA_FILT]; v.beta_filt = x[FB_X_BETA_FILT];
-    v.n_eng = x[FB_X_ENG_OMEGA] / c172::w_rated;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { v.pos[k] = in.pos(k); v.cmd[k] = cmd_of(k); }
-    v.on_gnd = aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
-    return v;
+    return x2_ctl_inputs<true>(a, i, T, x, a.s[i], a.s[a.n + i], a.ui[i], cmd_of);
 }
 
 constexpr int CTL_GAINS_MAX = 6144;   // doubles of LDS reserved for the gains blob (the shipped lookups need 5744)

@@ -62,6 +62,7 @@ struct fb_handle_s {
     double* cs = nullptr;      // [FB_NCS x n] control-law record
     double* cu = nullptr;      // [FB_NCU x n] control-law inputs
     double* q_pre = nullptr;   // [8 x n]
+    double* ctl_bak = nullptr; // [(FB_NCS + FB_NCU) x n] scratch of the airborne pass (see KArgs::ctl_bak)
     int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of k_step
     double* k1 = nullptr;      // [FB_NX x n] Cessna172Xv2: FSAL derivative carried from launch to launch
     int32_t* k1_valid = nullptr;
@@ -83,6 +84,13 @@ static KArgs make_args(fb_handle h) {
     a.dt = h->params.dt;
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
+    a.gains = h->gains; a.ctl_bak = h->ctl_bak;
+    for (int k = 0; k < 10; k++) a.ctl_off.off[k] = (int)h->gains_off[k];
+    a.ctl_off.total = (int)h->gains_total;
+    const int ratio = h->params.periodic_n > 0 ? h->params.periodic_n : 1;
+    a.ctl_dT = h->params.dt * ratio;
+    a.ctl_ratio = h->model == FB_MODEL_C172X2 ? ratio : 0;
+    a.ctl_phase = (int)(h->steps_done % ratio);
     return a;
 }
 static int32_t check_ready(fb_handle h) {
@@ -190,6 +198,7 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
         HIPCHK(hipMalloc(&h->cs, sizeof(double) * FB_NCS * n));
         HIPCHK(hipMalloc(&h->cu, sizeof(double) * FB_NCU * n));
         HIPCHK(hipMalloc(&h->q_pre, sizeof(double) * 8 * n));
+        HIPCHK(hipMalloc(&h->ctl_bak, sizeof(double) * (FB_NCS + FB_NCU) * n));
         HIPCHK(hipMemsetAsync(h->cs, 0, sizeof(double) * FB_NCS * n, h->stream));
         HIPCHK(hipMemsetAsync(h->cu, 0, sizeof(double) * FB_NCU * n, h->stream));
         HIPCHK(hipMemsetAsync(h->q_pre, 0, sizeof(double) * 8 * n, h->stream));
@@ -260,7 +269,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
-    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
@@ -615,31 +624,17 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
         HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * TABLE_BUF_DOUBLES, hipMemcpyHostToDevice));
         h->tables_f32_stale = false;
     }
-    const KArgs a = make_args(h);
+    KArgs a = make_args(h);
     int64_t left = nsteps;
-    if (is_x2(h)) {
-        // launches are cut at the multiples of Δt/dt; the control laws run between them on the outputs of the step's
-        // last f_ode! (cb_periodic after cb_step, FC/sim.jl:204-218, 366-381)
-        const int64_t ratio = h->params.periodic_n > 0 ? h->params.periodic_n : 1;
-        const CtlArgs c = ctl_args(h, 1);
-        while (left > 0) {
-            const int64_t to_periodic = ratio - (h->steps_done % ratio);
-            int64_t k = left < to_periodic ? left : to_periodic;
-            if (k > h->steps_per_launch) k = h->steps_per_launch;
-            FB_LAUNCH_STEP(grid_for(h->n, 256), a, (int)k);
-            h->launches++;
-            h->steps_done += k;
-            left -= k;
-            if (h->steps_done % ratio == 0) hipLaunchKernelGGL(k_x2_ctl, grid_for(h->n, 256), dim3(256), 0, h->stream, a, c);
-        }
-    } else {
-        while (left > 0) {
-            const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
-            FB_LAUNCH_STEP(grid_for(h->n, 256), a, k);
-            left -= k;
-            h->steps_done += k;
-            h->launches++;
-        }
+    // Cessna172Xv2: the control laws run inside the stepping kernels every Δt/dt steps (cb_periodic after cb_step, FC/sim.jl:204-218,
+    // 366-381), so a launch spans steps_per_launch steps like everyone else's; the kernels get the phase of the periodic update
+    while (left > 0) {
+        const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
+        a.ctl_phase = a.ctl_ratio > 0 ? (int)(h->steps_done % a.ctl_ratio) : 0;
+        FB_LAUNCH_STEP(grid_for(h->n, 256), a, k);
+        left -= k;
+        h->steps_done += k;
+        h->launches++;
     }
     HIPCHK(hipGetLastError());
     h->t += (double)nsteps * h->params.dt;
