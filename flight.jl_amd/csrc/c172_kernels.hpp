@@ -208,11 +208,11 @@ __device__ __noinline__ void x2_periodic(const KArgs& a_in, int64_t i, const Tab
     a.env = {uni(a_in.env.T_sl), uni(a_in.env.p_sl), uni(a_in.env.wind_n), uni(a_in.env.wind_e), uni(a_in.env.wind_d), uni(a_in.env.h_trn),
              uni(a_in.env.surface), uni(a_in.env.ln_p_sl), uni(a_in.env.k_rt)};
     const Tables T = {(lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.lds), uni(T_in.egm96), (lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.rk)};
-    // cs / cu rows are read and written where the laws use them (only the rows of the active modes move: the whole record, 1.5 KB
-    // per aircraft and update, was measured slower — HBM traffic) through global pointers with wave-uniform bases; the gains
-    // come by per-lane gather from the L2-resident blob, one table's corner records per burst. (Scalar loads through a
-    // wave-uniform loop over the distinct grid cells, `ctl_lookup(UniPtr, ...)`, were measured 2x slower: every s_load batch is
-    // an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit.)
+    // cs / cu rows are read and written where the laws use them, through global pointers with wave-uniform bases (only the rows of
+    // the active modes move; prefetching the whole 94-row record into registers and writing back what changed was measured 2x
+    // slower: the copy spills). The gains come by per-lane gather from the L2-resident blob, one table's corner records per burst
+    // (scalar loads through a wave-uniform loop over the distinct grid cells were also measured 2x slower: every s_load batch
+    // is an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit).
     typedef __attribute__((address_space(1))) double* gptr;
     typedef __attribute__((address_space(1))) const double* gcptr;
     const CtlIn v = x2_ctl_inputs<GROUND>(a, i, T, x, stall, eng, ui, [&](int k) { return cmd[k]; });

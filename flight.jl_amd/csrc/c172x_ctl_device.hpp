@@ -89,51 +89,6 @@ FBD void ctl_lookup(P lk, double EAS, double h, double (&out)[REC]) {
     for (int c = 0; c < REC; c++) out[c] = (1 - wE) * ((1 - wH) * a00[c] + wH * a01[c]) + wE * ((1 - wH) * a10[c] + wH * a11[c]);
 }
 
-// The same lookup for the stepping kernels, which have no LDS left for the 46 KB blob: the blob stays in global memory and is read
-// through SCALAR loads. Lanes are grouped by grid cell (a waterfall loop: in a batch flying one scenario all 64 lanes share the
-// cell and the loop runs once); within a group the four corner records have wave-uniform addresses, so they arrive by
-// s_load_dwordx16 and enter the per-lane bilinear blend as SGPR operands — no per-lane gather (64 scattered 8-byte loads per
-// element would cost the TA ~100x the arithmetic).
-struct UniPtr { gk_cptr p; };
-FBD UniPtr operator+(UniPtr a, int o) { return {a.p + o}; }
-template <int REC>
-FBD void ctl_lookup(UniPtr lku, double EAS, double h, double (&out)[REC]) {
-    const gk_cptr lk = lku.p;
-    const int nE = (int)lk[0], nH = (int)lk[1];
-    int i0 = 0, j0 = 0;
-    double wE = 0, wH = 0;
-    if (nE > 1) {
-        const double xi = (fmin(fmax(EAS, (double)lk[2]), (double)lk[3]) - lk[2]) / ((lk[3] - lk[2]) / (nE - 1));
-        i0 = min(max((int)floor(xi), 0), nE - 2); wE = xi - i0;
-    }
-    if (nH > 1) {
-        const double xj = (fmin(fmax(h, (double)lk[4]), (double)lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
-        j0 = min(max((int)floor(xj), 0), nH - 2); wH = xj - j0;
-    }
-    const int cell = i0 + nE * j0;
-    // A loop over the distinct cells of the active lanes, WAVE-UNIFORM in every iteration: `remaining` is an SGPR mask, the cell
-    // of its first lane comes out by v_readlane, and only the blend is predicated on `cell == c`. (The textbook per-lane
-    // `while (todo) { c = readfirstlane(cell); if (cell == c) ... }` does not survive the optimiser here: it substitutes the
-    // per-lane cell for c inside the branch, or sinks the loads out of the divergent loop.)
-    uint64_t remaining = __builtin_amdgcn_ballot_w64(true);
-#pragma unroll 1
-    while (remaining != 0) {
-        const int lane = __builtin_ctzll(remaining);
-        int c = __builtin_amdgcn_readlane(cell, lane);
-        asm volatile("" : "+s"(c));                            // opaque, and truly uniform here
-        const int iu = c % nE, ju = c / nE;
-        const int i1 = nE > 1 ? iu + 1 : iu, j1 = nH > 1 ? ju + 1 : ju;
-        const gk_cptr d = lk + FB_CTL_GRID_HDR;
-        const gk_cptr a00 = d + (iu + nE * ju) * REC, a10 = d + (i1 + nE * ju) * REC, a01 = d + (iu + nE * j1) * REC, a11 = d + (i1 + nE * j1) * REC;
-        const bool mine = cell == c;
-        if (mine) {
-#pragma unroll
-            for (int k = 0; k < REC; k++) out[k] = (1 - wE) * ((1 - wH) * (double)a00[k] + wH * (double)a01[k]) + wE * ((1 - wH) * (double)a10[k] + wH * (double)a11[k]);
-        }
-        remaining &= ~__builtin_amdgcn_ballot_w64(mine);
-    }
-}
-
 // ---- compensators; their states are rows of the cs record ------------------------------------------------------
 struct PidGains { double k_p, k_i, k_d, tau_f; };
 template <class P>
