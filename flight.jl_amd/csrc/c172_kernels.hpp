@@ -119,7 +119,7 @@ struct KArgs {
     double* cs;         // [FB_NCS x n] control-law record (actuator commands live here)
     const double* cu;   // [FB_NCU x n] control-law inputs
     double* q_pre;      // [8 x n] q_wb, q_ew of the last evaluation before f_step! (what the periodic update must see)
-    int32_t* redo;      // [n] set by the airborne pass of k_step for lanes that came within reach of the ground
+    int32_t* redo;      // [n] set by the airborne pass of the stepping kernel for lanes that came within reach of the ground
     double* k1;         // [FB_NX x n] Cessna172X: derivative left by the last evaluation of the previous launch (FSAL across launches)
     int32_t* k1_valid;  // [n] 1 when k1 is the derivative at the current x, s, u
     // Cessna172X: f_periodic!(avionics, vehicle) runs INSIDE the stepping kernels, after the f_step! of every step n with
@@ -291,181 +291,20 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     a.status[i] |= st;
 }
 
-// nsteps x step!(sim), fused.
-//
-// Registers are the limiter of this kernel: VALU instructions address 256 VGPRs (the AGPR half of the
-// file is only a spill cache), one fp64 value takes two, and a single RHS keeps ~200 fp64 values alive.
-// So the RK4 bookkeeping does not live in registers at all:
-//   * per lane, x_n (NX doubles) and the running stage sum (NX doubles) sit in two [NX][256] LDS panels
-//     (lane-contiguous rows: conflict-free ds_read_b64/ds_write_b64). LDS per workgroup: 22 KB of tables
-//     + 108 KB (NX = 27) or 136 KB (NX = 34) of panels = one 256-lane workgroup per CU, one wave per SIMD;
-//   * the stage update is fused INTO the RHS: each derivative k_j is consumed the moment it is produced
-//     (acc_j += w k_j in LDS, x_next_j = x_n,j + c dt k_j), so no k[NX] array is ever alive.
-// Stage sum: acc = k1 + 2 k2 + 2 k3, x_{n+1} = x_n + dt/6 (acc + k4) — the classic RK4 combination
+// ---- nsteps x step!(sim), fused: the stepping kernel ------------------------------------------------------------------------------
+// Registers are the limiter: VALU instructions address 256 VGPRs (the AGPR half of the file is only a spill cache), one fp64 value
+// takes two, and a single RHS keeps ~200 fp64 values alive. So the RK4 bookkeeping does not live in registers at all: per lane, x_n,
+// the running stage sum and the state being evaluated sit in [rows][256] LDS panels (lane-contiguous rows: conflict-free ds_read_b64 /
+// ds_write_b64), and the stage update is fused INTO the RHS: each derivative k_j is consumed the moment it is produced (emit), so no
+// k[NX] array is ever alive. Stage sum: acc = k1 + 2 k2 + 2 k3, x_{n+1} = x_n + dt/6 (acc + k4) — the classic RK4 combination
 // (OrdinaryDiffEq writes it as dt/6 (2 (k2 + k3) + (k1 + k4)); same value up to the last bit).
-// X = Cessna172X: seven more states (first-order actuators driven by the commands in cs / u, constant during a
-// launch: the control laws run between launches), inputs derived from the actuator positions; with 34 rows per panel
-// there is no LDS left for an input panel, so mixture / payload / commands are read from global memory (L1/L2 hits).
-// Two passes per launch group: the AIRBORNE instance (GROUND = false: no ground-contact code, no call ABI, 15 % faster)
-// steps every lane; a lane that comes within 10 m of the terrain at any evaluation stops without committing anything and
-// raises its redo flag; the GROUND-capable instance then re-runs exactly those lanes from the same launch-start state
-// (workgroups without such a lane leave at once).
-template <bool X, int KIN, bool GROUND>
-__global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
-    constexpr int NXT = Dims<X>::NXT;
-    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
-    __shared__ double rk[LDS_RK_DOUBLES];
-    __shared__ double xs_l[NXT * STEP_BLOCK];   // x_n
-    __shared__ double acc_l[NXT * STEP_BLOCK];  // k1 + 2 k2 + 2 k3 of the current step
-    __shared__ double in_l[X ? 8 : INPUT_PANEL_ROWS * STEP_BLOCK];  // Sv0: per-lane inputs, read at the point of use
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if constexpr (GROUND) {   // second pass: only the lanes the airborne pass handed over
-        const int mine = (i < a.n) && a.redo[i] != 0;
-        if (!__syncthreads_or(mine)) return;
-        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
-        if (!mine) return;
-        a.redo[i] = 0;
-    } else {
-        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
-        if (i >= a.n) return;
-    }
-    if (a.status[i] != 0) return;  // terminated aircraft stay frozen (SimulationTermination, sim.jl:561-570)
-    bool dead = false;             // a status bit was raised during this launch (bits go straight to memory: rare)
-    const int t = threadIdx.x;
-    double xt[NXT];
-#pragma unroll
-    for (int k = 0; k < NXT; k++) { xt[k] = a.x[(int64_t)k * a.n + i]; xs_l[k * STEP_BLOCK + t] = xt[k]; }
-    InputsLds<STEP_BLOCK> in;
-    if constexpr (!X) {
-        Inputs in_r;
-        load_inputs(a, i, in_r);
-        in.store((lds_ptr)in_l + t, in_r);
-    }
-    const int ui = a.ui[i];
-    int stall = a.s[i], eng = a.s[a.n + i];
-    const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
-    int stage = 0, step = 0;
-    bool pending_cb = false;
-    if constexpr (X) {
-        // FSAL across launches. With the control laws between them, a launch is only Δt/dt steps long, and re-evaluating k1
-        // at its start would be one RHS in nine. The previous launch ended with an evaluation at this very state; its 27
-        // vehicle derivatives are still valid (they depend on the actuator POSITIONS, which are states, not on the commands
-        // the control laws have just changed) unless f_step! modified x or s, or the host touched x / u / the environment.
-        if (a.k1 && a.k1_valid[i]) {
-#pragma unroll
-            for (int j = 0; j < NXT; j++) {
-                const double kj = j < FB_NX ? a.k1[(int64_t)j * a.n + i] : 1 / ACT_TAU * (x2_command(a, i, j - X2_ACT) - xt[j]);
-                acc_l[j * STEP_BLOCK + t] = kj;
-                xt[j] = xt[j] + hdt * kj;
-            }
-            stage = 1;
-        }
-    }
-#pragma unroll 1
-    while (true) {
-        double xn[NXT];
-        StepAux aux;
-        // Opaque (always zero) offsets: without them LICM hoists every loop-invariant table / input load
-        // (~150 knots and values) out of the stage loop into VGPRs and the kernel spills 1.7 KB/lane.
-        int lds_off = 0;
-        asm volatile("" : "+s"(lds_off));
-        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
-        const double cdt = (stage == 2) ? dt : hdt;  // wave-uniform
-        auto emit = [&](int j, double kj) {
-            const int idx = j * STEP_BLOCK + t;
-            const double xs = xs_l[idx];
-#ifdef FB_DEBUG_ROW
-            if (j == FB_DEBUG_ROW && i == 1) printf("emit row %d stage %d xs %.17g kj %.17g acc %.17g xt %.17g\n", j, stage, xs, kj, acc_l[idx], xt[j]);
-#endif
-            if (stage == 0) {
-                acc_l[idx] = kj;
-                xn[j] = xs + cdt * kj;
-            } else if (stage < 3) {
-                acc_l[idx] = acc_l[idx] + 2 * kj;
-                xn[j] = xs + cdt * kj;
-            } else {
-                const double v = xs + dt6 * (acc_l[idx] + kj);
-                xs_l[idx] = v;
-                xn[j] = v;
-            }
-        };
-        // NB: a stage-3 emit overwrites x_n in LDS component by component; the RHS itself reads its state
-        // from the registers xt[], never from the panel, so this is safe.
-        int32_t bits;
-        bool mod = false;
-        if constexpr (X) {
-            const InputsX inl = {&xt[X2_ACT], a.u + i + lds_off, a.n, ui};
-            bits = rhs<KIN, GROUND, true>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
-            KArgs ao = a;
-            ao.cs = a.cs + lds_off; ao.u = a.u + lds_off;
-#pragma unroll
-            for (int k = 0; k < FB_NACT; k++) emit(X2_ACT + k, 1 / ACT_TAU * (x2_command(ao, i, k) - xt[X2_ACT + k]));
-            if (stage == 0 && pending_cb) {
-                // f_periodic! follows f_step! (FC/sim.jl:204-218) but reads the outputs of the step's last f_ode!, i.e. of THIS
-                // evaluation, taken before f_step! renormalises the quaternions: tap them first
-                // (a lane that f_step! is about to terminate — status bits from this evaluation, a crash flag — gets no update: the
-                // reference throws out of cb_step before cb_periodic runs)
-                const bool ctl_now = a.ctl_ratio > 0 && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
-                if (ctl_now && bits == 0 && !aux.crash) {
-                    const double cmd4[4] = {x2_command(ao, i, 0), x2_command(ao, i, 1), x2_command(ao, i, 2), x2_command(ao, i, 3)};
-                    x2_periodic<GROUND>(ao, i, T, xt, stall, eng, ui, cmd4);
-                    // the actuator commands have changed: this evaluation doubles as k1 of the next step, whose actuator rows must see them
-#pragma unroll
-                    for (int k = 0; k < FB_NACT; k++) emit(X2_ACT + k, 1 / ACT_TAU * (x2_command(ao, i, k) - xt[X2_ACT + k]));
-                }
-                mod = f_step<KIN>(xt, stall, eng, inl, aux, bits);
-            }
-        } else {
-            InputsLds<STEP_BLOCK> inl = in;
-            inl.p = in.p + lds_off;
-            bits = rhs<KIN, GROUND, true>(xt, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { a.redo[i] = 1; return; }   // nothing has been committed for this lane
-            if (stage == 0 && pending_cb) mod = f_step<KIN>(xt, stall, eng, in, aux, bits);
-        }
-        if (stage == 0 && pending_cb) {  // this evaluation sat at x_{n+1} (= xt): the discrete callbacks have run on it
-            pending_cb = false;
-            step++;
-            if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
-            if (mod) {
-#pragma unroll
-                for (int j = 0; j < FB_NX; j++) xs_l[j * STEP_BLOCK + t] = xt[j];
-            }
-            if (dead || step == nsteps) {
-                if constexpr (X) {
-                    if (a.k1) {   // this evaluation's derivatives (stage-0 emits: acc = k) are the next launch's k1 unless something changed
-                        const bool keep = !dead && !mod;
-                        if (keep) {
-#pragma unroll
-                            for (int j = 0; j < FB_NX; j++) a.k1[(int64_t)j * a.n + i] = acc_l[j * STEP_BLOCK + t];
-                        }
-                        a.k1_valid[i] = keep ? 1 : 0;
-                    }
-                }
-                break;
-            }
-            if (mod) continue;  // re-evaluate k1 on the modified state (this pass's stage-0 emits are simply redone)
-        }
-        if (bits != 0) { a.status[i] |= bits; dead = true; }
-#pragma unroll
-        for (int j = 0; j < NXT; j++) xt[j] = xn[j];
-        stage = (stage + 1) & 3;
-        pending_cb = (stage == 0);
-    }
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < NXT; j++) bad = bad || !isfinite(xt[j]);
-    if (bad) a.status[i] |= FB_ST_NAN;
-#pragma unroll
-    for (int j = 0; j < NXT; j++) a.x[(int64_t)j * a.n + i] = xt[j];
-    a.s[i] = stall;
-    a.s[a.n + i] = eng;
-}
-
-// ---- the airborne pass of Cessna172Sv0 / WA, third generation ---------------------------------------------------------------
-// k_step<false, WA, false> keeps the stage state xt[27] and the next stage's state xn[27] in registers: 108 of the 256
-// addressable VGPRs, which is why a fifth of its VALU instructions are v_accvgpr moves. Here the stage state lives in a third
-// LDS panel and is read at the point of use; emit() updates it IN PLACE (every row's derivative is produced after the last
+// Two passes per launch: the AIRBORNE instance (GROUND = false: no ground-contact code) steps every lane; a lane that comes within
+// 10 m of the terrain at any evaluation stops without committing anything and raises its redo flag; the GROUND-capable instance
+// (same source, GROUND = true) then re-runs exactly those lanes from the same launch-start state (workgroups without such a lane
+// leave at once). History: the first generations kept the stage state in registers (k_step<X, KIN, GROUND>, 108 of the 256 VGPRs,
+// a fifth of its VALU instructions v_accvgpr moves, a per-lane stage machine); the ground-capable pass was the last user of that
+// form (4.9e8 aircraft-steps/s on the ground; 1.10e9 on this design with the contact branch inlined).
+// The stage state lives in a third LDS panel and is read at the point of use; emit() updates it IN PLACE (every row's derivative is produced after the last
 // read of that row within one evaluation — checked against rhs()'s source order), so neither array exists in registers.
 // LDS room for the third panel comes from two facts about an airborne aircraft: its six contact-regulator states are
 // identically zero (reset by f_step! whenever a wheel is off the ground, zero derivative at zero) so they need no rows —
@@ -474,11 +313,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step(KArgs a, int nsteps) {
 #ifndef FB_AIR_SCALAR_KNOTS
 #define FB_AIR_SCALAR_KNOTS true
 #endif
-template <int STRIDE>
+// GROUND = true is the same kernel for the lanes the airborne pass hands over (second pass of a launch): all 27 rows, the
+// ground-contact branch compiled in, and — 3 x 27 rows would not fit the LDS — the stage sum in registers instead of a panel.
+template <int STRIDE, bool GROUND = false>
 struct StateLds {
     lds_cptr p;   // &panel[lane]
-    __device__ __forceinline__ static constexpr int row(int k) { return k < FB_X_LDG_FRC ? k : k - 6; }
-    __device__ __forceinline__ double operator[](int k) const { return (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : p[row(k) * STRIDE]; }
+    __device__ __forceinline__ static constexpr bool skip(int k) { return !GROUND && k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6; }
+    __device__ __forceinline__ static constexpr int row(int k) { return GROUND ? k : (k < FB_X_LDG_FRC ? k : k - 6); }
+    __device__ __forceinline__ double operator[](int k) const { return skip(k) ? 0.0 : p[row(k) * STRIDE]; }
 };
 // X = Cessna172X: the seven first-order actuators (ẋ = (cmd - x)/τ, commands constant during a launch) are linear, so classic
 // RK4 on them has a closed form — stage values cmd + (x_n - cmd) m_s with m = 1, 1 - z/2, 1 - z/2 + z²/4, 1 - z + z²/2 - z³/4 and
@@ -490,62 +332,86 @@ struct StateLds {
 // Bit-identical to the branched form (acc + 1 k = k exactly at stage 0, A 1 = A, same fma's) and to the ground-capable kernel's:
 // near the ground a one-ulp difference in this combination is amplified to 1e-6 within a few hundred steps (tried:
 // x_n + dt/6 acc + dt/6 k4 saves the select and fails test_approach_crosses_the_air_ground_handover).
-template <int B>
+// the stage sum k1 + 2 k2 + 2 k3: an LDS panel [rows][B] in the airborne pass, 27 registers per lane (the compiler parks them in
+// AGPRs) in the ground-capable one
+template <int B, bool GROUND> struct AccStore;
+template <int B> struct AccStore<B, false> {
+    lds_ptr l; int t;
+    __device__ __forceinline__ double get(int r) const { return l[r * B + t]; }
+    __device__ __forceinline__ void set(int r, double v) const { l[r * B + t] = v; }
+};
+template <int B> struct AccStore<B, true> {
+    double* r_;   // the kernel's local array (every index is a compile-time constant after unrolling: registers)
+    __device__ __forceinline__ double get(int r) const { return r_[r]; }
+    __device__ __forceinline__ void set(int r, double v) const { r_[r] = v; }
+};
+template <int B, bool GROUND = false>
 struct AirEmit {
     typedef void batched_tag;
     lds_cptr xs_l;            // x_n panel
-    lds_ptr acc_l, xwr_l;     // stage sum; the panel this stage writes (evaluation panel, at stage 3 x_n itself)
+    AccStore<B, GROUND> acc;  // stage sum
+    lds_ptr xwr_l;            // the panel this stage writes (evaluation panel, at stage 3 x_n itself)
     double eb, ee, em;
     bool last;
     int t;
-    using SV = StateLds<B>;
+    using SV = StateLds<B, GROUND>;
     __device__ __forceinline__ void operator()(int j, double kj) const {
-        if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) return;   // identically zero in the air
-        const int idx = SV::row(j) * B + t;
+        if (SV::skip(j)) return;   // identically zero in the air
+        const int r = SV::row(j), idx = r * B + t;
         const double xs = xs_l[idx];
-        const double A = __builtin_fma(eb, kj, acc_l[idx]);
-        acc_l[idx] = A * em;
+        const double A = __builtin_fma(eb, kj, acc.get(r));
+        acc.set(r, A * em);
         xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
     }
     template <int NE>
-    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {   // NE consecutive non-contact rows
+    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {   // NE consecutive rows (no contact rows among them in the air)
         double xs[NE], A[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) { const int idx = SV::row(j0 + e) * B + t; xs[e] = xs_l[idx]; A[e] = acc_l[idx]; }
+        for (int e = 0; e < NE; e++) { const int r = SV::row(j0 + e); xs[e] = xs_l[r * B + t]; A[e] = acc.get(r); }
 #pragma unroll
         for (int e = 0; e < NE; e++) A[e] = __builtin_fma(eb, k[e], A[e]);
 #pragma unroll
         for (int e = 0; e < NE; e++) {
-            const int idx = SV::row(j0 + e) * B + t;
-            acc_l[idx] = A[e] * em;
-            xwr_l[idx] = __builtin_fma(ee, last ? A[e] : k[e], xs[e]);
+            const int r = SV::row(j0 + e);
+            acc.set(r, A[e] * em);
+            xwr_l[r * B + t] = __builtin_fma(ee, last ? A[e] : k[e], xs[e]);
         }
     }
 };
-template <int KIN, bool X = false>
+template <int KIN, bool X = false, bool GROUND = false>
 __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
-    constexpr int B = STEP_BLOCK, NR = FB_NX - 6;
-    using SV = StateLds<B>;
+    constexpr int B = STEP_BLOCK, NR = GROUND ? (int)FB_NX : FB_NX - 6;
+    using SV = StateLds<B, GROUND>;
     using InT = typename std::conditional<X, InputsXAgg, InputsAgg>::type;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
-    __shared__ double acc_l[NR * B];   // k1 + 2 k2 + 2 k3
+    __shared__ double acc_l[GROUND ? 1 : NR * B];   // k1 + 2 k2 + 2 k3 (airborne pass; the ground-capable one keeps it in acc_r)
     __shared__ double xc_l[NR * B];    // the state being evaluated (x_n, or x_n + c dt k_j), updated in place by emit()
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    if constexpr (GROUND) {   // second pass: only the lanes the airborne pass handed over
+        const int mine = (i < a.n) && a.redo[i] != 0;
+        if (!__syncthreads_or(mine)) return;
+        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+        if (!mine) return;
+        a.redo[i] = 0;
+    } else {
+        stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+        if (i >= a.n) return;
+    }
     if (a.status[i] != 0) return;
     const int t = threadIdx.x;
+    double acc_r[GROUND ? NR : 1];
+    const AccStore<B, GROUND> acc = [&] { if constexpr (GROUND) return AccStore<B, true>{acc_r}; else return AccStore<B, false>{(lds_ptr)acc_l, t}; }();
     bool to_ground = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
         const double v = a.x[(int64_t)k * a.n + i];
-        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) to_ground = to_ground || (v != 0.0);
-        else { xs_l[SV::row(k) * B + t] = v; acc_l[SV::row(k) * B + t] = 0.0; }
+        if (SV::skip(k)) to_ground = to_ground || (v != 0.0);
+        else { xs_l[SV::row(k) * B + t] = v; acc.set(SV::row(k), 0.0); }
     }
     if (to_ground) { a.redo[i] = 1; return; }
-    if constexpr (X) {
+    if constexpr (X && !GROUND) {
         // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass must
         // find them as they were at launch start
         if (a.ctl_ratio > 0) {
@@ -558,7 +424,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     InT in;
     // actuator positions x_n and commands. Only the five the airborne RHS reads are tracked through the stages; the two brake
     // actuators are advanced at the end, over the steps this lane completed, with the same closed form.
-    constexpr int NAL = FB_ACT_BRAKE_LEFT;
+    constexpr int NAL = GROUND ? (int)FB_NACT : (int)FB_ACT_BRAKE_LEFT;   // (on the ground the brakes are inputs of the RHS like the rest)
     static_assert(FB_ACT_BRAKE_LEFT == 5 && FB_ACT_BRAKE_RIGHT == 6 && FB_NACT == 7, "brakes are the last two actuators");
     double xa[X ? NAL : 1], ca[X ? NAL : 1];
     int steps_alive = 0;
@@ -569,7 +435,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         sum_payload_of(in);
     } else {
         load_inputs(a, i, in);
-        in.u_glob = nullptr;   // ground-only inputs are never read here
+        if constexpr (!GROUND) in.u_glob = nullptr;   // ground-only inputs (steering, brakes) are never read in the air
         in.sum_payload();
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
@@ -584,16 +450,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     bool pending_cb = false, redoing = false;      // uniform
     bool alive = true, dead = false, run = true, handoff = false;   // per lane
     if constexpr (X) {
-        // FSAL across launches (see k_step): the previous launch's last evaluation sat at this very state. A wave whose lanes all
+        // FSAL across launches: the previous launch's last evaluation sat at this very state. A wave whose lanes all
         // hold a valid k1 starts at stage 1; otherwise the lanes without one evaluate it first while the others sit out.
         const bool have_k1 = a.k1 && a.k1_valid[i];
         if (have_k1) {
 #pragma unroll
             for (int j = 0; j < FB_NX; j++) {
-                if (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) continue;
+                if (SV::skip(j)) continue;
                 const int idx = SV::row(j) * B + t;
                 const double kj = a.k1[(int64_t)j * a.n + i];
-                acc_l[idx] = kj;
+                acc.set(SV::row(j), kj);
                 xc_l[idx] = xs_l[idx] + hdt * kj;
             }
         }
@@ -604,7 +470,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     while (true) {
         StepAux aux;
         int lds_off = 0;
-        asm volatile("" : "+s"(lds_off));   // see k_step: keeps loop-invariant LDS loads inside the loop
+        asm volatile("" : "+s"(lds_off));   // an opaque zero offset: without it LICM hoists every loop-invariant table / input load (~150 values) into VGPRs: 1.7 KB/lane of spills
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
         const bool last = stage == 3;
         const double eb = (stage == 1 || stage == 2) ? 2.0 : 1.0, ee = last ? dt6 : (stage == 2 ? dt : hdt), em = last ? 0.0 : 1.0;
@@ -620,16 +486,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 const double ms = stage == 0 ? 1.0 : (stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
 #pragma unroll
                 for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
-                xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
+                if constexpr (!GROUND) { xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0; }   // (never read in the air)
                 inl.xa = xa_s;
                 inl.u_glob = in.u_glob + lds_off;
             } else {
                 asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             }
-            const AirEmit<B> emit = {(lds_cptr)xs_l, (lds_ptr)acc_l, xwr_l, eb, ee, em, last, t};
+            const AirEmit<B, GROUND> emit = {(lds_cptr)xs_l, acc, xwr_l, eb, ee, em, last, t};
             const SV xv = {xrd_l + t + lds_off};
-            bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-            if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
+            bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
             if constexpr (X) {
                 if (last) {
                     const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
@@ -655,11 +521,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                     if (ctl_now && bits == 0 && !aux.crash) {
                         double xq[FB_X2_NX];
 #pragma unroll
-                        for (int k = 0; k < FB_NX; k++) xq[k] = (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) ? 0.0 : xs_l[SV::row(k) * B + t];
+                        for (int k = 0; k < FB_NX; k++) xq[k] = SV::skip(k) ? 0.0 : xs_l[SV::row(k) * B + t];
 #pragma unroll
-                        for (int k = 0; k < FB_NACT; k++) xq[X2_ACT + k] = k < NAL ? xa[k] : 0.0;   // (the brakes are not tapped)
+                        for (int k = 0; k < FB_NACT; k++) xq[X2_ACT + k] = k < NAL ? xa[k] : 0.0;   // (in the air the brakes are not tapped)
                         const double cmd4[4] = {ca[0], ca[1], ca[2], ca[3]};
-                        x2_periodic<false>(a, i, T, xq, stall, eng, in.ui, cmd4);
+                        x2_periodic<GROUND>(a, i, T, xq, stall, eng, in.ui, cmd4);
 #pragma unroll
                         for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
                     }
@@ -681,6 +547,16 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                 if (aux.alpha > c172::alpha_stall_hi) stall = 1;
                 else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
                 if (aux.crash) bits |= FB_ST_GROUND_CRASH;
+                if constexpr (GROUND) {   // the friction regulators of a unit without weight on its wheel are reset (landinggear.jl:479-483)
+#pragma unroll
+                    for (int g = 0; g < 3; g++) {
+                        if (!(aux.wow & (1 << g))) {
+                            const int i0 = SV::row(FB_X_LDG_FRC + 2 * g) * B + t, i1 = SV::row(FB_X_LDG_FRC + 2 * g + 1) * B + t;
+                            if (xs_l[i0] != 0.0 || xs_l[i1] != 0.0) mod = true;
+                            xs_l[i0] = 0.0; xs_l[i1] = 0.0;
+                        }
+                    }
+                }
                 const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
                 const bool fuel = aux.m_avail > 0;
                 const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
@@ -695,7 +571,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
                         if (keep) {
 #pragma unroll
                             for (int j = 0; j < FB_NX; j++)
-                                a.k1[(int64_t)j * a.n + i] = (j >= FB_X_LDG_FRC && j < FB_X_LDG_FRC + 6) ? 0.0 : acc_l[SV::row(j) * B + t];
+                                a.k1[(int64_t)j * a.n + i] = SV::skip(j) ? 0.0 : acc.get(SV::row(j));
                         }
                         a.k1_valid[i] = keep ? 1 : 0;
                     }
@@ -706,7 +582,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
                 if (mod) {
 #pragma unroll
-                    for (int r = 0; r < NR; r++) acc_l[r * B + t] = 0.0;   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
+                    for (int r = 0; r < NR; r++) acc.set(r, 0.0);   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
                 }
                 run = mod; redoing = true;
                 continue;
@@ -716,7 +592,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
-    if (handoff) {
+    if (!GROUND && handoff) {
         if constexpr (X) {
             if (a.ctl_ratio > 0) {   // nothing of this lane's launch is committed: undo the control-law updates it has made
 #pragma unroll 1
@@ -731,7 +607,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
-        if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) continue;
+        if (SV::skip(k)) continue;
         const double v = xs_l[SV::row(k) * B + t];
         bad = bad || !isfinite(v);
         a.x[(int64_t)k * a.n + i] = v;

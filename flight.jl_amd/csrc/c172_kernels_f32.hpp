@@ -1,6 +1,6 @@
 // c172_kernels_f32.hpp — the fp32 airborne stepper of Cessna172Sv0 (FB_F32 handles; BASELINE.json configs[4] asks for an fp32 fleet).
 //
-// Same algorithm and call order as k_step<false, WA, false> (c172_kernels.hpp), instantiated from the same source over
+// Same algorithm and call order as k_step_air<WA> (c172_kernels.hpp), instantiated from the same source over
 // `float` (namespace fbf of c172_device.hpp). What fp32 buys on gfx950 is not a faster FMA — scalar fp32 and fp64 VALU
 // instructions issue at the same rate — but half the registers and half the LDS per aircraft: the kernel fits TWO
 // workgroups per CU (two waves per SIMD), so one wave's LDS / memory waits are covered by the other's arithmetic, and
@@ -13,7 +13,7 @@
 //   * everything else — attitude, rates, velocities, aerodynamics, engine, mass, dynamics — is fp32;
 //   * fp32 cannot resolve wheel heights (ECEF coordinates are ~6.4e6 m: 0.5 m per ulp), so this instance is airborne-only by
 //     construction: a lane that comes within 10 m of the terrain stops uncommitted and is re-run, like in the fp64 path, by
-//     the fp64 ground-capable kernel k_step<false, WA, true>.
+//     the fp64 ground-capable kernel k_step_air<WA, false, true>.
 //   * q_wb is renormalised every step (its fp32 drift per step is of the order of the 1e-8 trigger of the reference).
 #pragma once
 #include "c172_kernels.hpp"
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
     while (true) {
         StepAux aux;
         int lds_off = 0;
-        asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step)
+        asm volatile("" : "+s"(lds_off));   // keeps the loop-invariant table loads inside the loop (see k_step_air)
         const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables_f32 + lds_off};
         const bool last = stage == 3;
         const float eb = (stage == 1 || stage == 2) ? 2.0f : 1.0f, ee = last ? dt6 : (stage == 2 ? dt : hdt);

@@ -1,4 +1,4 @@
-// c172x_kernels.hpp — Cessna172Xv2 kernels besides the stepping kernel (k_step<true> in c172_kernels.hpp):
+// c172x_kernels.hpp — Cessna172Xv2 kernels besides the stepping kernels (k_step_air<WA, true, GROUND> in c172_kernels.hpp, which also run the control laws every Δt):
 //   k_x2_ctl   f_periodic!(avionics, vehicle): the control laws on the outputs of the last f_ode! (aircraftbase.jl:232-242)
 //   k_x2_init  f_init!(aircraft, trim) after the trim solve: actuator states and the control-law initialisation
 //              (c172x.jl:285-326; aircraftbase.jl:255-265; c172x_ctl.jl:463-519, 1000-1032)

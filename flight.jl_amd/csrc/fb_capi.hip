@@ -63,7 +63,7 @@ struct fb_handle_s {
     double* cu = nullptr;      // [FB_NCU x n] control-law inputs
     double* q_pre = nullptr;   // [8 x n]
     double* ctl_bak = nullptr; // [(FB_NCS + FB_NCU) x n] scratch of the airborne pass (see KArgs::ctl_bak)
-    int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of k_step
+    int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of the stepping kernel
     double* k1 = nullptr;      // [FB_NX x n] Cessna172Xv2: FSAL derivative carried from launch to launch
     int32_t* k1_valid = nullptr;
     double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
@@ -143,19 +143,19 @@ static row_map_t row_map_of(fb_handle h) {
     do {                                                                                                                              \
         if (is_x2(h)) {                                                                                                               \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
-            hipLaunchKernelGGL((k_step<true, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                         \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
-            hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_ECEF, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
+            hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                 \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_ECEF, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                  \
         } else if (h->kin == FB_KIN_NED) {                                                                                            \
-            hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_NED, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                       \
+            hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                  \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_NED, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                   \
         } else if (h->dtype == FB_F32) {   /* fp32 airborne stepper; lanes near the ground go to the fp64 ground-capable kernel */    \
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                    \
         } else {                                                                                                                      \
             hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                   \
-            hipLaunchKernelGGL((k_step<false, FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                        \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                    \
         }                                                                                                                             \
     } while (0)
 static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
