@@ -199,7 +199,8 @@ def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     xf = w.x
     out["status_bad"] = int((st != 0).sum())
     out["fuel_not_decreasing"] = int((xf[8] >= fuel0).sum())
-    out["quat_off_unit"] = int(((np.abs(np.sqrt((xf[12:16] ** 2).sum(0)) - 1) > 1.1e-8) | (np.abs(np.sqrt((xf[16:20] ** 2).sum(0)) - 1) > 1.1e-8)).sum())
+    qtol = 1.1e-8 if args.dtype == "f64" else 5e-7    # f_step! renormalises beyond 1e-8 (kinematics.jl:114-118); the fp32 stepper holds q_wb to fp32 rounding
+    out["quat_off_unit"] = int(((np.abs(np.sqrt((xf[12:16] ** 2).sum(0)) - 1) > qtol) | (np.abs(np.sqrt((xf[16:20] ** 2).sum(0)) - 1) > qtol)).sum())
     out["non_finite"] = int((~np.isfinite(xf)).any(axis=0).sum())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -449,7 +450,7 @@ def main():
                        "aircraft_total": head["n_total"], "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "rk4_steps_per_contract_step": args.inner, "dt": DT,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "trim_success_fraction": head["trim_ok"] / head["n_total"], "trim_seconds": head["trim_s"], "terminated_aircraft": head["status_bad"],
-                       "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= 1e-8 (q_wb, q_ew), all states finite"},
+                       "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= " + ("1e-8" if args.dtype == "f64" else "5e-7") + " (q_wb, q_ew), all states finite"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": ("fbd::k_step_air<0, false>" if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "

@@ -1,5 +1,5 @@
 import sys, os, time, numpy as np, ctypes as C
-sys.path.insert(0, "flight.jl_amd"); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flight.jl_amd"))
 import flightbatch as fb
 n = 262144
 w = fb.BatchedWorld(n)

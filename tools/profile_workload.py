@@ -7,12 +7,12 @@ import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "flight.jl_amd")); sys.path.insert(0, R)
 import flightbatch as fb
-from bench import lattice, N_PER_GPU, DT
+from bench import lattice, N_TOTAL as N_PER_GPU, DT
 inner = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dtype = sys.argv[3] if len(sys.argv) > 3 else "f64"
 w = fb.BatchedWorld(N_PER_GPU, dtype=dtype)
-EAS, h, psi = lattice(0)
+EAS, h, psi, _ = lattice(0)
 fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
 xd = np.zeros((27, N_PER_GPU)); fb.f_ode(w, xd)          # calibration launch (k_f_ode with xdot)
 sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=inner)
