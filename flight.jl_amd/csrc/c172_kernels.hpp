@@ -215,8 +215,8 @@ __device__ __noinline__ void x2_periodic(const KArgs& a_in, int64_t i, const Tab
     // is an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit).
     typedef __attribute__((address_space(1))) double* gptr;
     typedef __attribute__((address_space(1))) const double* gcptr;
-    const CtlIn v = x2_ctl_inputs<GROUND>(a, i, T, x, stall, eng, ui, [&](int k) { return cmd[k]; });
     const CtlMemT<gptr> M = {(gptr)(uintptr_t)a.cu + i, (gptr)(uintptr_t)a.cs + i, a.n};
+    const CtlIn v = x2_ctl_inputs<GROUND>(a, i, T, x, stall, eng, ui, [&](int k) { return cmd[k]; });
     gdc_update(M, v);
     const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)a.gains, a.ctl_off};
     ctl_lon(tab, M, a.ctl_dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
@@ -525,7 +525,12 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
 #pragma unroll
                         for (int k = 0; k < FB_NACT; k++) xq[X2_ACT + k] = k < NAL ? xa[k] : 0.0;   // (in the air the brakes are not tapped)
                         const double cmd4[4] = {ca[0], ca[1], ca[2], ca[3]};
-                        x2_periodic<GROUND>(a, i, T, xq, stall, eng, in.ui, cmd4);
+                        // (copies by design: the callee takes its arguments by reference, i.e. through memory, and handing it the kernel's
+                        // own `a` / `T` would move the kernel arguments to scratch for the WHOLE kernel — every table pointer a per-lane
+                        // value, the knot scans' scalar loads turned into vector global loads: measured +25 % on every step)
+                        const KArgs a_call = a;
+                        const Tables T_call = T;
+                        x2_periodic<GROUND>(a_call, i, T_call, xq, stall, eng, in.ui, cmd4);
 #pragma unroll
                         for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
                     }
