@@ -87,7 +87,7 @@ def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False):
     fb.f_ode(w)
     y = w.y
     out = dict(phase=phase.copy(), status=w.status, v_gnd=y[K["FB_Y_KIN"] + 37], touchdown=touchdown, h_agl=y[K["FB_Y_KIN"] + 21] - H_ORTH,
-               e_sb=w.cs[K["FB_CS_SEG_E_SB"]])
+               e_sb=w.cs[K["FB_CS_SEG_E_SB"]], x=w.x, cs=w.cs)
     if verbose:
         print(f"n = {n}: phases {np.bincount(phase, minlength=4)}, terminated {int((w.status != 0).sum())}, touchdown at "
               f"{np.nanmin(touchdown[0]):.1f}-{np.nanmax(touchdown[0]):.1f} s, {np.nanmin(touchdown[1]):.0f}..{np.nanmax(touchdown[1]):.0f} m past the threshold, "

@@ -102,6 +102,9 @@ __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& 
     o.tau_b = cross(o.r_bc_b, F_b);
 }
 
+__device__ __noinline__ void gear_ground_kinematics_call(const GroundIn& in, GroundOut& o) { gear_ground_kinematics(in, o); }
+__device__ __noinline__ void gear_ground_force_call(const GroundIn& in, GroundOut& o) { gear_ground_force(in, o); }
+
 // ---- kernel arguments -----------------------------------------------------------------------
 struct KArgs {
     double* x;          // [NX x n]  (NX = 27, or 34 for Cessna172X: rows 27..33 = actuator positions)
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 // (same source, GROUND = true) then re-runs exactly those lanes from the same launch-start state (workgroups without such a lane
 // leave at once). History: the first generations kept the stage state in registers (k_step<X, KIN, GROUND>, 108 of the 256 VGPRs,
 // a fifth of its VALU instructions v_accvgpr moves, a per-lane stage machine); the ground-capable pass was the last user of that
-// form (4.9e8 aircraft-steps/s on the ground; 1.10e9 on this design with the contact branch inlined).
+// form (4.9e8 aircraft-steps/s on the ground; 7.9e8 on this design).
 // The stage state lives in a third LDS panel and is read at the point of use; emit() updates it IN PLACE (every row's derivative is produced after the last
 // read of that row within one evaluation — checked against rhs()'s source order), so neither array exists in registers.
 // LDS room for the third panel comes from two facts about an airborne aircraft: its six contact-regulator states are
@@ -313,8 +316,8 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
 #ifndef FB_AIR_SCALAR_KNOTS
 #define FB_AIR_SCALAR_KNOTS true
 #endif
-// GROUND = true is the same kernel for the lanes the airborne pass hands over (second pass of a launch): all 27 rows, the
-// ground-contact branch compiled in, and — 3 x 27 rows would not fit the LDS — the stage sum in registers instead of a panel.
+// GROUND = true is the same kernel for the lanes the airborne pass hands over (second pass of a launch): all 27 rows and the
+// ground-contact branch compiled in (see step_block() for its workgroup size).
 template <int STRIDE, bool GROUND = false>
 struct StateLds {
     lds_cptr p;   // &panel[lane]
@@ -332,9 +335,8 @@ struct StateLds {
 // Bit-identical to the branched form (acc + 1 k = k exactly at stage 0, A 1 = A, same fma's) and to the ground-capable kernel's:
 // near the ground a one-ulp difference in this combination is amplified to 1e-6 within a few hundred steps (tried:
 // x_n + dt/6 acc + dt/6 k4 saves the select and fails test_approach_crosses_the_air_ground_handover).
-// the stage sum k1 + 2 k2 + 2 k3: an LDS panel [rows][B] in the airborne pass, 27 registers per lane (the compiler parks them in
-// AGPRs) in the ground-capable one
-template <int B, bool GROUND> struct AccStore;
+// the stage sum k1 + 2 k2 + 2 k3: an LDS panel [rows][B], or (REGS, see step_acc_in_regs) NR registers per lane
+template <int B, bool REGS> struct AccStore;
 template <int B> struct AccStore<B, false> {
     lds_ptr l; int t;
     __device__ __forceinline__ double get(int r) const { return l[r * B + t]; }
@@ -345,11 +347,11 @@ template <int B> struct AccStore<B, true> {
     __device__ __forceinline__ double get(int r) const { return r_[r]; }
     __device__ __forceinline__ void set(int r, double v) const { r_[r] = v; }
 };
-template <int B, bool GROUND = false>
+template <int B, bool GROUND = false, bool ACC_REGS = false>
 struct AirEmit {
     typedef void batched_tag;
     lds_cptr xs_l;            // x_n panel
-    AccStore<B, GROUND> acc;  // stage sum
+    AccStore<B, ACC_REGS> acc;  // stage sum
     lds_ptr xwr_l;            // the panel this stage writes (evaluation panel, at stage 3 x_n itself)
     double eb, ee, em;
     bool last;
@@ -378,15 +380,31 @@ struct AirEmit {
         }
     }
 };
+// Lanes per workgroup, and where the stage sum lives. The airborne instances: 256 lanes, three 21-row panels (151 KB). The
+// ground-capable instances need all 27 rows: three 27-row panels fit the LDS for 192 lanes (147 KB), so they run three waves per
+// workgroup. Measured alternative (FB_GROUND_BLOCK=256 FB_GROUND_ACC_REGS=1: 256 lanes, two panels + the stage sum in 54 registers):
+// 1.13e9 instead of 7.9e8 aircraft-steps/s on a batch that sits on the ground, but at that register pressure (up to 1.5 KB of
+// scratch per lane in the Xv2 instance) this LLVM placed spill code before the exec restore of control-flow join blocks in some
+// instances (tools/check_isa_spills.py, which the build enforces): lanes then reload garbage and results change from run to run
+// (seen in the scripted crosswind landing, tools/det_check.py). Correctness first: 192 lanes, no instance trips the check.
+#ifndef FB_GROUND_BLOCK
+#define FB_GROUND_BLOCK 192
+#endif
+#ifndef FB_GROUND_ACC_REGS
+#define FB_GROUND_ACC_REGS 0
+#endif
+template <bool X, bool GROUND> constexpr int step_block() { return GROUND ? FB_GROUND_BLOCK : STEP_BLOCK; }
+template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND && FB_GROUND_ACC_REGS; }
 template <int KIN, bool X = false, bool GROUND = false>
-__global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
-    constexpr int B = STEP_BLOCK, NR = GROUND ? (int)FB_NX : FB_NX - 6;
+__global__ __launch_bounds__((step_block<X, GROUND>())) void k_step_air(KArgs a, int nsteps) {
+    constexpr int B = step_block<X, GROUND>(), NR = GROUND ? (int)FB_NX : FB_NX - 6;
+    constexpr bool ACC_REGS = step_acc_in_regs<X, GROUND>();
     using SV = StateLds<B, GROUND>;
     using InT = typename std::conditional<X, InputsXAgg, InputsAgg>::type;
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
-    __shared__ double acc_l[GROUND ? 1 : NR * B];   // k1 + 2 k2 + 2 k3 (airborne pass; the ground-capable one keeps it in acc_r)
+    __shared__ double acc_l[ACC_REGS ? 1 : NR * B];   // k1 + 2 k2 + 2 k3 (an LDS panel, or the registers acc_r: see step_acc_in_regs)
     __shared__ double xc_l[NR * B];    // the state being evaluated (x_n, or x_n + c dt k_j), updated in place by emit()
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (GROUND) {   // second pass: only the lanes the airborne pass handed over
@@ -401,8 +419,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
     }
     if (a.status[i] != 0) return;
     const int t = threadIdx.x;
-    double acc_r[GROUND ? NR : 1];
-    const AccStore<B, GROUND> acc = [&] { if constexpr (GROUND) return AccStore<B, true>{acc_r}; else return AccStore<B, false>{(lds_ptr)acc_l, t}; }();
+    double acc_r[ACC_REGS ? NR : 1];
+    const AccStore<B, ACC_REGS> acc = [&] { if constexpr (ACC_REGS) return AccStore<B, true>{acc_r}; else return AccStore<B, false>{(lds_ptr)acc_l, t}; }();
     bool to_ground = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
@@ -435,7 +453,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
         sum_payload_of(in);
     } else {
         load_inputs(a, i, in);
-        if constexpr (!GROUND) in.u_glob = nullptr;   // ground-only inputs (steering, brakes) are never read in the air
+        if constexpr (GROUND) in.load_ground_inputs();
+        in.u_glob = nullptr;   // (ground-only inputs are never read in the air, and the ground-capable pass has just fetched them)
         in.sum_payload();
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void k_step_air(KArgs a, int nsteps) {
             } else {
                 asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             }
-            const AirEmit<B, GROUND> emit = {(lds_cptr)xs_l, acc, xwr_l, eb, ee, em, last, t};
+            const AirEmit<B, GROUND, ACC_REGS> emit = {(lds_cptr)xs_l, acc, xwr_l, eb, ee, em, last, t};
             const SV xv = {xrd_l + t + lds_off};
             bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane

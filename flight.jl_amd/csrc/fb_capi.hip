@@ -143,19 +143,19 @@ static row_map_t row_map_of(fb_handle h) {
     do {                                                                                                                              \
         if (is_x2(h)) {                                                                                                               \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                     \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
             hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                 \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_ECEF, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                  \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_ECEF, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                  \
         } else if (h->kin == FB_KIN_NED) {                                                                                            \
             hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                  \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_NED, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                   \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_NED, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                   \
         } else if (h->dtype == FB_F32) {   /* fp32 airborne stepper; lanes near the ground go to the fp64 ground-capable kernel */    \
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                    \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                    \
         } else {                                                                                                                      \
             hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                   \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                    \
+            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                    \
         }                                                                                                                             \
     } while (0)
 static CtlArgs ctl_args(fb_handle h, int use_q_pre) {

@@ -24,6 +24,18 @@ def test_crosswind_landing_batch(fb):
     assert out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2         # stopped, sitting on its wheels
 
 
+def test_crosswind_landing_is_reproducible(fb):
+    """The same scenario twice in one process, bit for bit — through the airborne pass, the hand-over, the ground-capable pass and the
+    in-kernel control laws. (A kernel miscompiled at full register pressure — spill code before the exec restore of a join block,
+    tools/check_isa_spills.py — reloads whatever the scratch memory held: the two runs then differ, as they did during round 2.)"""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import crosswind_landing as demo
+    a = demo.run(n=64, t_end=120.0, seed=0)
+    b = demo.run(n=64, t_end=120.0, seed=0)
+    assert (a["phase"] >= 2).any(), "the horizon must include the flare and the ground roll"
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["cs"], b["cs"]) and np.array_equal(a["status"], b["status"])
+
+
 def test_traffic_pattern_batch(fb):
     """c172_demos.jl:502-645: cold start on the runway, engine start, takeoff, four guided legs, final, flare, landing, full stop."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
