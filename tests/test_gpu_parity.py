@@ -446,6 +446,31 @@ def test_approach_crosses_the_air_ground_handover(fb, oracle):
     assert (np.abs(x2 - xg) / state_scale(xo))[:, live & ~near].max() < 1e-9
 
 
+@pytest.mark.parametrize("kin", ["WA", "ECEF", "NED"])
+def test_ground_handover_is_reproducible(fb, kin):
+    """The same approach-to-touchdown batch twice, bit for bit, for every kinematic mechanisation: the ground-capable stepping
+    instances run at the highest register pressure of the library, where a miscompiled spill shows up as run-to-run differences
+    (tools/check_isa_spills.py; tests/test_gpu_scenarios.py does the same for Cessna172Xv2)."""
+    n = 1024
+    rng = np.random.default_rng(29)
+    h_trn = 300.0
+    tp = fb.TrimParameters(EAS=rng.uniform(33, 40, n), h_e=h_trn + rng.uniform(12, 30, n), γ_wb_n=-np.deg2rad(rng.uniform(2, 5, n)),
+                           flaps=1.0, ψ_nb=rng.uniform(-3, 3, n))
+    res = []
+    for _ in range(2):
+        w = fb.BatchedWorld(n, kinematics=kin)
+        w.set_params(h_terrain=h_trn)
+        fb.f_init(w, tp)
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=25)
+        fb.step(sim, 6.0); w.sync()
+        fb.f_ode(w)
+        y = w.y
+        res.append((w.x, w.s, w.status, (y[fb.K["FB_Y_LDG"] + 1] + y[fb.K["FB_Y_LDG"] + 12] + y[fb.K["FB_Y_LDG"] + 23]) > 0))
+        w.close()
+    assert res[0][3].sum() > 20, "the batch must reach the ground"
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res[0], res[1]))
+
+
 def test_f_ode_fuzz_wide_envelope(fb, oracle):
     """f_ode! on 65 536 random states far outside the benchmark's envelope — every attitude, −500 m … 25 km (three ISA layers),
     0 … 120 m/s in any direction, tumbling rates, every engine state, stalled or not, random inputs, wind and a non-standard day —
