@@ -395,8 +395,11 @@ struct AirEmit {
 #endif
 template <bool X, bool GROUND> constexpr int step_block() { return GROUND ? FB_GROUND_BLOCK : STEP_BLOCK; }
 template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND && FB_GROUND_ACC_REGS; }
+#ifndef FB_STEP_ATTR
+#define FB_STEP_ATTR
+#endif
 template <int KIN, bool X = false, bool GROUND = false>
-__global__ __launch_bounds__((step_block<X, GROUND>())) void k_step_air(KArgs a, int nsteps) {
+__global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step_air(KArgs a, int nsteps) {
     constexpr int B = step_block<X, GROUND>(), NR = GROUND ? (int)FB_NX : FB_NX - 6;
     constexpr bool ACC_REGS = step_acc_in_regs<X, GROUND>();
     using SV = StateLds<B, GROUND>;
