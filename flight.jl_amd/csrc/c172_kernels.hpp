@@ -133,9 +133,12 @@ struct KArgs {
     int ctl_ratio;        // Δt / dt (0: never)
     int ctl_phase;        // steps taken since the last init, modulo ctl_ratio, when the launch starts
     double* ctl_bak;      // [(FB_NCS + FB_NCU) x n] the airborne pass's copy of cs | cu at launch start (restored for lanes it hands over)
+    double* duo_pld;      // [DUO_NCONST x n] k_step_duo: per-aircraft constants of the launch (the payload's mass-property sums, the
+                          // deflection-only aerodynamic terms), written by its prologue and read back at the top of every evaluation
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
+constexpr int DUO_NCONST = 22;   // rows of KArgs::duo_pld: 10 payload sums, 8 aerodynamic sums, 2 x (interval, weight) of the flap-axis locations
 
 // Stage the [aero | piston | propeller] blob into LDS. NC = propeller coefficients kept per grid point: all six when the
 // full output record is produced, the first four (C_Fx, C_Mx, C_Fz_α, C_Mz_α) otherwise — 7 KB of LDS less.
@@ -656,6 +659,322 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     if (bad) a.status[i] |= FB_ST_NAN;
     a.s[i] = stall;
     a.s[a.n + i] = eng;
+}
+
+// ---- the wave-specialised airborne stepper (Cessna172Sv0) --------------------------------------------------------------------------
+// k_step_air is bound by what ONE wave per SIMD can issue: its 151 KB of LDS panels and ~450 registers leave room for no second
+// wave, every instruction costs the lone wave ~4.3 cycles and nothing hides an LDS round trip. k_step_duo serves the
+// same 256 aircraft per workgroup with EIGHT waves: waves 0-3 ("P") evaluate kinematics rows, propeller, engine, fuel and mass
+// properties, waves 4-7 ("D") aerodynamics, landing gear (the airborne shortcut) and the rigid-body dynamics — see the roles of
+// rhs(). Wave w and wave w + 4 sit on the same SIMD and work on the same 64 aircraft, so the SIMD always has a second instruction
+// stream to issue from; each role needs at most 256 registers. Per evaluation the pair meets at two workgroup barriers: at the
+// top (the previous evaluation's emits are visible) and at the exchange point in the middle (P hands the propeller wrench and the
+// mass properties over through a 17-row LDS panel; before it nobody overwrites a row the other role still reads, see rhs()).
+// A third barrier precedes f_step!, which modifies x_{n+1} in place. LDS: tables 22 KB, x_n and the evaluation state 2 x 42 KB,
+// D's eight stage sums 16 KB (P keeps its thirteen in registers), exchange 34 KB, flags 1 KB = 157 KB.
+// The step's bookkeeping (stage machine, f_step!, status, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
+// P follows through a per-lane flag word and a per-pair control word in LDS.
+constexpr int DUO_B = 256;
+constexpr int DUO_NPL = 7;   // how many of role P's thirteen stage sums live in LDS (what is left of the 160 KB)
+template <int ROLE>
+struct DuoEmit {
+    static constexpr int role = ROLE;
+    typedef void batched_tag;
+    using SV = StateLds<DUO_B, false>;
+    lds_cptr xs_l;     // x_n panel
+    lds_ptr xwr_l;     // the panel this stage writes
+    lds_ptr accd_l;    // role D: its eight stage sums [8][DUO_B]; role P: the first DUO_NPL of its thirteen [DUO_NPL][DUO_B]
+    double* acc_r;     // role P: the rest of its stage sums (registers)
+    lds_ptr xch_l;     // exchange panel [XC_ROWS - 6][DUO_B] (rows 6.. of the exchange)
+    lds_ptr xov_l;     // rows 0-5 of the exchange: the angular / linear velocity rows of the evaluation panel, which nobody reads
+                       // between the head barrier and D's own emit of those rows at the end of the evaluation
+    double eb, ee, em;
+    bool last;
+    int t;
+    // panel rows: 0-1 filters (D), 2 fuel, 3-5 engine, 6-14 q_wb q_ew h_e (P), 15-20 angular and linear velocity (D)
+    __device__ __forceinline__ static constexpr bool owned(int j) {
+        if (SV::skip(j)) return false;
+        const int r = SV::row(j);
+        return ROLE == 1 ? (r >= 2 && r <= 14) : (r < 2 || r >= 15);
+    }
+    __device__ __forceinline__ static constexpr int slot(int r) { return ROLE == 1 ? r - 2 : (r < 2 ? r : r - 13); }
+    __device__ __forceinline__ double aget(int r) const {
+        if (ROLE == 1 && slot(r) >= DUO_NPL) return acc_r[slot(r) - DUO_NPL];
+        return accd_l[slot(r) * DUO_B + t];
+    }
+    __device__ __forceinline__ void aset(int r, double v) const {
+        if (ROLE == 1 && slot(r) >= DUO_NPL) acc_r[slot(r) - DUO_NPL] = v;
+        else accd_l[slot(r) * DUO_B + t] = v;
+    }
+    __device__ __forceinline__ void operator()(int j, double kj) const {
+        if (!owned(j)) return;
+        const int r = SV::row(j), idx = r * DUO_B + t;
+        const double xs = xs_l[idx];
+        const double A = __builtin_fma(eb, kj, aget(r));
+        aset(r, A * em);
+        xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
+    }
+    template <int NE>
+    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {   // (no batch straddles the roles)
+        if (!owned(j0)) return;
+        double xs[NE], A[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) { const int r = SV::row(j0 + e); xs[e] = xs_l[r * DUO_B + t]; A[e] = aget(r); }
+#pragma unroll
+        for (int e = 0; e < NE; e++) A[e] = __builtin_fma(eb, k[e], A[e]);
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int r = SV::row(j0 + e);
+            aset(r, A[e] * em);
+            xwr_l[r * DUO_B + t] = __builtin_fma(ee, last ? A[e] : k[e], xs[e]);
+        }
+    }
+    __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
+    __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
+    __device__ __forceinline__ void xsync() const { __syncthreads(); }
+};
+enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
+enum { DUO_C_EXIT = 4, DUO_C_CB = 8 };                              // per-pair control word: stage | EXIT | CB
+template <int KIN>
+__global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
+    constexpr int B = DUO_B, NR = FB_NX - 6, NP = 13, ND = 8;
+    using SV = StateLds<B, false>;
+    static_assert(KIN == FB_KIN_WA, "the wave-specialised stepper is built for the WA mechanisation");
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
+    __shared__ double rk[LDS_RK_DOUBLES];
+    __shared__ double xs_l[NR * B];    // x_n
+    __shared__ double xc_l[NR * B];    // the state being evaluated, updated in place by the emits
+    __shared__ double accd_l[ND * B];  // role D's stage sums
+    __shared__ double accp_l[DUO_NPL * B];   // role P's, as far as the LDS goes
+    __shared__ double xch_l[(XC_ROWS - 6) * B];
+    __shared__ int flags_l[B];
+    __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
+    __shared__ int ctrl_l[4];
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) + 1;   // 1: P (waves 0-3), 2: D (waves 4-7)
+    const int t = threadIdx.x & (B - 1);
+    const int pair = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int64_t i = (int64_t)blockIdx.x * B + t;
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    const bool valid = i < a.n && a.status[i] == 0;
+    const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    // what an evaluation at stage `stg` needs (wave-uniform)
+    struct StageK { bool last; double eb, ee, em; lds_cptr xrd_l; lds_ptr xwr_l; };
+    auto stage_k = [&](int stg) {
+        StageK k;
+        k.last = stg == 3;
+        k.eb = (stg == 1 || stg == 2) ? 2.0 : 1.0; k.ee = k.last ? dt6 : (stg == 2 ? dt : hdt); k.em = k.last ? 0.0 : 1.0;
+        // panel roles: stage 0 evaluates x_n straight from xs_l, stages 1-3 the state the previous stage left in xc_l; stages 0-2
+        // write the next evaluation state to xc_l, stage 3 the new x_n to xs_l
+        k.xrd_l = stg == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
+        k.xwr_l = k.last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
+        return k;
+    };
+    if (role == 1) {
+        // ================= role P =================
+        InputsAgg in;
+        in.ui = 0; in.u_glob = nullptr; in.n = a.n;
+        in.throttle = 0; in.mixture = 0; in.pld_M = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) in.pld_Mr[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) in.pld_J[k] = 0;
+        if (valid) { load_inputs(a, i, in); in.u_glob = nullptr; in.sum_payload(); }
+        // the payload's ten mass-property sums go to memory and come back at the top of every evaluation, where the mass properties
+        // are the first thing computed: twenty registers that would otherwise ride through the whole evaluation
+        const int64_t ic = valid ? i : 0;
+        double* pld_g = a.duo_pld + ic;
+        if (valid) {
+            pld_g[0] = in.pld_M;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pld_g[(int64_t)(1 + k) * a.n] = in.pld_Mr[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pld_g[(int64_t)(4 + k) * a.n] = in.pld_J[k];
+        }
+        double acc_r[NP - DUO_NPL];
+#pragma unroll
+        for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
+        __threadfence_block();
+#pragma unroll 1
+        while (true) {
+            double pc[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) pc[k] = pld_g[(int64_t)k * a.n];   // (in flight across the barrier)
+            __syncthreads();   // the previous evaluation's emits, and D's flag / control words, are visible
+            const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
+            const int f = flags_l[t];
+            if (c & DUO_C_EXIT) break;
+            const bool run = f & DUO_F_RUN;
+            const int eng = (f >> DUO_F_ENG_SHIFT) & 3;
+            if (f & DUO_F_ZERO_ACC) {
+#pragma unroll
+                for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
+            }
+            const StageK sk = stage_k(c & 3);
+            int lds_off = 0;
+            asm volatile("" : "+s"(lds_off));   // (see k_step_air: keeps the loop-invariant table / input loads from being hoisted into registers)
+            const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
+            if (__builtin_amdgcn_ballot_w64(run) != 0) {   // (the same in both waves of a pair)
+                if (run) {
+                    StepAux aux;
+                    InputsAgg inl;
+                    inl.ui = in.ui; inl.u_glob = nullptr; inl.n = in.n; inl.throttle = in.throttle; inl.mixture = in.mixture;
+                    inl.pld_M = pc[0];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) inl.pld_Mr[k] = pc[1 + k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) inl.pld_J[k] = pc[4 + k];
+                    asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
+                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                    const SV xv = {sk.xrd_l + t + lds_off};
+                    rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, 0, eng, inl, a.env, T, emit, aux, NoSink{});
+                }
+            } else { __syncthreads(); __syncthreads(); }   // (the two barriers of an evaluation nobody runs)
+            if (c & DUO_C_CB) __syncthreads();
+        }
+        return;
+    }
+    // ================= role D =================
+    // The lane's bookkeeping state lives in an LDS word between evaluations (D_* bits): kept in registers it is what the allocator
+    // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
+    enum { D_ALIVE = 1, D_DEAD = 2, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };
+    InputsAgg in;
+    in.ui = 0; in.u_glob = nullptr; in.n = a.n;
+    {
+        int stall = 0, eng = 0;
+        bool to_ground = false;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < FB_NX; k++) {
+                const double v = a.x[(int64_t)k * a.n + i];
+                if (SV::skip(k)) to_ground = to_ground || (v != 0.0);
+                else xs_l[SV::row(k) * B + t] = v;
+            }
+            if (to_ground) a.redo[i] = 1;
+            stall = a.s[i]; eng = a.s[a.n + i];
+            load_inputs(a, i, in); in.u_glob = nullptr; in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
+            const double ac[12] = {in.cd_in, in.cd_df, in.cy_in, in.cl_in, in.cl_df, in.croll_in, in.cm_in, in.cn_in,
+                                   (double)in.l_df4.i, in.l_df4.w, (double)in.l_df2.i, in.l_df2.w};
+#pragma unroll
+            for (int k = 0; k < 12; k++) a.duo_pld[(int64_t)(10 + k) * a.n + i] = ac[k];
+        }
+#pragma unroll
+        for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;
+        const bool active = valid && !to_ground;   // this launch owns the lane's state
+        dst_l[t] = (active ? (D_ALIVE | D_ACTIVE) : 0) | (stall ? D_STALL : 0) | (eng << D_ENG_SHIFT);
+        flags_l[t] = (active ? DUO_F_RUN : 0) | (eng << DUO_F_ENG_SHIFT);
+    }
+    // the wave-uniform stage machine (k_step_air's)
+    int stage = 0, step = 0;
+    bool pending_cb = false, redoing = false, exit_ = __builtin_amdgcn_ballot_w64(dst_l[t] & D_ALIVE) == 0;
+    if ((threadIdx.x & 63) == 0) ctrl_l[pair] = exit_ ? DUO_C_EXIT : 0;
+    const double* aero_g = a.duo_pld + (int64_t)10 * a.n + (valid ? i : 0);
+    __threadfence_block();
+#pragma unroll 1
+    while (true) {
+        double ac[12];   // the launch's aerodynamic constants, back from memory (see role P's payload sums)
+#pragma unroll
+        for (int k = 0; k < 12; k++) ac[k] = aero_g[(int64_t)k * a.n];
+        __syncthreads();
+        if (exit_) break;
+        const bool cb = stage == 0 && pending_cb && !redoing;
+        const StageK sk = stage_k(stage);
+        int lds_off = 0;
+        asm volatile("" : "+s"(lds_off));
+        const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
+        StepAux aux;
+        aux.alpha = 0; aux.m_avail = 0; aux.wow = 0; aux.crash = 0;
+        int32_t bits = 0;
+        bool run = flags_l[t] & DUO_F_RUN;
+        if (__builtin_amdgcn_ballot_w64(run) != 0) {
+            if (run) {
+                const int d0 = dst_l[t];
+                InputsAgg inl;
+                inl.ui = 0; inl.u_glob = nullptr; inl.n = a.n;
+                inl.cd_in = ac[0]; inl.cd_df = ac[1]; inl.cy_in = ac[2]; inl.cl_in = ac[3]; inl.cl_df = ac[4]; inl.croll_in = ac[5];
+                inl.cm_in = ac[6]; inl.cn_in = ac[7];
+                inl.l_df4 = {(int)ac[8], ac[9]}; inl.l_df2 = {(int)ac[10], ac[11]};
+                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                const SV xv = {sk.xrd_l + t + lds_off};
+                bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux, NoSink{});
+            }
+        } else { __syncthreads(); __syncthreads(); }
+        if (cb) __syncthreads();   // role P has read x_{n+1} for the last time: f_step! may modify it
+        int d = dst_l[t];
+        if (run && (bits & FB_ST_INTERNAL_REDO)) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }   // nothing is committed for this lane
+        bool zero_acc = false, advance = true;
+        if (redoing) { redoing = false; run = d & D_ALIVE; }   // the lanes that sat out the re-evaluation of k1 join again
+        else if (stage == 0 && pending_cb) {
+            // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
+            pending_cb = false;
+            step++;
+            bool mod = false;
+            if (run) {
+                auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229
+                    double q[4] = {0, 0, 0, 0}, n2 = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (k < len) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
+                    const double nr = ::sqrt(n2);
+                    if (fabs(nr - 1.0) > 1e-8) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (k < len) xs_l[SV::row(k0 + k) * B + t] = q[k] / nr;
+                        mod = true;
+                    }
+                };
+                renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4);
+                int stall = (d & D_STALL) ? 1 : 0, eng = (d >> D_ENG_SHIFT) & 3;
+                const int stall0 = stall, eng0 = eng;
+                if (aux.alpha > c172::alpha_stall_hi) stall = 1;
+                else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
+                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
+                const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
+                const bool fuel = aux.m_avail > 0;
+                const int ui = a.ui[i];
+                const bool start = ui & FB_UI_ENG_START, stop = ui & FB_UI_ENG_STOP;
+                if (eng == 0) { if (start) eng = 1; }
+                else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
+                else if (stop || w < c172::w_stall || !fuel) eng = 0;
+                mod = mod || stall != stall0 || eng != eng0;
+                d = (d & ~(D_STALL | (3 << D_ENG_SHIFT))) | (stall ? D_STALL : 0) | (eng << D_ENG_SHIFT);
+                if (bits != 0) { a.status[i] |= bits; d |= D_DEAD; bits = 0; }
+                if (d & D_DEAD) { d &= ~D_ALIVE; run = false; mod = false; }
+            }
+            if (step == nsteps || __builtin_amdgcn_ballot_w64(d & D_ALIVE) == 0) { exit_ = true; advance = false; }
+            else if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
+                if (mod) {
+#pragma unroll
+                    for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
+                }
+                zero_acc = mod; run = mod; redoing = true; advance = false;
+            }
+        }
+        if (advance) {
+            if (bits != 0) { a.status[i] |= bits; d |= D_DEAD; }
+            stage = (stage + 1) & 3;
+            pending_cb = (stage == 0);
+        }
+        dst_l[t] = d;
+        flags_l[t] = (run ? DUO_F_RUN : 0) | (zero_acc ? DUO_F_ZERO_ACC : 0) | (((d >> D_ENG_SHIFT) & 3) << DUO_F_ENG_SHIFT);
+        if ((threadIdx.x & 63) == 0)
+            ctrl_l[pair] = stage | (exit_ ? DUO_C_EXIT : 0) | ((stage == 0 && pending_cb && !redoing) ? DUO_C_CB : 0);
+    }
+    const int d = dst_l[t];
+    if (!(d & D_ACTIVE)) return;
+    if (d & D_HANDOFF) { a.redo[i] = 1; return; }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < FB_NX; k++) {
+        if (SV::skip(k)) continue;
+        const double v = xs_l[SV::row(k) * B + t];
+        bad = bad || !isfinite(v);
+        a.x[(int64_t)k * a.n + i] = v;
+    }
+    if (bad) a.status[i] |= FB_ST_NAN;
+    a.s[i] = (d & D_STALL) ? 1 : 0;
+    a.s[a.n + i] = (d >> D_ENG_SHIFT) & 3;
 }
 
 // ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------

@@ -53,6 +53,7 @@ struct fb_handle_s {
     bool have_table[4] = {false, false, false, false};
     fb_params params;
     int32_t steps_per_launch = 1;
+    bool duo = false;   // the wave-specialised airborne stepper (see env_step_duo)
     double t = 0.0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -63,6 +64,7 @@ struct fb_handle_s {
     double* cu = nullptr;      // [FB_NCU x n] control-law inputs
     double* q_pre = nullptr;   // [8 x n]
     double* ctl_bak = nullptr; // [(FB_NCS + FB_NCU) x n] scratch of the airborne pass (see KArgs::ctl_bak)
+    double* duo_pld = nullptr; // [DUO_NCONST x n] scratch of k_step_duo (see KArgs::duo_pld)
     int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of the stepping kernel
     double* k1 = nullptr;      // [FB_NX x n] Cessna172Xv2: FSAL derivative carried from launch to launch
     int32_t* k1_valid = nullptr;
@@ -84,7 +86,7 @@ static KArgs make_args(fb_handle h) {
     a.dt = h->params.dt;
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
-    a.gains = h->gains; a.ctl_bak = h->ctl_bak;
+    a.gains = h->gains; a.ctl_bak = h->ctl_bak; a.duo_pld = h->duo_pld;
     for (int k = 0; k < 10; k++) a.ctl_off.off[k] = (int)h->gains_off[k];
     a.ctl_off.total = (int)h->gains_total;
     const int ratio = h->params.periodic_n > 0 ? h->params.periodic_n : 1;
@@ -138,6 +140,9 @@ static row_map_t row_map_of(fb_handle h) {
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
     } while (0)
+// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): 1 selects the wave-specialised airborne stepper
+// k_step_duo for Cessna172Sv0 / WA / fp64, 0 the one-wave-per-SIMD k_step_air
+static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : false; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
 #define FB_LAUNCH_STEP(GRID, A, K)                                                                                                    \
     do {                                                                                                                              \
@@ -154,7 +159,8 @@ static row_map_t row_map_of(fb_handle h) {
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                    \
         } else {                                                                                                                      \
-            hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                   \
+            if (h->duo) hipLaunchKernelGGL(k_step_duo<FB_KIN_WA>, grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);    \
+            else hipLaunchKernelGGL(k_step_air<FB_KIN_WA>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                              \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                    \
         }                                                                                                                             \
     } while (0)
@@ -247,6 +253,7 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (device_id >= ndev) return fail("device_id out of range");
     HIPCHK(hipSetDevice(device_id));
     fb_handle h = new fb_handle_s();
+    h->duo = env_step_duo();
     h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
     h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
     h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
@@ -269,7 +276,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
-    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
@@ -624,6 +631,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
         HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * TABLE_BUF_DOUBLES, hipMemcpyHostToDevice));
         h->tables_f32_stale = false;
     }
+    if (h->duo && !h->duo_pld) HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * h->n));
     KArgs a = make_args(h);
     int64_t left = nsteps;
     // Cessna172Xv2: the control laws run inside the stepping kernels every Δt/dt steps (cb_periodic after cb_step, FC/sim.jl:204-218,
