@@ -133,12 +133,12 @@ struct KArgs {
     int ctl_ratio;        // Δt / dt (0: never)
     int ctl_phase;        // steps taken since the last init, modulo ctl_ratio, when the launch starts
     double* ctl_bak;      // [(FB_NCS + FB_NCU) x n] the airborne pass's copy of cs | cu at launch start (restored for lanes it hands over)
-    double* duo_pld;      // [DUO_NCONST x n] k_step_duo: per-aircraft constants of the launch (the payload's mass-property sums, the
-                          // deflection-only aerodynamic terms), written by its prologue and read back at the top of every evaluation
+    double* duo_pld;      // [DUO_NCONST x n] k_step_duo: per-aircraft constants of the launch (the deflection-only aerodynamic terms),
+                          // written by its prologue and fetched at the start of every evaluation's aerodynamics block
 };
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
-constexpr int DUO_NCONST = 22;   // rows of KArgs::duo_pld: 10 payload sums, 8 aerodynamic sums, 2 x (interval, weight) of the flap-axis locations
+constexpr int DUO_NCONST = 12;   // rows of KArgs::duo_pld: 8 aerodynamic sums, 2 x (interval, weight) of the flap-axis locations
 
 // Stage the [aero | piston | propeller] blob into LDS. NC = propeller coefficients kept per grid point: all six when the
 // full output record is produced, the first four (C_Fx, C_Mx, C_Fz_α, C_Mz_α) otherwise — 7 KB of LDS less.
@@ -384,20 +384,22 @@ struct AirEmit {
     }
 };
 // Lanes per workgroup, and where the stage sum lives. The airborne instances: 256 lanes, three 21-row panels (151 KB). The
-// ground-capable instances need all 27 rows: three 27-row panels fit the LDS for 192 lanes (147 KB), so they run three waves per
-// workgroup. Measured alternative (FB_GROUND_BLOCK=256 FB_GROUND_ACC_REGS=1: 256 lanes, two panels + the stage sum in 54 registers):
-// 1.13e9 instead of 7.9e8 aircraft-steps/s on a batch that sits on the ground, but at that register pressure (up to 1.5 KB of
-// scratch per lane in the Xv2 instance) this LLVM placed spill code before the exec restore of control-flow join blocks in some
+// ground-capable instances need all 27 rows. Cessna172Sv0: 256 lanes, two 27-row panels + the stage sum in 54 registers (450-458
+// registers, no scratch). Cessna172Xv2 (whose control-law call pushes it to 512 registers + scratch): three 27-row panels fit the LDS
+// for 192 lanes (147 KB), three waves per workgroup.
+// History: at full register pressure this LLVM places spill code before the exec restore of control-flow join blocks in some
 // instances (tools/check_isa_spills.py, which the build enforces): lanes then reload garbage and results change from run to run
-// (seen in the scripted crosswind landing, tools/det_check.py). Correctness first: 192 lanes, no instance trips the check.
-#ifndef FB_GROUND_BLOCK
-#define FB_GROUND_BLOCK 192
+// (seen in the scripted crosswind landing, tools/det_check.py). With machine LICM on (the fp64 literal pairs hoisted out of the loop,
+// see __graft_entry__.py) the 256-lane form tripped that check and every ground instance ran 192 lanes (7.9e8 aircraft-steps/s on a
+// batch sitting on the ground); without it the Sv0 instances have registers to spare and no spill code at all.
+#ifndef FB_GROUND_BLOCK_X
+#define FB_GROUND_BLOCK_X 192
 #endif
-#ifndef FB_GROUND_ACC_REGS
-#define FB_GROUND_ACC_REGS 0
+#ifndef FB_GROUND_BLOCK_S
+#define FB_GROUND_BLOCK_S 256
 #endif
-template <bool X, bool GROUND> constexpr int step_block() { return GROUND ? FB_GROUND_BLOCK : STEP_BLOCK; }
-template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND && FB_GROUND_ACC_REGS; }
+template <bool X, bool GROUND> constexpr int step_block() { return GROUND ? (X ? FB_GROUND_BLOCK_X : FB_GROUND_BLOCK_S) : STEP_BLOCK; }
+template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND && step_block<X, GROUND>() > 192; }
 #ifndef FB_STEP_ATTR
 #define FB_STEP_ATTR
 #endif
@@ -675,7 +677,43 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
 // The step's bookkeeping (stage machine, f_step!, status, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
 // P follows through a per-lane flag word and a per-pair control word in LDS.
 constexpr int DUO_B = 256;
-constexpr int DUO_NPL = 7;   // how many of role P's thirteen stage sums live in LDS (what is left of the 160 KB)
+constexpr int DUO_D_PALT = 128;   // bit of role D's bookkeeping word: role P found the CoM outside the altitude range
+constexpr int DUO_NPL = 1;   // how many of role P's thirteen stage sums live in LDS (what is left of the 160 KB)
+// Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation, and at 256 registers per
+// wave that is the difference between no spills and a dozen exposed scratch round trips per evaluation. Role P reads the payload's
+// ten mass-property sums from an LDS panel at the point of use; role D (no LDS left) fetches its aerodynamic sums from global
+// memory at the start of the aerodynamics block — one batch of loads whose latency the table lookups cover.
+struct InputsDuoP {
+    static constexpr bool pld_precomputed = true, aero_precomputed = true;
+    lds_cptr pld_l;   // &panel[lane], rows: M, Mr[3], J[6]
+    double throttle, mixture;
+    int ui;
+    __device__ __forceinline__ double get_throttle() const { return throttle; }
+    __device__ __forceinline__ double get_mixture() const { return mixture; }
+    __device__ __forceinline__ double get_pld_M() const { return pld_l[0]; }
+    __device__ __forceinline__ double get_pld_Mr(int k) const { return pld_l[(1 + k) * DUO_B]; }
+    __device__ __forceinline__ double get_pld_J(int k) const { return pld_l[(4 + k) * DUO_B]; }
+    __device__ __forceinline__ void fetch_aero(AeroC&) const {}
+};
+struct InputsDuoD {
+    static constexpr bool pld_precomputed = true, aero_precomputed = true;
+    const double* aero_g;   // &duo_pld[0 * n + i]
+    int64_t n;
+    int ui;
+    __device__ __forceinline__ void fetch_aero(AeroC& c) const {
+        double v[DUO_NCONST];
+#pragma unroll
+        for (int k = 0; k < DUO_NCONST; k++) v[k] = aero_g[(int64_t)k * n];
+        __builtin_amdgcn_sched_barrier(0);   // (issued here, not where the scheduler would like them: right before their use)
+        c.cd_in = v[0]; c.cd_df = v[1]; c.cy_in = v[2]; c.cl_in = v[3]; c.cl_df = v[4]; c.croll_in = v[5]; c.cm_in = v[6]; c.cn_in = v[7];
+        c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
+    }
+    __device__ __forceinline__ double get_throttle() const { return 0; }
+    __device__ __forceinline__ double get_mixture() const { return 0; }
+    __device__ __forceinline__ double get_pld_M() const { return 0; }
+    __device__ __forceinline__ double get_pld_Mr(int) const { return 0; }
+    __device__ __forceinline__ double get_pld_J(int) const { return 0; }
+};
 template <int ROLE>
 struct DuoEmit {
     static constexpr int role = ROLE;
@@ -686,6 +724,7 @@ struct DuoEmit {
     lds_ptr accd_l;    // role D: its eight stage sums [8][DUO_B]; role P: the first DUO_NPL of its thirteen [DUO_NPL][DUO_B]
     double* acc_r;     // role P: the rest of its stage sums (registers)
     lds_ptr xch_l;     // exchange panel [XC_ROWS - 6][DUO_B] (rows 6.. of the exchange)
+    int* dst_p;        // role D's bookkeeping word of this lane (role P raises DUO_D_PALT in it)
     lds_ptr xov_l;     // rows 0-5 of the exchange: the angular / linear velocity rows of the evaluation panel, which nobody reads
                        // between the head barrier and D's own emit of those rows at the end of the evaluation
     double eb, ee, em;
@@ -732,6 +771,7 @@ struct DuoEmit {
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
     __device__ __forceinline__ void xsync() const { __syncthreads(); }
+    __device__ __forceinline__ void xstatus(int32_t) const { *dst_p |= DUO_D_PALT; }   // (the one status bit role P can find: altitude range at the CoM)
 };
 enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
 enum { DUO_C_EXIT = 4, DUO_C_CB = 8 };                              // per-pair control word: stage | EXIT | CB
@@ -740,21 +780,27 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = 13, ND = 8;
     using SV = StateLds<B, false>;
     static_assert(KIN == FB_KIN_WA, "the wave-specialised stepper is built for the WA mechanisation");
-    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
+    __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs())
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
     __shared__ double xc_l[NR * B];    // the state being evaluated, updated in place by the emits
     __shared__ double accd_l[ND * B];  // role D's stage sums
     __shared__ double accp_l[DUO_NPL * B];   // role P's, as far as the LDS goes
+    __shared__ double pld_l[10 * B];   // role P: the payload's mass-property sums
     __shared__ double xch_l[(XC_ROWS - 6) * B];
     __shared__ int flags_l[B];
     __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
-    __shared__ int ctrl_l[4];
+    static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
+    int* ctrl_l = (int*)&rk[LDS_ATAN + ATAN_N];   // one control word per wave pair (the LDS is full to the last 16 bytes)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) + 1;   // 1: P (waves 0-3), 2: D (waves 4-7)
     const int t = threadIdx.x & (B - 1);
     const int pair = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t i = (int64_t)blockIdx.x * B + t;
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = a.tables[k];
+    __syncthreads();
+    for (int k = threadIdx.x; k < LDS_RK_KNOTS; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
+    for (int k = threadIdx.x; k < ATAN_N; k += blockDim.x) rk[LDS_ATAN + k] = atan(k * (1.0 / 32));
+    __syncthreads();
     const bool valid = i < a.n && a.status[i] == 0;
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     // what an evaluation at stage `stg` needs (wave-uniform)
@@ -771,36 +817,29 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     };
     if (role == 1) {
         // ================= role P =================
-        InputsAgg in;
-        in.ui = 0; in.u_glob = nullptr; in.n = a.n;
-        in.throttle = 0; in.mixture = 0; in.pld_M = 0;
+        InputsDuoP in;
+        in.pld_l = (lds_cptr)pld_l + t; in.throttle = 0; in.mixture = 0; in.ui = 0;
+        {
+            InputsAgg in0;
+            in0.ui = 0; in0.throttle = 0; in0.mixture = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) in.pld_Mr[k] = 0;
+            for (int k = 0; k < 5; k++) in0.m_pld[k] = 0;
+            if (valid) load_inputs(a, i, in0);
+            in0.sum_payload();
+            in.throttle = in0.throttle; in.mixture = in0.mixture; in.ui = in0.ui;
+            pld_l[t] = in0.pld_M;
 #pragma unroll
-        for (int k = 0; k < 6; k++) in.pld_J[k] = 0;
-        if (valid) { load_inputs(a, i, in); in.u_glob = nullptr; in.sum_payload(); }
-        // the payload's ten mass-property sums go to memory and come back at the top of every evaluation, where the mass properties
-        // are the first thing computed: twenty registers that would otherwise ride through the whole evaluation
-        const int64_t ic = valid ? i : 0;
-        double* pld_g = a.duo_pld + ic;
-        if (valid) {
-            pld_g[0] = in.pld_M;
+            for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) pld_g[(int64_t)(1 + k) * a.n] = in.pld_Mr[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) pld_g[(int64_t)(4 + k) * a.n] = in.pld_J[k];
+            for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
         }
         double acc_r[NP - DUO_NPL];
 #pragma unroll
         for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
-        __threadfence_block();
 #pragma unroll 1
         while (true) {
-            double pc[10];
-#pragma unroll
-            for (int k = 0; k < 10; k++) pc[k] = pld_g[(int64_t)k * a.n];   // (in flight across the barrier)
             __syncthreads();   // the previous evaluation's emits, and D's flag / control words, are visible
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
@@ -820,15 +859,10 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             if (__builtin_amdgcn_ballot_w64(run) != 0) {   // (the same in both waves of a pair)
                 if (run) {
                     StepAux aux;
-                    InputsAgg inl;
-                    inl.ui = in.ui; inl.u_glob = nullptr; inl.n = in.n; inl.throttle = in.throttle; inl.mixture = in.mixture;
-                    inl.pld_M = pc[0];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) inl.pld_Mr[k] = pc[1 + k];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) inl.pld_J[k] = pc[4 + k];
+                    InputsDuoP inl = in;
+                    inl.pld_l = in.pld_l + lds_off;
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
-                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, &dst_l[t], (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
                     const SV xv = {sk.xrd_l + t + lds_off};
                     rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, 0, eng, inl, a.env, T, emit, aux, NoSink{});
                 }
@@ -841,8 +875,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // The lane's bookkeeping state lives in an LDS word between evaluations (D_* bits): kept in registers it is what the allocator
     // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
     enum { D_ALIVE = 1, D_DEAD = 2, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };
-    InputsAgg in;
-    in.ui = 0; in.u_glob = nullptr; in.n = a.n;
+    InputsDuoD in;
+    in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
     {
         int stall = 0, eng = 0;
         bool to_ground = false;
@@ -855,11 +889,13 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             }
             if (to_ground) a.redo[i] = 1;
             stall = a.s[i]; eng = a.s[a.n + i];
-            load_inputs(a, i, in); in.u_glob = nullptr; in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
-            const double ac[12] = {in.cd_in, in.cd_df, in.cy_in, in.cl_in, in.cl_df, in.croll_in, in.cm_in, in.cn_in,
-                                   (double)in.l_df4.i, in.l_df4.w, (double)in.l_df2.i, in.l_df2.w};
+            InputsAgg in0;
+            load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
+            const double ac[DUO_NCONST] = {in0.cd_in, in0.cd_df, in0.cy_in, in0.cl_in, in0.cl_df, in0.croll_in, in0.cm_in, in0.cn_in,
+                                           (double)in0.l_df4.i, in0.l_df4.w, (double)in0.l_df2.i, in0.l_df2.w};
 #pragma unroll
-            for (int k = 0; k < 12; k++) a.duo_pld[(int64_t)(10 + k) * a.n + i] = ac[k];
+            for (int k = 0; k < DUO_NCONST; k++) a.duo_pld[(int64_t)k * a.n + i] = ac[k];
+            in.ui = in0.ui;
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;
@@ -871,13 +907,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false, exit_ = __builtin_amdgcn_ballot_w64(dst_l[t] & D_ALIVE) == 0;
     if ((threadIdx.x & 63) == 0) ctrl_l[pair] = exit_ ? DUO_C_EXIT : 0;
-    const double* aero_g = a.duo_pld + (int64_t)10 * a.n + (valid ? i : 0);
-    __threadfence_block();
+    __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
 #pragma unroll 1
     while (true) {
-        double ac[12];   // the launch's aerodynamic constants, back from memory (see role P's payload sums)
-#pragma unroll
-        for (int k = 0; k < 12; k++) ac[k] = aero_g[(int64_t)k * a.n];
         __syncthreads();
         if (exit_) break;
         const bool cb = stage == 0 && pending_cb && !redoing;
@@ -892,18 +924,16 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         if (__builtin_amdgcn_ballot_w64(run) != 0) {
             if (run) {
                 const int d0 = dst_l[t];
-                InputsAgg inl;
-                inl.ui = 0; inl.u_glob = nullptr; inl.n = a.n;
-                inl.cd_in = ac[0]; inl.cd_df = ac[1]; inl.cy_in = ac[2]; inl.cl_in = ac[3]; inl.cl_df = ac[4]; inl.croll_in = ac[5];
-                inl.cm_in = ac[6]; inl.cn_in = ac[7];
-                inl.l_df4 = {(int)ac[8], ac[9]}; inl.l_df2 = {(int)ac[10], ac[11]};
-                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                InputsDuoD inl = in;
+                inl.aero_g = in.aero_g + lds_off;
+                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, nullptr, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
                 const SV xv = {sk.xrd_l + t + lds_off};
                 bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux, NoSink{});
             }
         } else { __syncthreads(); __syncthreads(); }
         if (cb) __syncthreads();   // role P has read x_{n+1} for the last time: f_step! may modify it
         int d = dst_l[t];
+        if (d & DUO_D_PALT) { d &= ~DUO_D_PALT; if (run) bits |= FB_ST_ALT_RANGE; }
         if (run && (bits & FB_ST_INTERNAL_REDO)) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }   // nothing is committed for this lane
         bool zero_acc = false, advance = true;
         if (redoing) { redoing = false; run = d & D_ALIVE; }   // the lanes that sat out the re-evaluation of k1 join again
@@ -932,8 +962,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 if (aux.crash) bits |= FB_ST_GROUND_CRASH;
                 const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
                 const bool fuel = aux.m_avail > 0;
-                const int ui = a.ui[i];
-                const bool start = ui & FB_UI_ENG_START, stop = ui & FB_UI_ENG_STOP;
+                const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
                 if (eng == 0) { if (start) eng = 1; }
                 else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
                 else if (stop || w < c172::w_stall || !fuel) eng = 0;
