@@ -1,0 +1,287 @@
+// c172_duo_device.hpp — the right-hand side of the airborne Cessna172Sv0 / WA evaluation, cut in two for k_step_duo
+// (c172_kernels.hpp): two waves serve the same 64 aircraft, each evaluating its share, so that two waves fit a SIMD's registers.
+// Same arithmetic, block by block, as rhs() in c172_device_impl.inc (which stays the reference form: every other kernel uses it,
+// and tools/duo_check.py + the parity tests compare the two); only the order of the blocks and who evaluates them differ:
+//
+//   role P  "atmosphere + power plant"                     role D  "airframe"
+//   attitude, n_e                                          attitude, n_e
+//   geoid height (lat / lon, EGM96) -> h_o                 wind-relative velocity, airflow angles, filter rows,
+//   ISA atmosphere -> T, p, log p                          table locations on the alpha / beta axes
+//   put rho, h_o, 1/a  ------------------ barrier A ---->  get rho, h_o
+//   wind-relative velocity, propeller                      kinematics derivatives (9 rows), ground-effect location,
+//   put F_p, tau_p, h_rot                                  aerodynamic coefficients and wrench, landing gear (airborne shortcut),
+//   engine (3 rows)                                        mass properties, gravity at the CoM
+//        ...  ------------------------- barrier B ---->    get F_p, tau_p, h_rot
+//   engine tail, fuel row                                  rigid-body dynamics (6 rows)
+//
+// Only the attitude products (~100 instructions) are evaluated twice. Who may touch which LDS row when:
+//   * both roles read the state rows they need from the other role's rows BEFORE barrier A (D: nothing of P's but the fuel row,
+//     which P rewrites last of all, after B; P: attitude, altitude, angular and linear velocity);
+//   * D rewrites the kinematics rows after A, its angular / linear velocity rows after B; P rewrites the engine rows after A and
+//     the fuel row after B;
+//   * exchange rows 0-5 are the angular / linear velocity rows of the evaluation panel, dead between A and D's own emit at the end.
+#pragma once
+#include "c172_device.hpp"
+
+namespace fbd {
+
+constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
+
+template <int ROLE, class In, class Emit, class XV>
+__device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state, const In& in, const Env& env, const Tables& T, const Emit& emit, StepAux& aux) {
+    using namespace c172;
+    static_assert(ROLE == 1 || ROLE == 2, "role P or role D");
+    int32_t st = 0;
+    constexpr int KX = FB_X_Q_WB;
+    auto gkp = [&](int off) -> gk_cptr { return T.gk + off; };
+    auto atan2m = [&](double y, double x0) -> double { return atan2_step(y, x0, T.rk + LDS_ATAN); };
+    auto atan2p = [&](double y, double x0) -> double { return atan2_step<true>(y, x0, T.rk + LDS_ATAN); };   // x0 >= 0, not both zero
+
+    // ===== kinematics head, both roles (kinematics.jl:181-223; geodesy.jl:62-69, 140-147) =====
+    const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
+    const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
+    const double h_e = x[KX + 8];
+    if (!(h_e >= H_MIN)) st |= FB_ST_ALT_RANGE;
+    const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+    const quat q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
+    const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
+    const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
+    const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+    double s_nw, c_nw;
+    half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
+    const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
+    const quat q_nb = {c_nw * q_wb.w - s_nw * q_wb.z, c_nw * q_wb.x - s_nw * q_wb.y, c_nw * q_wb.y + s_nw * q_wb.x, c_nw * q_wb.z + s_nw * q_wb.w};
+    // wind-relative velocity (atmosphere.jl:269-283)
+    const v3 v_ew_n = {env.wind_n, env.wind_e, env.wind_d};
+    const v3 v_ew_b = qrot_inv(q_nb, v_ew_n);
+    const v3 v_wb_b = v_eb_b - v_ew_b;
+
+    if constexpr (ROLE == 1) {
+        // ================================= role P =================================
+        lds_cptr PT = T.lds + LDS_PISTON;
+        lds_cptr RPT = T.rk + LDS_PISTON;
+        const double w_eng = x[FB_X_ENG_OMEGA];
+        const double x_frc = x[FB_X_ENG_FRC], x_idle = x[FB_X_ENG_IDLE], x_fuel = x[FB_X_FUEL];
+        double lat, lon;
+        const double N_geoid = geoid_height<true>(T, n_e, lat, lon);
+        const double h_o = h_e - N_geoid;
+        if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        // ----- air data (atmosphere.jl:220-242) -----
+        double T_air, p_air, lnp_air;
+        const double h_gp = h_o * wgs::a / (wgs::a + h_o);   // geopotential altitude
+        isa_data<true>(h_gp, env.T_sl, env.p_sl, T_air, p_air, lnp_air, st);
+        const double rs_T = rsqrt(T_air), i_T = rs_T * rs_T;
+        const double rho = (p_air * (1 / isa::R)) * i_T;
+        constexpr double sqrt_gR = 20.046795704052055;   // sqrt(1.4 * 287.05287)
+        const double i_a_snd = (1 / sqrt_gR) * rs_T;
+        emit.xput(XD_RHO, rho); emit.xput(XD_HO, h_o);
+        if (st != 0) emit.xstatus(st);
+        emit.xsync();   // ----- barrier A -----
+
+        // ----- propeller (propellers.jl:405-452) -----
+        const double w_prop = w_eng;  // gear ratio 1
+        const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
+        const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
+        const double v_J = norm(v_p);
+        const double J_adv = 2 * PI * v_J / (fmax(fabs(w_prop), 1.0) * prop_d);
+        const double Mt = fabs(w_prop) * (prop_d / 2) * i_a_snd;
+        const loc lj = range_locate(0.0, 1.5, PR_NJ, J_adv, true);
+        const loc lm = range_locate(0.0, 1.5, PR_NM, Mt, true);
+        const double w00 = (1 - lj.w) * (1 - lm.w), w01 = (1 - lj.w) * lm.w, w10 = lj.w * (1 - lm.w), w11 = lj.w * lm.w;
+        // (no LDS to spare for this 14 KB table: its four corner records come from the blob in global memory — hot in the vector L1 — as
+        // one batch of loads)
+        gk_cptr g00 = T.gk + LDS_PROP + (lj.i + PR_NJ * lm.i) * PR_NC;
+        auto coef = [&](int cidx) {
+            return (w00 * g00[cidx] + w01 * g00[PR_NJ * PR_NC + cidx]) + (w10 * g00[PR_NC + cidx] + w11 * g00[PR_NJ * PR_NC + PR_NC + cidx]);
+        };
+        const double C_Fx = coef(0), C_Mx = coef(1), C_Fz_a = coef(2), C_Mz_a = coef(3);
+        double a_p = 0, b_p = 0;
+        if (!(v_J < 0.1)) {
+            a_p = atan2m(v_p.z, v_p.x);
+            b_p = atan2p(v_p.y, sqrt(v_p.x * v_p.x + v_p.z * v_p.z));
+        }
+        const double fr = w_prop / (2 * PI), fr2 = fr * fr;
+        constexpr double d4 = prop_d * prop_d * prop_d * prop_d, d5 = d4 * prop_d;
+        const double kF = rho * fr2 * d4, kM = rho * fr2 * d5;
+        const v3 F_p = {kF * C_Fx, kF * (C_Fz_a * b_p), kF * (C_Fz_a * a_p)};
+        const v3 tau_p = {kM * C_Mx, kM * (C_Mz_a * b_p), kM * (C_Mz_a * a_p)};  // CW: sense = +1
+        const v3 tau_pb = tau_p + cross(r_p, F_p);
+        emit.xput(XD_FP, F_p.x); emit.xput(XD_FP + 1, F_p.y); emit.xput(XD_FP + 2, F_p.z);
+        emit.xput(XD_TAUP, tau_pb.x); emit.xput(XD_TAUP + 1, tau_pb.y); emit.xput(XD_TAUP + 2, tau_pb.z);
+        emit.xput(XD_HROT, prop_Jxx * w_prop);
+
+        // ----- engine (piston.jl:314-426) -----
+        double out_frc, out_idle;
+        static_assert(FB_X_ENG_FRC == FB_X_ENG_IDLE + 1, "engine regulator rows are adjacent");
+        const double kfrc = pi_ode(5.0, 200.0, 0.0, -1.0, 1.0, -w_eng, x_frc, out_frc);
+        const double ke2[2] = {pi_ode(4.0, 2.0, 0.0, -0.5, 0.5, 1 - w_eng / w_idle, x_idle, out_idle), kfrc};
+        emit_rows<2>(emit, FB_X_ENG_IDLE, ke2);
+        const double mu_ratio_idle = 0.5 + out_idle;
+        const double n_eng = w_eng / w_rated;
+        const double rt_arg = (0.5 * 6.5e-3 * isa::R / isa::g_std) * (env.ln_p_sl + lnp_air);
+        const bool tropo = h_gp < 11000.0;
+        double rt_theta = env.k_rt * (T_air * rs_T);   // (T_ISA/T_std)^1/2, see rhs()
+        if (__builtin_amdgcn_ballot_w64(!tropo) != 0) { const double e = exp_step(rt_arg); rt_theta = tropo ? rt_theta : e; }
+        const double delta = (p_air / isa::p_std) / rt_theta;
+        const double throttle = in.get_throttle(), mixture = in.get_mixture();
+        const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
+        const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
+        const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
+        emit.xsync();   // ----- barrier B (role D has finished its aerodynamics by about now) -----
+        const double k_f = rsqrt(rho * (1 / isa::rho_std));
+        const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
+        const double f_run = mix_auto ? f_lean + mixture * (f_rich - f_lean) : k_f * (f_rich * (0.5 * (mixture + 1)));
+        const loc l_n13 = grid_locate<13, true, AUX_N13>(PT + PT_PISTD_N_K, RPT + PT_PISTD_N_K, n_eng, true, true, gkp(LDS_PISTON + PT_PISTD_N_K), T.gk);
+        const loc l_n5w = grid_locate<5, true>(PT + PT_PIWOT_N_K, RPT + PT_PIWOT_N_K, n_eng, true, true, gkp(LDS_PISTON + PT_PIWOT_N_K));
+        const loc l_n5s = grid_locate<5, true>(PT + PT_SFC_N_K, RPT + PT_SFC_N_K, n_eng, false, false, gkp(LDS_PISTON + PT_SFC_N_K));
+        const loc l_f = grid_locate<11, true, AUX_F11>(PT + PT_F_K, RPT + PT_F_K, f_run, true, true, gkp(LDS_PISTON + PT_F_K), T.gk);
+        const double pi_ratio = lerp1(PT + PT_PI_RATIO_V, l_f), sfc_ratio = lerp1(PT + PT_SFC_RATIO_V, l_f);
+        const double d_wot = lerp2(PT + PT_DELTA_WOT_V, 2, l_n2, range_locate(0.401, 0.936, 9, mu, false));
+        const double pi_std = lerp2(PT + PT_PISTD_V, 13, l_n13, grid_locate<3, true>(PT + PT_PISTD_MU_K, RPT + PT_PISTD_MU_K, mu, true, true, gkp(LDS_PISTON + PT_PISTD_MU_K)));
+        const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, l_n5w, grid_locate<3, true>(PT + PT_PIWOT_D_K, RPT + PT_PIWOT_D_K, d_wot, true, false, gkp(LDS_PISTON + PT_PIWOT_D_K)));
+        double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
+        pi_isa = fmax(pi_isa, 0.0);
+        const double pi_pow = pi_isa * (rt_theta * (isa_sqrt_T_std * rs_T));   // pi_isa (T_ISA / T)^1/2
+        const double pi_act = pi_pow * pi_ratio;
+        const double P_run = P_rated * pi_act;
+        const double tau_run = (w_eng > 0) ? P_run / w_eng : 0.0;
+        const double SFC_run = lerp2(PT + PT_SFC_POW_V, 5, l_n5s, grid_locate<8, true>(PT + PT_SFC_PI_K, RPT + PT_SFC_PI_K, pi_act, false, false, gkp(LDS_PISTON + PT_SFC_PI_K))) * sfc_ratio;
+        const bool eng_off = eng_state == 0, eng_starting = eng_state == 1, eng_running = !(eng_off || eng_starting);
+        const double tau_shaft = eng_off ? out_frc * (0.01 * P_rated / w_rated) : (eng_starting ? tau_start : tau_run);
+        const double mdot = eng_running ? SFC_run * P_run : 0.0;
+        const double tau_load = tau_p.x;  // gear_ratio * τ_prop
+        emit(FB_X_ENG_OMEGA, (tau_shaft + tau_load) / (J_eng + prop_Jxx));
+        // ----- fuel (c172.jl:607-616) -----
+        (void)x_fuel;
+        emit(FB_X_FUEL, -mdot / (m_full - m_res));
+        return st;
+    } else {
+        // ================================= role D =================================
+        lds_cptr A = T.lds + LDS_AERO;
+        lds_cptr RA = T.rk + LDS_AERO;
+        const quat q_eb = qmul(q_ew, q_wb);
+        const double x_fuel = x[FB_X_FUEL];   // (before barrier A: role P rewrites this row at the very end of its evaluation)
+        const double TAS = norm(v_wb_b);
+        // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
+        AeroC ac;
+        in.fetch_aero(ac);
+        double alpha = 0, beta = 0, cos_al = 1, sin_al = 0;
+        if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
+            const double r2 = v_wb_b.x * v_wb_b.x + v_wb_b.z * v_wb_b.z;
+            const bool r_ok = r2 > 0;
+            const double ir = rsqrt(r_ok ? r2 : 1.0), r = r2 * ir;
+            alpha = atan2m(v_wb_b.z, v_wb_b.x);
+            beta = atan2p(v_wb_b.y, r);   // (TAS > 0.1: r and v_y are not both zero)
+            if (r_ok) { cos_al = v_wb_b.x * ir; sin_al = v_wb_b.z * ir; }   // cos, sin of atan2(z, x) (atan2(0, 0) = 0)
+        }
+        const double V = fmax(TAS, V_min);
+        const double afd = 1 / tau_filt * (alpha - x[FB_X_ALPHA_FILT]);
+        const double bfd = 1 / tau_filt * (beta - x[FB_X_BETA_FILT]);
+        const double kf2[2] = {afd, bfd};
+        emit_rows<2>(emit, FB_X_ALPHA_FILT, kf2);
+        const double i2V = 1 / (2 * V);
+        const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
+        const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
+        const loc l_al26 = grid_locate<26, true, AUX_AL26>(A + AT_CD_ALPHA_K, RA + AT_CD_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CD_ALPHA_K), T.gk);
+        const loc l_al17 = grid_locate<17, true, AUX_AL17>(A + AT_CL_ALPHA_K, RA + AT_CL_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CL_ALPHA_K), T.gk);
+        const loc l_al2 = grid_locate<2, true>(A + AT_ALPHA2_K, RA + AT_ALPHA2_K, al, true, true, gkp(LDS_AERO + AT_ALPHA2_K));
+        const loc l_be3 = grid_locate<3, true>(A + AT_CY_BETA_K, RA + AT_CY_BETA_K, be, true, true, gkp(LDS_AERO + AT_CY_BETA_K));
+        const loc l_bu = grid_locate<3, true>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true, gkp(LDS_AERO + AT_UNIT3_K));
+        const loc l_stall = {0, stall ? 1.0 : 0.0};
+        const loc l_df4 = ac.l_df4, l_df2 = ac.l_df2;
+        // the lookups on those axes alone
+        const double cd_al = lerp2(A + AT_CD_ALPHA_DF_V, 26, l_al26, l_df4) + ac.cd_df, cd_be = lerp1(A + AT_CD_BETA_V, l_bu);
+        const double cy_be = lerp2(A + AT_CY_BETA_DF_V, 3, l_be3, l_df2);
+        const double cy_p = lerp2(A + AT_CY_P_V, 2, l_al2, l_df2), cy_r = lerp2(A + AT_CY_R_V, 2, l_al2, l_df2);
+        const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
+        const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
+        // ----- radii of curvature (geodesy.jl:125-129), fuel mass, mass properties, gravity at the CoM: while role P works on the atmosphere -----
+        const double i_fden = rsqrt(1 - wgs::e2 * n_e.z * n_e.z);   // 1 / sqrt(1 - e^2 sin^2 lat)
+        const double R_E = wgs::a * i_fden;
+        const double R_N = (wgs::a * (1 - wgs::e2)) * (i_fden * i_fden * i_fden);
+        const double RE_h = R_E + h_e, RN_h = R_N + h_e, i_REN = 1 / (RE_h * RN_h);   // both reciprocals from one division
+        const double i_RE = RN_h * i_REN, i_RN = RE_h * i_REN;
+        const double m_fuel_total = m_res + x_fuel * (m_full - m_res);
+        aux.m_avail = m_fuel_total - m_res;
+        double M, J[6], Jc[6], iM;
+        v3 r_bc;
+        mass_props(m_fuel_total, in, M, J, iM, r_bc, Jc);
+        const double Jxx = Jc[0], Jyy = Jc[1], Jzz = Jc[2], Jxy = Jc[3], Jxz = Jc[4], Jyz = Jc[5];
+        v3 d_e;
+        const v3 g_c_c = gravity_com(q_eb, r_bc, n_e, h_e, R_N, R_E, i_RN, i_RE, st, d_e);
+        const v3 w_ie_b = earth_rate_b(q_eb);
+        emit.xsync();   // ----- barrier A -----
+        const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
+        if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        const double q_dyn = 0.5 * rho * (TAS * TAS);
+
+        // ----- kinematics derivatives (kinematics.jl:181-242; geodesy.jl:125-129) -----
+        const v3 v_eb_n = qrot(q_nb, v_eb_b);
+        const v3 w_ew_n = {v_eb_n.y * i_RE, -v_eb_n.x * i_RN, 0.0};
+        const double cpsi = q_nw.w * q_nw.w - q_nw.z * q_nw.z, spsi = 2 * (q_nw.w * q_nw.z);
+        const v3 w_ew_w = {cpsi * w_ew_n.x + spsi * w_ew_n.y, cpsi * w_ew_n.y - spsi * w_ew_n.x, 0.0};
+        const v3 w_ew_b = qrot_inv(q_wb, w_ew_w);
+        const v3 w_wb_b = w_eb_b - w_ew_b;
+        {
+            const quat a = {-(q_wb.x * w_wb_b.x + q_wb.y * w_wb_b.y + q_wb.z * w_wb_b.z),
+                            q_wb.w * w_wb_b.x + (q_wb.y * w_wb_b.z - q_wb.z * w_wb_b.y),
+                            q_wb.w * w_wb_b.y + (q_wb.z * w_wb_b.x - q_wb.x * w_wb_b.z),
+                            q_wb.w * w_wb_b.z + (q_wb.x * w_wb_b.y - q_wb.y * w_wb_b.x)};
+            const quat b2 = {-(q_ew.x * w_ew_w.x + q_ew.y * w_ew_w.y), q_ew.w * w_ew_w.x - q_ew.z * w_ew_w.y,
+                             q_ew.w * w_ew_w.y + q_ew.z * w_ew_w.x, q_ew.x * w_ew_w.y - q_ew.y * w_ew_w.x};
+            const double kq1[4] = {0.5 * a.w, 0.5 * a.x, 0.5 * a.y, 0.5 * a.z};
+            const double kq2[5] = {0.5 * b2.w, 0.5 * b2.x, 0.5 * b2.y, 0.5 * b2.z, -v_eb_n.z};
+            emit_rows<4>(emit, KX, kq1);
+            emit_rows<5>(emit, KX + 4, kq2);
+        }
+
+        // ----- aerodynamics, the rest (c172.jl:341-373, 226-245) -----
+        const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
+        const double dh_nd = (h_o - env.h_trn) / b;
+        const loc l_ge = grid_locate<13, true, AUX_GE>(A + AT_GE_K, RA + AT_GE_K, dh_nd, true, true, gkp(LDS_AERO + AT_GE_K), T.gk);
+        auto S_ = [&](int k) -> double { return FB_SCALAR_DERIVS ? T.gk[LDS_AERO + AT_SCALARS + k] : A[AT_SCALARS + k]; };
+        const double C_D = ac.cd_in + lerp1(A + AT_CD_GE_V, l_ge) * cd_al + cd_be;
+        const double C_Y = ac.cy_in + cy_be + cy_p * p_nd + cy_r * r_nd;
+        const double C_L = lerp1(A + AT_CL_GE_V, l_ge) * cl_al + ac.cl_in + S_(AS_CL_Q) * q_nd + S_(AS_CL_ALPHA_DOT) * ad_nd;
+        const double C_l = ac.croll_in + S_(AS_Cl_BETA) * be + S_(AS_Cl_P) * p_nd + cl_r * r_nd;
+        const double C_m = ac.cm_in + S_(AS_CM_ALPHA) * al + S_(AS_CM_Q) * q_nd + S_(AS_CM_ALPHA_DOT) * ad_nd;
+        const double C_n = ac.cn_in + S_(AS_CN_BETA) * be + S_(AS_CN_P) * p_nd + S_(AS_CN_R) * r_nd;
+        // stability -> body axes: rotation by Ry(-α) with the UNCLAMPED α (c172.jl:356-359; atmosphere.jl:353-356)
+        const double qS = q_dyn * S;
+        const v3 F_s = {qS * -C_D, qS * C_Y, qS * -C_L};
+        const v3 F_a = {cos_al * F_s.x - sin_al * F_s.z, F_s.y, sin_al * F_s.x + cos_al * F_s.z};
+        const v3 tau_a = {qS * (C_l * b), qS * (C_m * c), qS * (C_n * b)};
+        aux.alpha = alpha;
+        // ----- landing gear: the high-clearance shortcut of rhs() (no wheel can touch within 10 m of clearance) -----
+        aux.wow = 0;
+        aux.crash = 0;
+        if (!(h_o - env.h_trn > 10.0)) st |= FB_ST_INTERNAL_REDO;
+        emit.xsync();   // ----- barrier B -----
+        const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
+        const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
+        const v3 h_rot = {emit.xget(XD_HROT), 0.0, 0.0};
+        // ----- rigid-body dynamics at the CoM (dynamics.jl:443-525), as in rhs() -----
+        const v3 F_b = F_a + F_p;
+        const v3 tau_b = tau_a + tau_pb;
+        auto Jmul = [&](v3 v) { return v3{Jxx * v.x + Jxy * v.y + Jxz * v.z, Jxy * v.x + Jyy * v.y + Jyz * v.z, Jxz * v.x + Jyz * v.y + Jzz * v.z}; };
+        const v3 F_c = F_b;
+        const v3 tau_c = tau_b - cross(r_bc, F_b);
+        const v3 v_ec_c = v_eb_b + cross(w_eb_b, r_bc);
+        const v3 w_ic_c = w_ie_b + w_eb_b;
+        const v3 hc = Jmul(w_ic_c) + h_rot;
+        const v3 rhs_w = tau_c - Jmul(cross(w_ie_b, w_eb_b)) - cross(w_ic_c, hc);
+        // symmetric 3x3 solve by cofactors
+        const double c11 = Jyy * Jzz - Jyz * Jyz, c12 = Jyz * Jxz - Jxy * Jzz, c13 = Jxy * Jyz - Jyy * Jxz;
+        const double c22 = Jxx * Jzz - Jxz * Jxz, c23 = Jxy * Jxz - Jxx * Jyz, c33 = Jxx * Jyy - Jxy * Jxy;
+        const double idet = 1 / (Jxx * c11 + Jxy * c12 + Jxz * c13);
+        const v3 wd = {(c11 * rhs_w.x + c12 * rhs_w.y + c13 * rhs_w.z) * idet, (c12 * rhs_w.x + c22 * rhs_w.y + c23 * rhs_w.z) * idet,
+                       (c13 * rhs_w.x + c23 * rhs_w.y + c33 * rhs_w.z) * idet};
+        const v3 vd_c = iM * F_c + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
+        const v3 vd_b = vd_c - cross(wd, r_bc);
+        const double kd6[6] = {wd.x, wd.y, wd.z, vd_b.x, vd_b.y, vd_b.z};
+        emit_rows<6>(emit, FB_X_OMEGA_EB_B, kd6);
+        return st;
+    }
+}
+
+}  // namespace fbd

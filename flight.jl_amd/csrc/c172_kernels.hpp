@@ -16,6 +16,7 @@
 #pragma once
 #include "c172_device.hpp"
 #include "c172x_ctl_device.hpp"
+#include "c172_duo_device.hpp"
 
 namespace fbd {
 
@@ -664,55 +665,46 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
 }
 
 // ---- the wave-specialised airborne stepper (Cessna172Sv0) --------------------------------------------------------------------------
-// k_step_air is bound by what ONE wave per SIMD can issue: its 151 KB of LDS panels and ~450 registers leave room for no second
+// k_step_air is bound by what ONE wave per SIMD can issue: its 151 KB of LDS panels and ~400 registers leave room for no second
 // wave, every instruction costs the lone wave ~4.3 cycles and nothing hides an LDS round trip. k_step_duo serves the
-// same 256 aircraft per workgroup with EIGHT waves: waves 0-3 ("P") evaluate kinematics rows, propeller, engine, fuel and mass
-// properties, waves 4-7 ("D") aerodynamics, landing gear (the airborne shortcut) and the rigid-body dynamics — see the roles of
-// rhs(). Wave w and wave w + 4 sit on the same SIMD and work on the same 64 aircraft, so the SIMD always has a second instruction
-// stream to issue from; each role needs at most 256 registers. Per evaluation the pair meets at two workgroup barriers: at the
-// top (the previous evaluation's emits are visible) and at the exchange point in the middle (P hands the propeller wrench and the
-// mass properties over through a 17-row LDS panel; before it nobody overwrites a row the other role still reads, see rhs()).
-// A third barrier precedes f_step!, which modifies x_{n+1} in place. LDS: tables 22 KB, x_n and the evaluation state 2 x 42 KB,
-// D's eight stage sums 16 KB (P keeps its thirteen in registers), exchange 34 KB, flags 1 KB = 157 KB.
+// same 256 aircraft per workgroup with EIGHT waves: waves 0-3 ("P") evaluate geoid, atmosphere, propeller and engine, waves 4-7
+// ("D") the airframe: aerodynamics, kinematics, mass, gravity, dynamics — rhs_duo() in c172_duo_device.hpp. Wave w and wave w + 4
+// work on the same 64 aircraft, so a SIMD always has a second instruction stream to issue from; each role fits 256 registers.
+// Per evaluation the pair meets at three workgroup barriers: at the top (the previous evaluation's emits are visible), A (P hands
+// density and orthometric altitude over) and B (P hands the propeller wrench over); a fourth precedes f_step!, which modifies
+// x_{n+1} in place. LDS (full to the last byte): aero and piston tables 8 KB, x_n and the evaluation state 2 x 42 KB, D's seventeen
+// stage sums 34 KB and three of P's four 6 KB, the payload's mass-property sums 20 KB, exchange 6 KB, flags 2 KB.
 // The step's bookkeeping (stage machine, f_step!, status, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
 // P follows through a per-lane flag word and a per-pair control word in LDS.
 constexpr int DUO_B = 256;
-constexpr int DUO_D_PALT = 128;   // bit of role D's bookkeeping word: role P found the CoM outside the altitude range
-constexpr int DUO_NPL = 1;   // how many of role P's thirteen stage sums live in LDS (what is left of the 160 KB)
-// Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation, and at 256 registers per
-// wave that is the difference between no spills and a dozen exposed scratch round trips per evaluation. Role P reads the payload's
-// ten mass-property sums from an LDS panel at the point of use; role D (no LDS left) fetches its aerodynamic sums from global
-// memory at the start of the aerodynamics block — one batch of loads whose latency the table lookups cover.
+constexpr int DUO_D_PST_SHIFT = 8;   // bits 8-9 of role D's bookkeeping word: status bits found by role P (altitude / ISA range)
+constexpr int DUO_NP = 4, DUO_ND = 17;   // state rows per role
+constexpr int DUO_NPL = 3;   // how many of role P's four stage sums live in LDS (what is left of the 160 KB)
+// Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation. Role D reads the payload's
+// ten mass-property sums from an LDS panel at the point of use and fetches its aerodynamic sums from global memory at the start of
+// the evaluation (one batch of loads, consumed after the table locations).
 struct InputsDuoP {
-    static constexpr bool pld_precomputed = true, aero_precomputed = true;
-    lds_cptr pld_l;   // &panel[lane], rows: M, Mr[3], J[6]
     double throttle, mixture;
     int ui;
     __device__ __forceinline__ double get_throttle() const { return throttle; }
     __device__ __forceinline__ double get_mixture() const { return mixture; }
-    __device__ __forceinline__ double get_pld_M() const { return pld_l[0]; }
-    __device__ __forceinline__ double get_pld_Mr(int k) const { return pld_l[(1 + k) * DUO_B]; }
-    __device__ __forceinline__ double get_pld_J(int k) const { return pld_l[(4 + k) * DUO_B]; }
-    __device__ __forceinline__ void fetch_aero(AeroC&) const {}
 };
 struct InputsDuoD {
     static constexpr bool pld_precomputed = true, aero_precomputed = true;
+    lds_cptr pld_l;         // &panel[lane], rows: M, Mr[3], J[6]
     const double* aero_g;   // &duo_pld[0 * n + i]
     int64_t n;
     int ui;
+    __device__ __forceinline__ double get_pld_M() const { return pld_l[0]; }
+    __device__ __forceinline__ double get_pld_Mr(int k) const { return pld_l[(1 + k) * DUO_B]; }
+    __device__ __forceinline__ double get_pld_J(int k) const { return pld_l[(4 + k) * DUO_B]; }
     __device__ __forceinline__ void fetch_aero(AeroC& c) const {
         double v[DUO_NCONST];
 #pragma unroll
         for (int k = 0; k < DUO_NCONST; k++) v[k] = aero_g[(int64_t)k * n];
-        __builtin_amdgcn_sched_barrier(0);   // (issued here, not where the scheduler would like them: right before their use)
         c.cd_in = v[0]; c.cd_df = v[1]; c.cy_in = v[2]; c.cl_in = v[3]; c.cl_df = v[4]; c.croll_in = v[5]; c.cm_in = v[6]; c.cn_in = v[7];
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
-    __device__ __forceinline__ double get_throttle() const { return 0; }
-    __device__ __forceinline__ double get_mixture() const { return 0; }
-    __device__ __forceinline__ double get_pld_M() const { return 0; }
-    __device__ __forceinline__ double get_pld_Mr(int) const { return 0; }
-    __device__ __forceinline__ double get_pld_J(int) const { return 0; }
 };
 template <int ROLE>
 struct DuoEmit {
@@ -721,32 +713,31 @@ struct DuoEmit {
     using SV = StateLds<DUO_B, false>;
     lds_cptr xs_l;     // x_n panel
     lds_ptr xwr_l;     // the panel this stage writes
-    lds_ptr accd_l;    // role D: its eight stage sums [8][DUO_B]; role P: the first DUO_NPL of its thirteen [DUO_NPL][DUO_B]
+    lds_ptr acc_l;     // this role's stage sums in LDS: D's seventeen [17][DUO_B], the first DUO_NPL of P's four
     double* acc_r;     // role P: the rest of its stage sums (registers)
-    lds_ptr xch_l;     // exchange panel [XC_ROWS - 6][DUO_B] (rows 6.. of the exchange)
-    int* dst_p;        // role D's bookkeeping word of this lane (role P raises DUO_D_PALT in it)
-    lds_ptr xov_l;     // rows 0-5 of the exchange: the angular / linear velocity rows of the evaluation panel, which nobody reads
-                       // between the head barrier and D's own emit of those rows at the end of the evaluation
+    lds_ptr xch_l;     // exchange rows 6.. [XD_ROWS - 6][DUO_B]
+    int* dst_p;        // role D's bookkeeping word of this lane (role P leaves the status bits it finds there)
+    lds_ptr xov_l;     // exchange rows 0-5: the angular / linear velocity rows of the evaluation panel (see c172_duo_device.hpp)
     double eb, ee, em;
     bool last;
     int t;
-    // panel rows: 0-1 filters (D), 2 fuel, 3-5 engine, 6-14 q_wb q_ew h_e (P), 15-20 angular and linear velocity (D)
+    // panel rows: 0-1 filters (D), 2 fuel, 3-5 engine (P), 6-14 q_wb q_ew h_e (D), 15-20 angular and linear velocity (D)
     __device__ __forceinline__ static constexpr bool owned(int j) {
         if (SV::skip(j)) return false;
         const int r = SV::row(j);
-        return ROLE == 1 ? (r >= 2 && r <= 14) : (r < 2 || r >= 15);
+        return ROLE == 1 ? (r >= 2 && r <= 5) : (r < 2 || r >= 6);
     }
-    __device__ __forceinline__ static constexpr int slot(int r) { return ROLE == 1 ? r - 2 : (r < 2 ? r : r - 13); }
+    __device__ __forceinline__ static constexpr int slot(int r) { return ROLE == 1 ? r - 2 : (r < 2 ? r : r - 4); }
     __device__ __forceinline__ double aget(int r) const {
         if (ROLE == 1 && slot(r) >= DUO_NPL) return acc_r[slot(r) - DUO_NPL];
-        return accd_l[slot(r) * DUO_B + t];
+        return acc_l[slot(r) * DUO_B + t];
     }
     __device__ __forceinline__ void aset(int r, double v) const {
         if (ROLE == 1 && slot(r) >= DUO_NPL) acc_r[slot(r) - DUO_NPL] = v;
-        else accd_l[slot(r) * DUO_B + t] = v;
+        else acc_l[slot(r) * DUO_B + t] = v;
     }
     __device__ __forceinline__ void operator()(int j, double kj) const {
-        if (!owned(j)) return;
+        static_assert(ROLE == 1 || ROLE == 2, "");
         const int r = SV::row(j), idx = r * DUO_B + t;
         const double xs = xs_l[idx];
         const double A = __builtin_fma(eb, kj, aget(r));
@@ -754,8 +745,7 @@ struct DuoEmit {
         xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
     }
     template <int NE>
-    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {   // (no batch straddles the roles)
-        if (!owned(j0)) return;
+    __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {
         double xs[NE], A[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) { const int r = SV::row(j0 + e); xs[e] = xs_l[r * DUO_B + t]; A[e] = aget(r); }
@@ -771,23 +761,24 @@ struct DuoEmit {
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
     __device__ __forceinline__ void xsync() const { __syncthreads(); }
-    __device__ __forceinline__ void xstatus(int32_t) const { *dst_p |= DUO_D_PALT; }   // (the one status bit role P can find: altitude range at the CoM)
+    __device__ __forceinline__ void xstatus(int32_t st) const { *dst_p |= (st & 3) << DUO_D_PST_SHIFT; }   // (FB_ST_ALT_RANGE | FB_ST_ISA_RANGE)
 };
 enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
 enum { DUO_C_EXIT = 4, DUO_C_CB = 8 };                              // per-pair control word: stage | EXIT | CB
 template <int KIN>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
-    constexpr int B = DUO_B, NR = FB_NX - 6, NP = 13, ND = 8;
+    constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
     using SV = StateLds<B, false>;
     static_assert(KIN == FB_KIN_WA, "the wave-specialised stepper is built for the WA mechanisation");
-    __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs())
+    static_assert(FB_ST_ALT_RANGE == 1 && FB_ST_ISA_RANGE == 2, "DuoEmit::xstatus");
+    __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs_duo())
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
     __shared__ double xc_l[NR * B];    // the state being evaluated, updated in place by the emits
     __shared__ double accd_l[ND * B];  // role D's stage sums
     __shared__ double accp_l[DUO_NPL * B];   // role P's, as far as the LDS goes
-    __shared__ double pld_l[10 * B];   // role P: the payload's mass-property sums
-    __shared__ double xch_l[(XC_ROWS - 6) * B];
+    __shared__ double pld_l[10 * B];   // role D: the payload's mass-property sums
+    __shared__ double xch_l[(XD_ROWS - 6) * B];
     __shared__ int flags_l[B];
     __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
     static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
@@ -818,20 +809,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     if (role == 1) {
         // ================= role P =================
         InputsDuoP in;
-        in.pld_l = (lds_cptr)pld_l + t; in.throttle = 0; in.mixture = 0; in.ui = 0;
-        {
-            InputsAgg in0;
-            in0.ui = 0; in0.throttle = 0; in0.mixture = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) in0.m_pld[k] = 0;
-            if (valid) load_inputs(a, i, in0);
-            in0.sum_payload();
+        in.throttle = 0; in.mixture = 0; in.ui = 0;
+        if (valid) {
+            Inputs in0;
+            load_inputs(a, i, in0);
             in.throttle = in0.throttle; in.mixture = in0.mixture; in.ui = in0.ui;
-            pld_l[t] = in0.pld_M;
-#pragma unroll
-            for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
         }
         double acc_r[NP - DUO_NPL];
 #pragma unroll
@@ -860,13 +842,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 if (run) {
                     StepAux aux;
                     InputsDuoP inl = in;
-                    inl.pld_l = in.pld_l + lds_off;
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
                     const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, &dst_l[t], (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
                     const SV xv = {sk.xrd_l + t + lds_off};
-                    rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, 0, eng, inl, a.env, T, emit, aux, NoSink{});
+                    rhs_duo<1>(xv, 0, eng, inl, a.env, T, emit, aux);
                 }
-            } else { __syncthreads(); __syncthreads(); }   // (the two barriers of an evaluation nobody runs)
+            } else { __syncthreads(); __syncthreads(); }   // (barriers A and B of an evaluation nobody runs)
             if (c & DUO_C_CB) __syncthreads();
         }
         return;
@@ -876,7 +857,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
     enum { D_ALIVE = 1, D_DEAD = 2, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };
     InputsDuoD in;
-    in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
+    in.pld_l = (lds_cptr)pld_l + t; in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
     {
         int stall = 0, eng = 0;
         bool to_ground = false;
@@ -890,7 +871,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             if (to_ground) a.redo[i] = 1;
             stall = a.s[i]; eng = a.s[a.n + i];
             InputsAgg in0;
-            load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
+            load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO); in0.sum_payload();
+            pld_l[t] = in0.pld_M;
+#pragma unroll
+            for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
             const double ac[DUO_NCONST] = {in0.cd_in, in0.cd_df, in0.cy_in, in0.cl_in, in0.cl_df, in0.croll_in, in0.cm_in, in0.cn_in,
                                            (double)in0.l_df4.i, in0.l_df4.w, (double)in0.l_df2.i, in0.l_df2.w};
 #pragma unroll
@@ -925,15 +911,15 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             if (run) {
                 const int d0 = dst_l[t];
                 InputsDuoD inl = in;
-                inl.aero_g = in.aero_g + lds_off;
+                inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
                 const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, nullptr, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
                 const SV xv = {sk.xrd_l + t + lds_off};
-                bits = rhs<KIN, false, FB_AIR_SCALAR_KNOTS>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux, NoSink{});
+                bits = rhs_duo<2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
             }
         } else { __syncthreads(); __syncthreads(); }
         if (cb) __syncthreads();   // role P has read x_{n+1} for the last time: f_step! may modify it
         int d = dst_l[t];
-        if (d & DUO_D_PALT) { d &= ~DUO_D_PALT; if (run) bits |= FB_ST_ALT_RANGE; }
+        if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
         if (run && (bits & FB_ST_INTERNAL_REDO)) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }   // nothing is committed for this lane
         bool zero_acc = false, advance = true;
         if (redoing) { redoing = false; run = d & D_ALIVE; }   // the lanes that sat out the re-evaluation of k1 join again

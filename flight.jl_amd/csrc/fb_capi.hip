@@ -140,9 +140,9 @@ static row_map_t row_map_of(fb_handle h) {
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
     } while (0)
-// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): 1 selects the wave-specialised airborne stepper
-// k_step_duo for Cessna172Sv0 / WA / fp64, 0 the one-wave-per-SIMD k_step_air
-static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : false; }
+// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): Cessna172Sv0 / WA / fp64 is stepped by the
+// wave-specialised k_step_duo (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air
+static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
 #define FB_LAUNCH_STEP(GRID, A, K)                                                                                                    \
     do {                                                                                                                              \

@@ -7,13 +7,13 @@ summ = os.path.join(out, "summary"); os.makedirs(summ, exist_ok=True)
 for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(summ, f"{tag}_kernel_stats.csv"))
 # the airborne pass of the stepping kernel (the ground-capable pass that follows it finds no lane to redo in this workload)
-NAMES = {"k_step": "k_step_air<0, false, false>", "k_f_ode": "k_f_ode<false, 0>"}
+NAMES = {"k_step": ("k_step_duo<0>", "k_step_air<0, false, false>"), "k_f_ode": ("k_f_ode<false, 0>",)}   # (whichever airborne stepper ran)
 ctr = {"k_step": collections.defaultdict(list), "k_f_ode": collections.defaultdict(list)}
 dur = {"k_step": [], "k_f_ode": []}
 for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         for k in ctr:
-            if NAMES[k] in r["Kernel_Name"]:
+            if any(nm in r["Kernel_Name"] for nm in NAMES[k]):
                 ctr[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 mean = lambda v: sum(v) / len(v) if v else None
