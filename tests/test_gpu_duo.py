@@ -45,6 +45,9 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
     u0[fb.K["FB_U_M_PILOT"]] = rng.uniform(50, 100, n)             # per-aircraft payload: the mass-property sums differ lane by lane
     st0 = np.zeros(n, np.int32)
     st0[rng.random(n) < 0.05] = fb.K["FB_ST_NAN"]                  # terminated before the launch: must be left alone
+    if n >= 512:
+        st0[128:256] = fb.K["FB_ST_NAN"]                           # two whole wave pairs of workgroup 0 have nothing to do: they leave at
+        cruise[320:384] = True                                     # once, and the workgroup's barriers go on without them
     out = {}
     for duo in (False, True):
         w = _world(fb, n, duo)
