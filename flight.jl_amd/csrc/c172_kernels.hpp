@@ -194,27 +194,29 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
     v.on_gnd = GROUND && aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
     return v;
 }
-// Avionics f_periodic! inside a stepping kernel (c172x2.jl:27-37): the outputs of the step's last f_ode! tapped from the state x it
-// saw (before f_step! renormalises the quaternions), guidance, then the control laws; gains by scalar loads. OUT OF LINE on
-// purpose: it runs once per control period, and inlined into the stepping loop its ~12 k instructions cost the loop its register
-// allocation (512 registers + 1.7 KB of scratch); as a call, only the call site pays (live registers saved around it).
+// Avionics f_periodic! inside a stepping kernel (c172x2.jl:27-37): guidance, then the control laws, on the outputs of the step's last
+// f_ode! — which the stepping loop has tapped from that very evaluation (the one at x_{n+1}, before f_step! renormalises the
+// quaternions) through a CtlSink, so nothing is evaluated again here (a second evaluation just for the tap was 12 % of a launch at
+// two steps per control period). OUT OF LINE on purpose: it runs once per control period, and inlined into the stepping loop its
+// ~9 k instructions cost the loop its register allocation (512 registers + 1.7 KB of scratch); as a call, only the call site pays
+// (live registers saved around it).
 // wave-uniform values that reach a function through the call ABI arrive in VGPRs and the compiler must treat them as per-lane:
 // v_readfirstlane turns them back into SGPR values (scalar loads, SGPR base addresses)
 FBD int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 FBD int64_t uni(int64_t v) { return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)(uint64_t)v)); }
 FBD double uni(double v) { return __builtin_bit_cast(double, uni(__builtin_bit_cast(int64_t, v))); }
 template <class P> FBD P* uni(P* p) { return (P*)(uintptr_t)uni((int64_t)(uintptr_t)p); }
-template <bool GROUND>
-__device__ __noinline__ void x2_periodic(const KArgs& a_in, int64_t i, const Tables& T_in, const double (&x)[FB_X2_NX], int stall, int eng, int ui,
-                                         const double (&cmd)[4]) {
-    KArgs a;   // the fields this function reads, wave-uniform again
-    a.u = uni(a_in.u); a.cu = uni(a_in.cu); a.cs = uni(a_in.cs); a.n = uni(a_in.n); a.gains = uni(a_in.gains); a.ctl_dT = uni(a_in.ctl_dT);
+struct CtlCall {   // the kernel arguments x2_periodic reads (a COPY: handing the callee the kernel's own KArgs by reference moved the
+    const double* cu; double* cs; const double* gains; int64_t n; double ctl_dT; CtlOffsets ctl_off;   // kernel arguments to scratch for the whole kernel, +25 % on every step)
+};
+__device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const CtlIn& v) {
+    const double* cu = uni(c_in.cu); double* cs = uni(c_in.cs); const double* gains = uni(c_in.gains);
+    const int64_t n = uni(c_in.n);
+    const double dT = uni(c_in.ctl_dT);
+    CtlOffsets off;
 #pragma unroll
-    for (int k = 0; k < 10; k++) a.ctl_off.off[k] = uni(a_in.ctl_off.off[k]);
-    a.ctl_off.total = uni(a_in.ctl_off.total);
-    a.env = {uni(a_in.env.T_sl), uni(a_in.env.p_sl), uni(a_in.env.wind_n), uni(a_in.env.wind_e), uni(a_in.env.wind_d), uni(a_in.env.h_trn),
-             uni(a_in.env.surface), uni(a_in.env.ln_p_sl), uni(a_in.env.k_rt)};
-    const Tables T = {(lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.lds), uni(T_in.egm96), (lds_cptr)(uintptr_t)uni((int)(uintptr_t)T_in.rk)};
+    for (int k = 0; k < 10; k++) off.off[k] = uni(c_in.ctl_off.off[k]);
+    off.total = uni(c_in.ctl_off.total);
     // cs / cu rows are read and written where the laws use them, through global pointers with wave-uniform bases (only the rows of
     // the active modes move; prefetching the whole 94-row record into registers and writing back what changed was measured 2x
     // slower: the copy spills). The gains come by per-lane gather from the L2-resident blob, one table's corner records per burst
@@ -222,12 +224,11 @@ __device__ __noinline__ void x2_periodic(const KArgs& a_in, int64_t i, const Tab
     // is an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit).
     typedef __attribute__((address_space(1))) double* gptr;
     typedef __attribute__((address_space(1))) const double* gcptr;
-    const CtlMemT<gptr> M = {(gptr)(uintptr_t)a.cu + i, (gptr)(uintptr_t)a.cs + i, a.n};
-    const CtlIn v = x2_ctl_inputs<GROUND>(a, i, T, x, stall, eng, ui, [&](int k) { return cmd[k]; });
+    const CtlMemT<gptr> M = {(gptr)(uintptr_t)cu + i, (gptr)(uintptr_t)cs + i, n};
     gdc_update(M, v);
-    const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)a.gains, a.ctl_off};
-    ctl_lon(tab, M, a.ctl_dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
-    ctl_lat(tab, M, a.ctl_dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
+    const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)gains, off};
+    ctl_lon(tab, M, dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
+    ctl_lat(tab, M, dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
 }
 
 // f_ode!(world): xdot (optional) and the output record y
@@ -507,6 +508,8 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
         const lds_cptr xrd_l = stage == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
         const lds_ptr xwr_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
+        [[maybe_unused]] CtlSink tap;
+        [[maybe_unused]] const bool tap_now = X && a.ctl_ratio > 0 && stage == 0 && pending_cb && !redoing && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
         if (run) {
             InT inl = in;                   // and keeps products of the per-lane inputs from being hoisted out of it
             double xa_s[X ? FB_NACT : 1];
@@ -522,7 +525,13 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
             }
             const AirEmit<B, GROUND, ACC_REGS> emit = {(lds_cptr)xs_l, acc, xwr_l, eb, ee, em, last, t};
             const SV xv = {xrd_l + t + lds_off};
-            bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            if constexpr (X) {
+                // the evaluation at x_{n+1} of a step that closes a control period is the "last f_ode!" whose outputs the control
+                // laws read: it runs with the partial sink (a second instance of rhs() in the loop, taken once per period)
+                if (tap_now) bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, tap);
+                else bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+            } else
+                bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
             if constexpr (X) {
                 if (last) {
@@ -547,18 +556,21 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
             if (run) {
                 if constexpr (X) {
                     if (ctl_now && bits == 0 && !aux.crash) {
-                        double xq[FB_X2_NX];
+                        CtlIn v;
+                        v.lat = tap.lat; v.lon = tap.lon;
+                        v.EAS = tap.EAS; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
+                        v.w_wb_b = {tap.wx, tap.wy, tap.wz};
+                        v.alpha = tap.alpha; v.beta = tap.beta;
+                        auto XS = [&](int k) { return xs_l[SV::row(k) * B + t]; };   // x_{n+1}, before f_step! touches it
+                        v.h_e = XS(FB_X_H_E);
+                        v.w_eb_b = {XS(FB_X_OMEGA_EB_B), XS(FB_X_OMEGA_EB_B + 1), XS(FB_X_OMEGA_EB_B + 2)};
+                        v.alpha_filt = XS(FB_X_ALPHA_FILT); v.beta_filt = XS(FB_X_BETA_FILT);
+                        v.n_eng = XS(FB_X_ENG_OMEGA) / c172::w_rated;
 #pragma unroll
-                        for (int k = 0; k < FB_NX; k++) xq[k] = SV::skip(k) ? 0.0 : xs_l[SV::row(k) * B + t];
-#pragma unroll
-                        for (int k = 0; k < FB_NACT; k++) xq[X2_ACT + k] = k < NAL ? xa[k] : 0.0;   // (in the air the brakes are not tapped)
-                        const double cmd4[4] = {ca[0], ca[1], ca[2], ca[3]};
-                        // (copies by design: the callee takes its arguments by reference, i.e. through memory, and handing it the kernel's
-                        // own `a` / `T` would move the kernel arguments to scratch for the WHOLE kernel — every table pointer a per-lane
-                        // value, the knot scans' scalar loads turned into vector global loads: measured +25 % on every step)
-                        const KArgs a_call = a;
-                        const Tables T_call = T;
-                        x2_periodic<GROUND>(a_call, i, T_call, xq, stall, eng, in.ui, cmd4);
+                        for (int k = 0; k < 4; k++) { v.pos[k] = clampd(xa[k], k == FB_ACT_THROTTLE ? 0.0 : -1.0, 1.0); v.cmd[k] = ca[k]; }   // (InputsX::pos)
+                        v.on_gnd = GROUND && aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
+                        const CtlCall cc = {a.cu, a.cs, a.gains, a.n, a.ctl_dT, a.ctl_off};
+                        x2_periodic(cc, i, v);
 #pragma unroll
                         for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
                     }
