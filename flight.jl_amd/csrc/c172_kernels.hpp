@@ -210,6 +210,7 @@ struct CtlCall {   // the kernel arguments x2_periodic reads (a COPY: handing th
     const double* cu; double* cs; const double* gains; int64_t n; double ctl_dT; CtlOffsets ctl_off;   // kernel arguments to scratch for the whole kernel, +25 % on every step)
 };
 __device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const CtlIn& v) {
+    FB_X2_STAMP(21);
     const double* cu = uni(c_in.cu); double* cs = uni(c_in.cs); const double* gains = uni(c_in.gains);
     const int64_t n = uni(c_in.n);
     const double dT = uni(c_in.ctl_dT);
@@ -224,11 +225,23 @@ __device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const C
     // is an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit).
     typedef __attribute__((address_space(1))) double* gptr;
     typedef __attribute__((address_space(1))) const double* gcptr;
-    const CtlMemT<gptr> M = {(gptr)(uintptr_t)cu + i, (gptr)(uintptr_t)cs + i, n};
+    double lu[FB_NCU], ls[FB_NCS];
+    {
+        const gcptr u0 = (gcptr)(uintptr_t)cu + i, c0 = (gcptr)(uintptr_t)cs + i;
+#pragma unroll
+        for (int k = 0; k < FB_NCU; k++) lu[k] = u0[(int64_t)k * n];   // one burst: all 94 rows of the record in flight together
+#pragma unroll
+        for (int k = 0; k < FB_NCS; k++) ls[k] = c0[(int64_t)k * n];
+    }
+    const CtlMemCachedT<gptr> M = {(gptr)(uintptr_t)cu + i, (gptr)(uintptr_t)cs + i, n, lu, ls};
+    FB_X2_STAMP(22);
     gdc_update(M, v);
+    FB_X2_STAMP(23);
     const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)gains, off};
     ctl_lon(tab, M, dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
+    FB_X2_STAMP(24);
     ctl_lat(tab, M, dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
+    FB_X2_STAMP(25);
 }
 
 // f_ode!(world): xdot (optional) and the output record y
@@ -571,6 +584,7 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                         v.on_gnd = GROUND && aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
                         const CtlCall cc = {a.cu, a.cs, a.gains, a.n, a.ctl_dT, a.ctl_off};
                         x2_periodic(cc, i, v);
+                        FB_X2_STAMP(26);
 #pragma unroll
                         for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
                     }

@@ -12,6 +12,13 @@
 #include "c172_device.hpp"
 
 namespace fbd {
+#ifndef FB_X2_STAMP
+#ifdef FB_STAMP
+#define FB_X2_STAMP(k) fb_stamp(k)
+#else
+#define FB_X2_STAMP(k) do { } while (0)
+#endif
+#endif
 
 // the ten lookups (te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ) inside the FB_TABLE_CTL_GAINS blob: offsets in doubles, and the
 // pointer type the control laws read them through — global memory (init kernel) or the workgroup's LDS copy (periodic kernel:
@@ -33,6 +40,30 @@ struct CtlMemT {
     FBD auto& S(int k) const { return cs[(int64_t)k * n]; }
 };
 typedef CtlMemT<double*> CtlMem;
+// The same interface with the whole record (cu and cs) cached in registers: the stepping kernels' in-line update (x2_periodic)
+// fetches all 94 rows in ONE burst before guidance and the laws run. At one wave per SIMD every batch of reads from memory at its
+// point of use is an exposed HBM round trip (the record of 524 288 aircraft is 394 MB: no cache holds it between updates), and there
+// were four of them in a row (guidance inputs, longitudinal inputs, lateral inputs, compensator states): 15.32 -> 15.17 ms per launch
+// of 25 updates — a modest gain, because the burst reads all 94 rows where the laws touched ~60 (writing everything back in one burst
+// at the end as well costs another 1.0 ms: HBM bandwidth). Reads come from the cache, writes go to both (write-through). The
+// per-phase cycle profile of one update (tools/stamp_x2.py, -DFB_STAMP build): record burst 2.9 k, guidance 1.3 k, longitudinal
+// channel 24 k (outer loops 8 k, LQR lookup 4 k, LQR run and stores 10 k), lateral 10 k, call and return 6 k cycles.
+// Every index the laws pass is a compile-time constant after inlining, so the cache is 94 register pairs, not an array in scratch.
+template <class P>
+struct CtlMemCachedT {
+    P cu, cs;
+    int64_t n;
+    double* lu;        // the caller's local copy of the cu rows
+    double* ls;        // ... and of the cs rows
+    struct Ref {
+        P g; double* l;
+        FBD operator double() const { return *l; }
+        FBD const Ref& operator=(double v) const { *l = v; *g = v; return *this; }
+        FBD const Ref& operator=(const Ref& o) const { return *this = (double)o; }
+    };
+    FBD Ref U(int k) const { return {cu + (int64_t)k * n, lu + k}; }
+    FBD Ref S(int k) const { return {cs + (int64_t)k * n, ls + k}; }
+};
 // what the control laws read from vehicle.y (XLonRed/XLonFull/XLatRed, Zte/Ztv/Zvh/Zφβ/Zar: c172x_ctl.jl:84-199, 745-810)
 struct CtlIn {
     double EAS, h_e, theta, phi, clm, chi, lat, lon;
@@ -192,6 +223,7 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     const double lo[2] = {0, -1}, hi[2] = {1, 1};
     const double x_red[8] = {v.w_eb_b.y, theta, EAS, v.alpha, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
     double out[2];
+    FB_X2_STAMP(27);
     if (te2te) {
         const double sat_thr = M.S(FB_CS_TE2TE + 2), sat_ele = M.S(FB_CS_TE2TE + 3);   // te2te_lqr.y.out_sat of the previous update
         if (v2t) {
@@ -219,8 +251,10 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             const double io = integ_run(M, FB_CS_Q2E_INT, dT, q_ref - q, sat_ele);
             elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
         }
+        FB_X2_STAMP(28);
         double g[FB_CTL_LQR8_REC];
         ctl_lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g);
+        FB_X2_STAMP(29);
         const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
         M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
         lqr_run<8>(M, FB_CS_TE2TE, g, lo, hi, dT, x_red, z, z_ref, out);
