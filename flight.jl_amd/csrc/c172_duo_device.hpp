@@ -6,11 +6,11 @@
 //   role P  "atmosphere + power plant"                     role D  "airframe"
 //   attitude, n_e                                          attitude, n_e
 //   geoid height (lat / lon, EGM96) -> h_o                 wind-relative velocity, airflow angles, filter rows,
-//   ISA atmosphere -> T, p, log p                          table locations on the alpha / beta axes
-//   put rho, h_o, 1/a  ------------------ barrier A ---->  get rho, h_o
-//   wind-relative velocity, propeller                      kinematics derivatives (9 rows), ground-effect location,
-//   put F_p, tau_p, h_rot                                  aerodynamic coefficients and wrench, landing gear (airborne shortcut),
-//   engine (3 rows)                                        mass properties, gravity at the CoM
+//   ISA atmosphere -> T, p, log p                          table locations and lookups on the alpha / beta axes
+//   put rho, h_o  ----------------------- barrier A ---->  get rho, h_o
+//   wind-relative velocity, propeller                      radii of curvature, kinematics derivatives (9 rows), mass properties,
+//   put F_p, tau_p, h_rot                                  gravity at the CoM, ground-effect location, aerodynamic coefficients and
+//   engine (3 rows)                                        wrench, landing gear (airborne shortcut)
 //        ...  ------------------------- barrier B ---->    get F_p, tau_p, h_rot
 //   engine tail, fuel row                                  rigid-body dynamics (6 rows)
 //
@@ -195,27 +195,18 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double cy_p = lerp2(A + AT_CY_P_V, 2, l_al2, l_df2), cy_r = lerp2(A + AT_CY_R_V, 2, l_al2, l_df2);
         const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
         const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
-        // ----- radii of curvature (geodesy.jl:125-129), fuel mass, mass properties, gravity at the CoM: while role P works on the atmosphere -----
-        const double i_fden = rsqrt(1 - wgs::e2 * n_e.z * n_e.z);   // 1 / sqrt(1 - e^2 sin^2 lat)
-        const double R_E = wgs::a * i_fden;
-        const double R_N = (wgs::a * (1 - wgs::e2)) * (i_fden * i_fden * i_fden);
-        const double RE_h = R_E + h_e, RN_h = R_N + h_e, i_REN = 1 / (RE_h * RN_h);   // both reciprocals from one division
-        const double i_RE = RN_h * i_REN, i_RN = RE_h * i_REN;
-        const double m_fuel_total = m_res + x_fuel * (m_full - m_res);
-        aux.m_avail = m_fuel_total - m_res;
-        double M, J[6], Jc[6], iM;
-        v3 r_bc;
-        mass_props(m_fuel_total, in, M, J, iM, r_bc, Jc);
-        const double Jxx = Jc[0], Jyy = Jc[1], Jzz = Jc[2], Jxy = Jc[3], Jxz = Jc[4], Jyz = Jc[5];
-        v3 d_e;
-        const v3 g_c_c = gravity_com(q_eb, r_bc, n_e, h_e, R_N, R_E, i_RN, i_RE, st, d_e);
-        const v3 w_ie_b = earth_rate_b(q_eb);
         emit.xsync();   // ----- barrier A -----
         const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         const double q_dyn = 0.5 * rho * (TAS * TAS);
 
         // ----- kinematics derivatives (kinematics.jl:181-242; geodesy.jl:125-129) -----
+        // ----- radii of curvature (geodesy.jl:125-129), fuel mass, mass properties, gravity at the CoM: while role P works on the atmosphere -----
+        const double i_fden = rsqrt(1 - wgs::e2 * n_e.z * n_e.z);   // 1 / sqrt(1 - e^2 sin^2 lat)
+        const double R_E = wgs::a * i_fden;
+        const double R_N = (wgs::a * (1 - wgs::e2)) * (i_fden * i_fden * i_fden);
+        const double RE_h = R_E + h_e, RN_h = R_N + h_e, i_REN = 1 / (RE_h * RN_h);   // both reciprocals from one division
+        const double i_RE = RN_h * i_REN, i_RN = RE_h * i_REN;
         const v3 v_eb_n = qrot(q_nb, v_eb_b);
         const v3 w_ew_n = {v_eb_n.y * i_RE, -v_eb_n.x * i_RN, 0.0};
         const double cpsi = q_nw.w * q_nw.w - q_nw.z * q_nw.z, spsi = 2 * (q_nw.w * q_nw.z);
@@ -234,6 +225,16 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             emit_rows<4>(emit, KX, kq1);
             emit_rows<5>(emit, KX + 4, kq2);
         }
+        // ----- fuel mass, mass properties, gravity at the CoM -----
+        const double m_fuel_total = m_res + x_fuel * (m_full - m_res);
+        aux.m_avail = m_fuel_total - m_res;
+        double M, J[6], Jc[6], iM;
+        v3 r_bc;
+        mass_props(m_fuel_total, in, M, J, iM, r_bc, Jc);
+        const double Jxx = Jc[0], Jyy = Jc[1], Jzz = Jc[2], Jxy = Jc[3], Jxz = Jc[4], Jyz = Jc[5];
+        v3 d_e;
+        const v3 g_c_c = gravity_com(q_eb, r_bc, n_e, h_e, R_N, R_E, i_RN, i_RE, st, d_e);
+        const v3 w_ie_b = earth_rate_b(q_eb);
 
         // ----- aerodynamics, the rest (c172.jl:341-373, 226-245) -----
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
