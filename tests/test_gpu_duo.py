@@ -43,6 +43,10 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
     u0[fb.K["FB_U_ELEVATOR"]] += rng.uniform(-0.03, 0.03, n)      # not a steady state
     u0[fb.K["FB_U_AILERON"]] += rng.uniform(-0.03, 0.03, n)
     u0[fb.K["FB_U_M_PILOT"]] = rng.uniform(50, 100, n)             # per-aircraft payload: the mass-property sums differ lane by lane
+    x0 = x0.copy()
+    far = np.nonzero(cruise & ok)[0][:8]
+    x0[fb.K["FB_X_H_E"], far[:4]] = 90e3                            # above the ISA model (found by role P: FB_ST_ISA_RANGE)
+    x0[fb.K["FB_X_H_E"], far[4:]] = -1500.0                         # below the altitude range (FB_ST_ALT_RANGE)
     st0 = np.zeros(n, np.int32)
     st0[rng.random(n) < 0.05] = fb.K["FB_ST_NAN"]                  # terminated before the launch: must be left alone
     if n >= 512:
@@ -60,6 +64,8 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
         w.close()
     (xa, sa, sta), (xd, sd, std) = out[False], out[True]
     assert np.array_equal(sta, std) and np.array_equal(sa, sd)
+    hi, lo = far[:4][st0[far[:4]] == 0], far[4:][st0[far[4:]] == 0]   # (those not already terminated before the launch)
+    assert len(hi) + len(lo) > 0 and (std[hi] & fb.K["FB_ST_ISA_RANGE"]).all() and (std[lo] & fb.K["FB_ST_ALT_RANGE"]).all()
     dead0 = st0 != 0
     assert np.array_equal(xd[:, dead0], x0[:, dead0])               # untouched
     live = ok & (sta == 0)
