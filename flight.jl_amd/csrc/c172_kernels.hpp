@@ -789,6 +789,22 @@ struct DuoEmit {
     __device__ __forceinline__ void xsync() const { __syncthreads(); }
     __device__ __forceinline__ void xstatus(int32_t st) const { *dst_p |= (st & 3) << DUO_D_PST_SHIFT; }   // (FB_ST_ALT_RANGE | FB_ST_ISA_RANGE)
 };
+// every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
+constexpr bool duo_rows_ok() {
+    int np = 0, nd = 0;
+    bool seen_p[DUO_NP] = {}, seen_d[DUO_ND] = {};
+    for (int j = 0; j < FB_NX; j++) {
+        if (StateLds<DUO_B, false>::skip(j)) { if (DuoEmit<1>::owned(j) || DuoEmit<2>::owned(j)) return false; continue; }
+        const int r = StateLds<DUO_B, false>::row(j);
+        if (DuoEmit<1>::owned(j) == DuoEmit<2>::owned(j)) return false;
+        if (DuoEmit<1>::owned(j)) { const int k = DuoEmit<1>::slot(r); if (k < 0 || k >= DUO_NP || seen_p[k]) return false; seen_p[k] = true; np++; }
+        else { const int k = DuoEmit<2>::slot(r); if (k < 0 || k >= DUO_ND || seen_d[k]) return false; seen_d[k] = true; nd++; }
+    }
+    return np == DUO_NP && nd == DUO_ND;
+}
+static_assert(duo_rows_ok(), "k_step_duo: row ownership / stage-sum slots");
+static_assert(DuoEmit<1>::owned(FB_X_FUEL) && DuoEmit<1>::owned(FB_X_ENG_OMEGA) && DuoEmit<2>::owned(FB_X_Q_WB) && DuoEmit<2>::owned(FB_X_V_EB_B + 2),
+              "rhs_duo emits the engine and fuel rows in role P, everything else in role D");
 enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
 enum { DUO_C_EXIT = 4, DUO_C_CB = 8 };                              // per-pair control word: stage | EXIT | CB
 template <int KIN>
