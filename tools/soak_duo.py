@@ -1,0 +1,36 @@
+"""One-off long run of the default airborne fp64 stepper against the CPU oracle: 100 s of flight (10 000 RK4 steps) for a stratified
+sample of bench.py's lattice, plus invariants over a larger batch.   python tools/soak_duo.py [n_oracle=1024] [n_batch=65536]"""
+import os, sys, time
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, "flight.jl_amd")); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import flightbatch as fb
+import bench
+from oracle_binding import Oracle
+n_or = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+EAS, h, psi, cell = bench.lattice(0)
+EAS, h, psi = EAS[:n], h[:n], psi[:n]
+w = fb.BatchedWorld(n)
+fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+x0, s0, u0, ui0 = w.x, w.s, w.u.copy(), w.ui
+rng = np.random.default_rng(3)
+u0[fb.K["FB_U_ELEVATOR"]] += rng.uniform(-0.02, 0.02, n); u0[fb.K["FB_U_AILERON"]] += rng.uniform(-0.02, 0.02, n)   # phugoid + roll
+w.u = u0
+sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+t0 = time.time(); fb.step(sim, 100.0); w.sync(); print("GPU: %d aircraft x 10000 steps in %.2f s" % (n, time.time() - t0), flush=True)
+xg, sg, stg = w.x, w.s, w.status
+idx = np.sort(rng.choice(n, n_or, replace=False))
+orc = Oracle()
+t0 = time.time()
+xo, so, sto = orc.step(x0[:, idx], u0[:, idx], ui0[idx], s0[:, idx], orc.default_env(), 0.01, 10000)
+print("oracle: %d aircraft x 10000 steps in %.1f s" % (n_or, time.time() - t0), flush=True)
+mis = np.nonzero(stg[idx] != sto)[0]
+print("status mismatches: %d; GPU bits %s, oracle bits %s; final h_e (oracle) there: %s" % (len(mis), stg[idx][mis][:10].tolist(), sto[mis][:10].tolist(), np.round(xo[20, mis][:10], 1).tolist()))
+print("status histogram GPU (all): %s" % dict(zip(*np.unique(stg, return_counts=True))))
+live = (sto == 0) & (stg[idx] == 0)
+err = np.abs(xg[:, idx] - xo) / np.maximum(np.abs(xo), 1.0)
+# (the GPU freezes an aircraft at its first termination bit; the oracle's loop steps on and collects further bits: compare "terminated or not")
+print("terminated-or-not equal: %s; terminated: GPU %d of %d, oracle %d of %d" % (np.array_equal(stg[idx] != 0, sto != 0), int((stg != 0).sum()), n, int((sto != 0).sum()), n_or))
+print("max scaled |x_gpu - x_oracle| after 10000 steps over %d live aircraft: %.3e (row %d)" % (int(live.sum()), err[:, live].max(), int(err[:, live].max(axis=1).argmax())))
+q = xg[12:16]; print("max | |q_wb| - 1 | = %.2e; non-finite states: %d" % (np.abs(np.sqrt((q ** 2).sum(0)) - 1).max(), int((~np.isfinite(xg)).sum())))
