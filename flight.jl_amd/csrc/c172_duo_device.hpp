@@ -4,28 +4,31 @@
 // and tools/duo_check.py + the parity tests compare the two); only the order of the blocks and who evaluates them differ:
 //
 //   role P  "atmosphere + power plant"                     role D  "airframe"
-//   attitude, n_e                                          attitude, n_e
-//   geoid height (lat / lon, EGM96) -> h_o                 wind-relative velocity, airflow angles, filter rows,
+//   n_e                                                    attitude, n_e, wind-relative velocity -> put the velocity at the propeller
+//   geoid height (lat / lon, EGM96) -> h_o                 airflow angles, filter rows,
 //   ISA atmosphere -> T, p, log p                          table locations and lookups on the alpha / beta axes
 //   put rho, h_o  ----------------------- barrier A ---->  get rho, h_o
-//   wind-relative velocity, propeller                      radii of curvature, kinematics derivatives (9 rows), mass properties,
+//   get the velocity at the propeller; propeller            radii of curvature, kinematics derivatives (9 rows), mass properties,
 //   put F_p, tau_p, h_rot                                  gravity at the CoM, ground-effect location, aerodynamic coefficients and
 //   engine (3 rows)                                        wrench, landing gear (airborne shortcut)
 //        ...  ------------------------- barrier B ---->    get F_p, tau_p, h_rot
 //   engine tail, fuel row                                  rigid-body dynamics (6 rows)
 //
-// Only the attitude products (~100 instructions) are evaluated twice. Who may touch which LDS row when:
+// Only n_e (ten instructions) is evaluated twice. Who may touch which LDS row when:
 //   * both roles read the state rows they need from the other role's rows BEFORE barrier A (D: nothing of P's but the fuel row,
-//     which P rewrites last of all, after B; P: attitude, altitude, angular and linear velocity);
+//     which P rewrites last of all, after B; P: q_ew and h_e);
 //   * D rewrites the kinematics rows after A, its angular / linear velocity rows after B; P rewrites the engine rows after A and
 //     the fuel row after B;
-//   * exchange rows 0-5 are the angular / linear velocity rows of the evaluation panel, dead between A and D's own emit at the end.
+//   * exchange rows 0-5 are the angular / linear velocity rows of the evaluation panel: only role D reads them as state (at its head),
+//     so it may overwrite rows 0-2 with the velocity at the propeller before A; role P reads that after A and then writes F_p, tau_p
+//     over rows 0-5, which D reads after B and overwrites with its own emit at the end.
 #pragma once
 #include "c172_device.hpp"
 
 namespace fbd {
 
 constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
+constexpr int XD_VP = XD_FP;   // role D -> role P before barrier A: the velocity at the propeller, in the rows that carry F_p after it
 
 template <int ROLE, class In, class Emit, class XV>
 __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state, const In& in, const Env& env, const Tables& T, const Emit& emit, StepAux& aux) {
@@ -37,24 +40,15 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
     auto atan2m = [&](double y, double x0) -> double { return atan2_step(y, x0, T.rk + LDS_ATAN); };
     auto atan2p = [&](double y, double x0) -> double { return atan2_step<true>(y, x0, T.rk + LDS_ATAN); };   // x0 >= 0, not both zero
 
-    // ===== kinematics head, both roles (kinematics.jl:181-223; geodesy.jl:62-69, 140-147) =====
-    const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
-    const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
+    // ===== kinematics head (kinematics.jl:181-223; geodesy.jl:62-69, 140-147). Role P needs the position only (n_e from q_ew, h_e); the
+    // attitude products, the wind-relative velocity and from it the velocity at the propeller are role D's, which hands the latter over =====
     const double h_e = x[KX + 8];
     if (!(h_e >= H_MIN)) st |= FB_ST_ALT_RANGE;
-    const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
     const quat q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
     const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
     const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
     const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
-    double s_nw, c_nw;
-    half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
-    const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
-    const quat q_nb = {c_nw * q_wb.w - s_nw * q_wb.z, c_nw * q_wb.x - s_nw * q_wb.y, c_nw * q_wb.y + s_nw * q_wb.x, c_nw * q_wb.z + s_nw * q_wb.w};
-    // wind-relative velocity (atmosphere.jl:269-283)
-    const v3 v_ew_n = {env.wind_n, env.wind_e, env.wind_d};
-    const v3 v_ew_b = qrot_inv(q_nb, v_ew_n);
-    const v3 v_wb_b = v_eb_b - v_ew_b;
+    const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
 
     if constexpr (ROLE == 1) {
         // ================================= role P =================================
@@ -80,8 +74,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
 
         // ----- propeller (propellers.jl:405-452) -----
         const double w_prop = w_eng;  // gear ratio 1
-        const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
-        const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
+        const v3 v_p = {emit.xget(XD_VP), emit.xget(XD_VP + 1), emit.xget(XD_VP + 2)};   // v_wb_b + w_eb_b x r_p, from role D
         const double v_J = norm(v_p);
         const double J_adv = 2 * PI * v_J / (fmax(fabs(w_prop), 1.0) * prop_d);
         const double Mt = fabs(w_prop) * (prop_d / 2) * i_a_snd;
@@ -159,6 +152,21 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         // ================================= role D =================================
         lds_cptr A = T.lds + LDS_AERO;
         lds_cptr RA = T.rk + LDS_AERO;
+        const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
+        const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
+        const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+        double s_nw, c_nw;
+        half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
+        const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
+        const quat q_nb = {c_nw * q_wb.w - s_nw * q_wb.z, c_nw * q_wb.x - s_nw * q_wb.y, c_nw * q_wb.y + s_nw * q_wb.x, c_nw * q_wb.z + s_nw * q_wb.w};
+        // wind-relative velocity (atmosphere.jl:269-283)
+        const v3 v_ew_n = {env.wind_n, env.wind_e, env.wind_d};
+        const v3 v_ew_b = qrot_inv(q_nb, v_ew_n);
+        const v3 v_wb_b = v_eb_b - v_ew_b;
+        {   // ... and at the propeller, for role P (exchange rows 0-2: this role's own velocity rows of the evaluation panel, read just above)
+            const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
+            emit.xput(XD_VP, v_p.x); emit.xput(XD_VP + 1, v_p.y); emit.xput(XD_VP + 2, v_p.z);
+        }
         const quat q_eb = qmul(q_ew, q_wb);
         const double x_fuel = x[FB_X_FUEL];   // (before barrier A: role P rewrites this row at the very end of its evaluation)
         const double TAS = norm(v_wb_b);
