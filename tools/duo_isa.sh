@@ -1,4 +1,5 @@
 #!/bin/bash
+mkdir -p /tmp/w
 # compile the device code to ISA and summarise the wave-specialised stepper: registers, scratch, spill ops between barriers, spill check
 cd /root/repo/flight.jl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -freciprocal-math -fapprox-func -fno-hip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm -fPIC "$@" -S --cuda-device-only -o /tmp/w/duo.s fb_capi.hip 2>&1 | grep -v "argument unused" | head -30
 cd /root/repo
