@@ -218,13 +218,14 @@ __device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const C
 #pragma unroll
     for (int k = 0; k < 10; k++) off.off[k] = uni(c_in.ctl_off.off[k]);
     off.total = uni(c_in.ctl_off.total);
+    off.same_grid = uni(c_in.ctl_off.same_grid);
     // cs / cu rows are read and written where the laws use them, through global pointers with wave-uniform bases (only the rows of
     // the active modes move; prefetching the whole 94-row record into registers and writing back what changed was measured 2x
     // slower: the copy spills). The gains come by per-lane gather from the L2-resident blob, one table's corner records per burst
     // (scalar loads through a wave-uniform loop over the distinct grid cells were also measured 2x slower: every s_load batch
     // is an exposed L2 round trip behind a 16 KB scalar cache that the 46 KB blob does not fit).
     typedef __attribute__((address_space(1))) double* gptr;
-    typedef __attribute__((address_space(1))) const double* gcptr;
+    typedef ctlg_cptr gcptr;
     double lu[FB_NCU], ls[FB_NCS];
     {
         const gcptr u0 = (gcptr)(uintptr_t)cu + i, c0 = (gcptr)(uintptr_t)cs + i;
@@ -237,10 +238,17 @@ __device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const C
     FB_X2_STAMP(22);
     gdc_update(M, v);
     FB_X2_STAMP(23);
-    const CtlTabT<gcptr> tab = {(gcptr)(uintptr_t)gains, off};
+    const CtlTabT<gcptr> tab = ctl_tab((gcptr)(uintptr_t)gains, off, v.EAS, v.h_e);
+    const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
+#ifdef FB_X2_LAT_EARLY
+    const LatGains LG = ctl_lat_gains(tab, v, lat_req);   // in flight while the longitudinal channel runs
+#endif
     ctl_lon(tab, M, dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
     FB_X2_STAMP(24);
-    ctl_lat(tab, M, dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
+#ifndef FB_X2_LAT_EARLY
+    const LatGains LG = ctl_lat_gains(tab, v, lat_req);
+#endif
+    ctl_lat(tab, M, dT, v, lat_req, LG);
     FB_X2_STAMP(25);
 }
 

@@ -23,14 +23,59 @@ namespace fbd {
 // the ten lookups (te2te tv2te vh2te q2e c2θ v2t ar2ar φβ2ar p2φ χ2φ) inside the FB_TABLE_CTL_GAINS blob: offsets in doubles, and the
 // pointer type the control laws read them through — global memory (init kernel) or the workgroup's LDS copy (periodic kernel:
 // 46 KB staged once per workgroup; the ~330 corner loads per aircraft then cost LDS, not L2, latency)
-struct CtlOffsets { int off[10]; int total; };
+// same_grid: all ten lookups sit on ONE (EAS, h) grid (fb_set_table compares the headers; true of the reference's data files:
+// 7 x 4 nodes over 25-55 m/s x 50-3050 m). The cell and the weights are then located once per update, from the first lookup's
+// header, instead of once per lookup (with its own header fetch: an exposed round trip ahead of every gather).
+struct CtlOffsets { int off[10]; int total; int same_grid; };
 typedef __attribute__((address_space(3))) const double* ldsd_cptr;
+typedef __attribute__((address_space(1))) const double* ctlg_cptr;   // the gains blob through a global-memory pointer (x2_periodic)
+typedef __attribute__((address_space(4))) const double* ctlk_cptr;   // ... and its wave-uniform headers through scalar loads
+FBD ctlk_cptr ctl_hdr(ctlg_cptr p) { return (ctlk_cptr)(uintptr_t)p; }
+template <class P> FBD P ctl_hdr(P p) { return p; }
+struct CtlCell { int r00, r10, r01, r11; double wE, wH; };   // the four corner records of the cell and the weights along EAS and h
+// linear in (EAS, h_e), Flat extrapolation (FP/control.jl:950-994); H: the lookup's six-double header
+template <class H>
+FBD CtlCell ctl_cell(const H& lk, double EAS, double h) {
+    const int nE = (int)lk[0], nH = (int)lk[1];
+    int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
+    double wE = 0, wH = 0;
+    if (nE > 1) {
+        const double xi = (fmin(fmax(EAS, lk[2]), lk[3]) - lk[2]) / ((lk[3] - lk[2]) / (nE - 1));
+        i0 = min(max((int)floor(xi), 0), nE - 2); i1 = i0 + 1; wE = xi - i0;
+    }
+    if (nH > 1) {
+        const double xj = (fmin(fmax(h, lk[4]), lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
+        j0 = min(max((int)floor(xj), 0), nH - 2); j1 = j0 + 1; wH = xj - j0;
+    }
+    return {i0 + nE * j0, i1 + nE * j0, i0 + nE * j1, i1 + nE * j1, wE, wH};
+}
+template <int REC, class P>
+FBD void ctl_interp(P d, const CtlCell& c, double (&out)[REC]) {
+    const P a00 = d + c.r00 * REC, a10 = d + c.r10 * REC, a01 = d + c.r01 * REC, a11 = d + c.r11 * REC;
+    const double wE = c.wE, wH = c.wH;
+#pragma unroll
+    for (int k = 0; k < REC; k++) out[k] = (1 - wE) * ((1 - wH) * a00[k] + wH * a01[k]) + wE * ((1 - wH) * a10[k] + wH * a11[k]);
+}
 template <class P>
 struct CtlTabT {
     P base;
     CtlOffsets o;
+    CtlCell cell;      // of this update's (EAS, h_e), when o.same_grid (ctl_tab)
     FBD P lk(int k) const { return base + o.off[k]; }
+    // the record of lookup `p` (a per-lane choice between lookups of one record size is fine) at (EAS, h)
+    template <int REC>
+    FBD void lookup(P p, double EAS, double h, double (&out)[REC]) const {
+        CtlCell c = cell;
+        if (!o.same_grid) c = ctl_cell(p, EAS, h);
+        ctl_interp<REC>(p + FB_CTL_GRID_HDR, c, out);
+    }
 };
+template <class P>
+FBD CtlTabT<P> ctl_tab(P base, const CtlOffsets& o, double EAS, double h) {
+    CtlTabT<P> T = {base, o, {0, 0, 0, 0, 0.0, 0.0}};
+    if (o.same_grid) T.cell = ctl_cell(ctl_hdr(base + o.off[0]), EAS, h);
+    return T;
+}
 template <class P>
 struct CtlMemT {
     P cu;              // &cu[0 * n + i]  (guidance rewrites references and mode requests)
@@ -97,35 +142,12 @@ FBD double sgnd(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
 FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
 constexpr double CTL_INF = __builtin_huge_val();
 
-// ---- gain lookup: bilinear over the (EAS, h) grid, record by record -------------------------------------------
-template <int REC, class P>
-FBD void ctl_lookup(P lk, double EAS, double h, double (&out)[REC]) {
-    const int nE = (int)lk[0], nH = (int)lk[1];
-    int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
-    double wE = 0, wH = 0;
-    if (nE > 1) {
-        const double xi = (fmin(fmax(EAS, lk[2]), lk[3]) - lk[2]) / ((lk[3] - lk[2]) / (nE - 1));
-        i0 = min(max((int)floor(xi), 0), nE - 2); i1 = i0 + 1; wE = xi - i0;
-    }
-    if (nH > 1) {
-        const double xj = (fmin(fmax(h, lk[4]), lk[5]) - lk[4]) / ((lk[5] - lk[4]) / (nH - 1));
-        j0 = min(max((int)floor(xj), 0), nH - 2); j1 = j0 + 1; wH = xj - j0;
-    }
-    const P d = lk + FB_CTL_GRID_HDR;
-    const P a00 = d + (i0 + nE * j0) * REC;
-    const P a10 = d + (i1 + nE * j0) * REC;
-    const P a01 = d + (i0 + nE * j1) * REC;
-    const P a11 = d + (i1 + nE * j1) * REC;
-#pragma unroll
-    for (int c = 0; c < REC; c++) out[c] = (1 - wE) * ((1 - wH) * a00[c] + wH * a01[c]) + wE * ((1 - wH) * a10[c] + wH * a11[c]);
-}
-
 // ---- compensators; their states are rows of the cs record ------------------------------------------------------
 struct PidGains { double k_p, k_i, k_d, tau_f; };
-template <class P>
-FBD PidGains pid_gains(P lk, double EAS, double h) {
+template <class TAB, class P>
+FBD PidGains pid_gains(const TAB& T, P lk, double EAS, double h) {
     double g[FB_CTL_PID_REC];
-    ctl_lookup<FB_CTL_PID_REC>(lk, EAS, h, g);
+    T.template lookup<FB_CTL_PID_REC>(lk, EAS, h, g);
     return {g[0], g[1], g[2], g[3]};
 }
 // PID f_periodic! (β_p = β_d = 1); rows s0 .. s0+2 = x_i0, x_d0, sat_out_0
@@ -224,15 +246,25 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     const double x_red[8] = {v.w_eb_b.y, theta, EAS, v.alpha, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
     double out[2];
     FB_X2_STAMP(27);
+    // The gains of the three PID loops are fetched TOGETHER, ahead of the loops: at one wave per SIMD every lookup placed at its
+    // point of use was an exposed gather (and, with a header per lookup, a second round trip ahead of it). A lane whose mode runs
+    // fewer loops fetches gains it does not use. (The LQR record stays at its point of use: held across the loops, its 36 values
+    // push the update's register footprint to where the calling kernel's allocation suffers.)
+    PidGains P_v2t = {0, 0, 0, 0}, P_q2e = {0, 0, 0, 0}, P_c2t = {0, 0, 0, 0};
+    if (q2e) {
+        P_v2t = pid_gains(T, T.lk(5), EAS, h_e);
+        P_q2e = pid_gains(T, T.lk(3), EAS, h_e);
+        P_c2t = pid_gains(T, T.lk(4), EAS, h_e);
+    }
     if (te2te) {
         const double sat_thr = M.S(FB_CS_TE2TE + 2), sat_ele = M.S(FB_CS_TE2TE + 3);   // te2te_lqr.y.out_sat of the previous update
         if (v2t) {
-            const PidGains P = pid_gains(T.lk(5), EAS, h_e);
+            const PidGains P = P_v2t;
             if (changed) { pid_init(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT); if (P.k_i != 0) M.S(FB_CS_V2T_PID) = M.S(FB_CS_THROTTLE_CMD); }
             throttle_ref = pid_run(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT, EAS_ref - EAS, sat_thr);
         }
         if (q2e) {
-            const PidGains P = pid_gains(T.lk(3), EAS, h_e);
+            const PidGains P = P_q2e;
             if (changed) {
                 integ_init(M, FB_CS_Q2E_INT, dT);
                 pid_init(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT);
@@ -240,7 +272,7 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             }
             if (th2q) {
                 if (mode == FB_LON_EAS_CLM) {
-                    const PidGains Pc = pid_gains(T.lk(4), EAS, h_e);
+                    const PidGains Pc = P_c2t;
                     if (changed) { pid_init(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT); if (Pc.k_i != 0) M.S(FB_CS_C2THETA_PID) = theta; }
                     theta_ref = pid_run(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT, clm_ref - v.clm, sat_ele);
                 }
@@ -252,25 +284,25 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
         }
         FB_X2_STAMP(28);
-        double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g);
+        double g8[FB_CTL_LQR8_REC];
+        T.template lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g8);
         FB_X2_STAMP(29);
         const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
         M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
-        lqr_run<8>(M, FB_CS_TE2TE, g, lo, hi, dT, x_red, z, z_ref, out);
+        lqr_run<8>(M, FB_CS_TE2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
         throttle_cmd = out[0]; elevator_cmd = out[1];
     }
     if (mode == FB_LON_THR_EAS) {
-        double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(1), EAS, h_e, g);
-        if (changed) lqr_init<8>(M, FB_CS_TV2TE, g, lo, hi, dT);
+        double g8[FB_CTL_LQR8_REC];
+        T.template lookup<FB_CTL_LQR8_REC>(T.lk(1), EAS, h_e, g8);
+        if (changed) lqr_init<8>(M, FB_CS_TV2TE, g8, lo, hi, dT);
         const double z[2] = {v.cmd[0], EAS}, z_ref[2] = {throttle_ref, EAS_ref};
-        lqr_run<8>(M, FB_CS_TV2TE, g, lo, hi, dT, x_red, z, z_ref, out);
+        lqr_run<8>(M, FB_CS_TV2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
         throttle_cmd = out[0]; elevator_cmd = out[1];
     }
     if (mode == FB_LON_EAS_ALT) {
         double g[FB_CTL_LQR9_REC];
-        ctl_lookup<FB_CTL_LQR9_REC>(T.lk(2), EAS, h_e, g);
+        T.template lookup<FB_CTL_LQR9_REC>(T.lk(2), EAS, h_e, g);
         if (changed) lqr_init<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
         const double x_full[9] = {v.w_eb_b.y, theta, EAS, v.alpha, h_e, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
         const double z[2] = {EAS, h_e}, z_ref[2] = {EAS_ref, h_ref};
@@ -328,8 +360,22 @@ FBD void gdc_update(const MEM& M, const CtlIn& v) {
 }
 
 // ---- lateral channel -----------------------------------------------------------------------------------------------
+// the gains the lateral mode may need — one eight-state LQR record and one PID record, chosen per lane — fetched in one block
+// (and, by x2_periodic, AHEAD of the longitudinal channel, whose dependent chains then hide the gathers)
+struct LatGains { double g8[FB_CTL_LQR8_REC]; PidGains P; };
+template <class TAB>
+FBD LatGains ctl_lat_gains(const TAB& T, const CtlIn& v, int mode_req) {
+    const int mode = v.on_gnd ? (int)FB_LAT_DIRECT : mode_req;
+    LatGains G;
+    G.P = {0, 0, 0, 0};
+    if (mode == FB_LAT_SAS || mode == FB_LAT_P_BETA || mode == FB_LAT_PHI_BETA || mode == FB_LAT_CHI_BETA) {
+        T.template lookup<FB_CTL_LQR8_REC>(mode == FB_LAT_SAS ? T.lk(6) : T.lk(7), v.EAS, v.h_e, G.g8);
+        G.P = pid_gains(T, mode == FB_LAT_P_BETA ? T.lk(8) : T.lk(9), v.EAS, v.h_e);
+    }
+    return G;
+}
 template <class TAB, class MEM>
-FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
+FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req, const LatGains& G) {
     const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
     double phi_ref = M.U(FB_CU_PHI_REF);
     const double EAS = v.EAS, h_e = v.h_e;
@@ -343,16 +389,14 @@ FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     const double x_lat[8] = {v.w_eb_b.x, v.w_eb_b.z, v.phi, EAS, v.beta, v.beta_filt, v.pos[1], v.pos[3]};
     double out[2];
     if (mode == FB_LAT_SAS) {
-        double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(6), EAS, h_e, g);
         const double z[2] = {v.cmd[1], v.cmd[3]}, z_ref[2] = {aileron_ref, rudder_ref};
-        lqr_run<8>(M, FB_CS_AR2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
+        lqr_run<8>(M, FB_CS_AR2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
         aileron_cmd = out[0]; rudder_cmd = out[1];
     }
     if (mode == FB_LAT_P_BETA || mode == FB_LAT_PHI_BETA || mode == FB_LAT_CHI_BETA) {
         const double sat_ail = M.S(FB_CS_PHIBETA2AR + 2);
         if (mode == FB_LAT_P_BETA) {
-            const PidGains P = pid_gains(T.lk(8), EAS, h_e);
+            const PidGains P = G.P;
             if (changed) {
                 integ_init(M, FB_CS_P2PHI_INT, dT);
                 pid_init(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT);
@@ -361,16 +405,14 @@ FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             const double io = integ_run(M, FB_CS_P2PHI_INT, dT, p_ref - v.w_wb_b.x, sat_ail);
             phi_ref = pid_run(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ail);
         } else if (mode == FB_LAT_CHI_BETA) {
-            const PidGains P = pid_gains(T.lk(9), EAS, h_e);
+            const PidGains P = G.P;
             if (changed) { pid_init(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT); if (P.k_i != 0) M.S(FB_CS_CHI2PHI_PID) = M.S(FB_CS_PHIBETA2AR + 4); }
             phi_ref = pid_run(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT, wrap_to_pi(chi_ref - v.chi), sat_ail);
         }
-        double g[FB_CTL_LQR8_REC];
-        ctl_lookup<FB_CTL_LQR8_REC>(T.lk(7), EAS, h_e, g);
-        if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT);
+        if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT);
         const double z[2] = {v.phi, v.beta}, z_ref[2] = {phi_ref, beta_ref};
         M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];
-        lqr_run<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
+        lqr_run<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
         aileron_cmd = out[0]; rudder_cmd = out[1];
     }
     M.S(FB_CS_LAT_MODE) = mode;

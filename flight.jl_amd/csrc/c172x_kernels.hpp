@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const CtlIn v = x2_ctl_inputs(a, i, T, x, [&](int k) { return x2_command(a, i, k); });
     const CtlMem M = {const_cast<double*>(a.cu) + i, a.cs + i, a.n};
     gdc_update(M, v);   // Avionics f_periodic!: guidance first, then the control laws (c172x2.jl:27-37)
-    const CtlTabT<ldsd_cptr> tab = {(ldsd_cptr)gains_l, c.off};
+    const CtlTabT<ldsd_cptr> tab = ctl_tab((ldsd_cptr)gains_l, c.off, v.EAS, v.h_e);
     ctl_lon(tab, M, c.dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
-    ctl_lat(tab, M, c.dT, v, (int)M.U(FB_CU_LAT_MODE_REQ));
+    const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
+    ctl_lat(tab, M, c.dT, v, lat_req, ctl_lat_gains(tab, v, lat_req));
 }
 
 // After k_trim has left the trimmed Sv0 state, u and s: actuator states = actuator commands = trim values (c172x.jl:253-271),
@@ -79,12 +80,12 @@ __global__ __launch_bounds__(256) void k_x2_init(KArgs a, CtlArgs c) {
     U(FB_CU_P_REF) = v.w_wb_b.x; U(FB_CU_PHI_REF) = v.phi; U(FB_CU_BETA_REF) = v.beta; U(FB_CU_CHI_REF) = v.chi;
     // one pass in every SAS-based mode loads the trim point into the LQR trackers; both channels end in `direct`
     const int lon_seq[4] = {FB_LON_SAS, FB_LON_THR_EAS, FB_LON_EAS_ALT, FB_LON_DIRECT};
-    const CtlTabT<const double*> tab = {c.gains, c.off};
+    const CtlTabT<const double*> tab = ctl_tab(c.gains, c.off, v.EAS, v.h_e);
 #pragma unroll 1
     for (int m = 0; m < 4; m++) ctl_lon(tab, M, c.dT, v, lon_seq[m]);
     const int lat_seq[3] = {FB_LAT_SAS, FB_LAT_PHI_BETA, FB_LAT_DIRECT};
 #pragma unroll 1
-    for (int m = 0; m < 3; m++) ctl_lat(tab, M, c.dT, v, lat_seq[m]);
+    for (int m = 0; m < 3; m++) ctl_lat(tab, M, c.dT, v, lat_seq[m], ctl_lat_gains(tab, v, lat_seq[m]));
     U(FB_CU_LON_MODE_REQ) = FB_LON_DIRECT; U(FB_CU_LAT_MODE_REQ) = FB_LAT_DIRECT;
     // guidance defaults: mode direct, no requests, target = Segment() (c172x_gdc.jl:85, 206-210, 281-283)
     U(FB_CU_GDC_MODE_REQ) = FB_GDC_DIRECT; U(FB_CU_SEG_HOR_REQ) = 0; U(FB_CU_SEG_VRT_REQ) = 0;

@@ -71,6 +71,7 @@ struct fb_handle_s {
     double* gains = nullptr;   // FB_TABLE_CTL_GAINS blob
     int64_t gains_off[10] = {0};
     int64_t gains_total = 0;
+    bool gains_same_grid = false;   // all ten lookups on one (EAS, h) grid: CtlOffsets::same_grid
     bool have_gains = false;
     int64_t steps_done = 0;    // steps since the last init (phase of the periodic update)
     struct LogState* log = nullptr;  // on-device TimeSeries log (fb_log_*)
@@ -89,6 +90,7 @@ static KArgs make_args(fb_handle h) {
     a.gains = h->gains; a.ctl_bak = h->ctl_bak; a.duo_pld = h->duo_pld;
     for (int k = 0; k < 10; k++) a.ctl_off.off[k] = (int)h->gains_off[k];
     a.ctl_off.total = (int)h->gains_total;
+    a.ctl_off.same_grid = h->gains_same_grid ? 1 : 0;
     const int ratio = h->params.periodic_n > 0 ? h->params.periodic_n : 1;
     a.ctl_dT = h->params.dt * ratio;
     a.ctl_ratio = h->model == FB_MODEL_C172X2 ? ratio : 0;
@@ -169,6 +171,7 @@ static CtlArgs ctl_args(fb_handle h, int use_q_pre) {
     c.gains = h->gains;
     for (int k = 0; k < 10; k++) c.off.off[k] = (int)h->gains_off[k];
     c.off.total = (int)h->gains_total;
+    c.off.same_grid = h->gains_same_grid ? 1 : 0;
     c.dT = h->params.dt * (h->params.periodic_n > 0 ? h->params.periodic_n : 1);
     c.use_q_pre = use_q_pre;
     return c;
@@ -354,6 +357,10 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
         if (off != count) return fail("control-law gains blob: %lld doubles given, layout needs %lld", (long long)count, (long long)off);
         if (count > CTL_GAINS_MAX) return fail("control-law gains blob: %lld doubles exceed the %d the periodic kernel stages in LDS", (long long)count, (int)CTL_GAINS_MAX);
         h->gains_total = count;
+        h->gains_same_grid = true;
+        for (int k = 1; k < 10; k++)
+            if (std::memcmp(b + h->gains_off[k], b + h->gains_off[0], sizeof(double) * FB_CTL_GRID_HDR) != 0) h->gains_same_grid = false;
+        if (const char* e = getenv("FLIGHTBATCH_CTL_SAME_GRID")) if (e[0] == '0') h->gains_same_grid = false;   // diagnostic: force the per-lookup headers
         if (h->gains) { (void)hipFree(h->gains); h->gains = nullptr; }
         HIPCHK(hipMalloc(&h->gains, sizeof(double) * count));
         HIPCHK(hipMemcpy(h->gains, data, sizeof(double) * count, hipMemcpyHostToDevice));

@@ -62,9 +62,13 @@ def test_x2_init_matches_oracle(fb, oracle, gains):
     w.close()
 
 
-def test_x2_closed_loop_trajectory_matches_oracle(fb, oracle, gains):
+@pytest.mark.parametrize("same_grid", ["1", "0"])
+def test_x2_closed_loop_trajectory_matches_oracle(fb, oracle, gains, same_grid, monkeypatch):
     """README example 2 configuration (dt = 0.01, Δt = 0.02): every aircraft in its own pair of control modes with its own
-    references, 10 s; state, control-law record and status against the oracle at the north-star tolerance."""
+    references, 10 s; state, control-law record and status against the oracle at the north-star tolerance. Both forms of the
+    gain lookup inside the stepping kernel: the cell located once per update (the ten lookups of the reference's data share one
+    grid: CtlOffsets::same_grid) and once per lookup from its own header (FLIGHTBATCH_CTL_SAME_GRID=0, read when the blob is set)."""
+    monkeypatch.setenv("FLIGHTBATCH_CTL_SAME_GRID", same_grid)
     K = fb.K
     n = 2048
     w, sim, X, env, o = make_pair(fb, oracle, gains, n, seed=22)
@@ -218,15 +222,47 @@ def test_x2_segment_guidance_matches_oracle(fb, oracle, gains):
     w.close()
 
 
-def test_x2_control_laws_fuzz(fb, oracle, gains):
+def refine_lookup(blob, offsets, recs, k, along_EAS=True):
+    """The blob with lookup k resampled on a finer grid (midpoints inserted along h, and along EAS too if asked): the same
+    piecewise-bilinear function on a DIFFERENT grid from the other lookups."""
+    o = offsets[k]; nE, nH = int(blob[o]), int(blob[o + 1]); rec = recs[k]
+    body = blob[o + 6:o + 6 + nE * nH * rec].reshape(nH, nE, rec)
+    if along_EAS:
+        wide = np.zeros((nH, 2 * nE - 1, rec))
+        wide[:, ::2] = body; wide[:, 1::2] = 0.5 * (body[:, :-1] + body[:, 1:])
+        body = wide
+    fine = np.zeros((2 * nH - 1, body.shape[1], rec))
+    fine[::2] = body; fine[1::2] = 0.5 * (body[:-1] + body[1:])
+    hdr = blob[o:o + 6].copy(); hdr[0] = fine.shape[1]; hdr[1] = fine.shape[0]
+    return np.concatenate([blob[:o], hdr, fine.reshape(-1), blob[o + 6 + nE * nH * rec:]])
+
+
+@pytest.mark.parametrize("variant", ["same_grid", "per_lookup_headers", "one_lookup_refined"])
+def test_x2_control_laws_fuzz(fb, oracle, gains, variant, monkeypatch):
     """f_periodic!(Unconditional(), world) — guidance + control laws — from 16 384 random controller records: every pair of
     previous / requested modes (so every bumpless-transfer branch), arbitrary compensator states and saturation flags, references
-    all over the place, gain lookups inside, on the edge of and outside the (EAS, h) grid; record and inputs against the oracle."""
+    all over the place, gain lookups inside, on the edge of and outside the (EAS, h) grid; record and inputs against the oracle.
+    Variants: the shared-cell lookup (the reference's ten lookups sit on one grid), the per-lookup headers forced on the same blob,
+    and a blob whose q2e and v2t lookups are resampled on finer grids (the library must notice that the grids differ; the oracle
+    runs on the original blob: the functions are the same. The blob must still fit the 6144 doubles fb_f_periodic stages in LDS)."""
     K = fb.K
     n = 16384
+    gains_gpu = gains
+    if variant == "per_lookup_headers": monkeypatch.setenv("FLIGHTBATCH_CTL_SAME_GRID", "0")
+    if variant == "one_lookup_refined":
+        recs = [K["FB_CTL_LQR8_REC"], K["FB_CTL_LQR8_REC"], K["FB_CTL_LQR9_REC"]] + [K["FB_CTL_PID_REC"]] * 3 + [K["FB_CTL_LQR8_REC"]] * 2 + [K["FB_CTL_PID_REC"]] * 2
+        def offsets_of(b):
+            offs, o = [], 0
+            for r in recs:
+                offs.append(o); o += 6 + int(b[o]) * int(b[o + 1]) * r
+            assert o == b.size
+            return offs
+        gains_gpu = refine_lookup(gains, offsets_of(gains), recs, 3)
+        gains_gpu = refine_lookup(gains_gpu, offsets_of(gains_gpu), recs, 5, along_EAS=False)
+        assert gains_gpu.size <= 6144
     rng = np.random.default_rng(99)
     tp = fb.TrimParameters(EAS=rng.uniform(36, 56, n), h_e=rng.uniform(100, 3300, n), ψ_nb=rng.uniform(-3, 3, n))
-    w = fb.Cessna172Xv2World(n, gains=gains)
+    w = fb.Cessna172Xv2World(n, gains=gains_gpu)
     sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False)
     fb.init(sim, tp)
     x = w.x
