@@ -206,19 +206,24 @@ FBD int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 FBD int64_t uni(int64_t v) { return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)(uint64_t)v)); }
 FBD double uni(double v) { return __builtin_bit_cast(double, uni(__builtin_bit_cast(int64_t, v))); }
 template <class P> FBD P* uni(P* p) { return (P*)(uintptr_t)uni((int64_t)(uintptr_t)p); }
-struct CtlCall {   // the kernel arguments x2_periodic reads (a COPY: handing the callee the kernel's own KArgs by reference moved the
-    const double* cu; double* cs; const double* gains; int64_t n; double ctl_dT; CtlOffsets ctl_off;   // kernel arguments to scratch for the whole kernel, +25 % on every step)
-};
-__device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const CtlIn& v) {
+// The kernel arguments it reads travel as SCALAR arguments, i.e. in registers (COPIES: handing the callee the kernel's own KArgs by
+// reference moved the kernel arguments to scratch for the whole kernel, +25 % on every step; and a struct argument, whatever its
+// size, goes through private memory: the callee then starts with an exposed round trip). The ten lookup offsets are packed two
+// to a word (the blob is at most CTL_GAINS_MAX = 6144 doubles), `tsg` = total | same_grid << 16.
+// Returns the four commands it leaves in cs — in registers: re-reading the rows just written waits for the stores to land first.
+struct CtlOut { double cmd[4]; };   // throttle, aileron, elevator, rudder, as x2_command() would read them back
+__device__ __noinline__ CtlOut x2_periodic(const double* a_cu, double* a_cs, const double* a_gains, int64_t a_n, double a_dT, uint32_t o01, uint32_t o23,
+                                           uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, const CtlIn& v) {
     FB_X2_STAMP(21);
-    const double* cu = uni(c_in.cu); double* cs = uni(c_in.cs); const double* gains = uni(c_in.gains);
-    const int64_t n = uni(c_in.n);
-    const double dT = uni(c_in.ctl_dT);
+    const double* cu = uni(a_cu); double* cs = uni(a_cs); const double* gains = uni(a_gains);
+    const int64_t n = uni(a_n);
+    const double dT = uni(a_dT);
+    const uint32_t op[5] = {o01, o23, o45, o67, o89};
     CtlOffsets off;
 #pragma unroll
-    for (int k = 0; k < 10; k++) off.off[k] = uni(c_in.ctl_off.off[k]);
-    off.total = uni(c_in.ctl_off.total);
-    off.same_grid = uni(c_in.ctl_off.same_grid);
+    for (int k = 0; k < 10; k++) off.off[k] = uni((int)((op[k / 2] >> (16 * (k % 2))) & 0xffffu));
+    off.total = uni((int)(tsg & 0xffffu));
+    off.same_grid = uni((int)(tsg >> 16));
     // cs / cu rows are read and written where the laws use them, through global pointers with wave-uniform bases (only the rows of
     // the active modes move; prefetching the whole 94-row record into registers and writing back what changed was measured 2x
     // slower: the copy spills). The gains come by per-lane gather from the L2-resident blob, one table's corner records per burst
@@ -239,17 +244,14 @@ __device__ __noinline__ void x2_periodic(const CtlCall& c_in, int64_t i, const C
     gdc_update(M, v);
     FB_X2_STAMP(23);
     const CtlTabT<gcptr> tab = ctl_tab((gcptr)(uintptr_t)gains, off, v.EAS, v.h_e);
-    const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
-#ifdef FB_X2_LAT_EARLY
-    const LatGains LG = ctl_lat_gains(tab, v, lat_req);   // in flight while the longitudinal channel runs
-#endif
     ctl_lon(tab, M, dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
     FB_X2_STAMP(24);
-#ifndef FB_X2_LAT_EARLY
-    const LatGains LG = ctl_lat_gains(tab, v, lat_req);
-#endif
-    ctl_lat(tab, M, dT, v, lat_req, LG);
+    // (fetching the lateral gains ahead of the longitudinal channel, to hide their gather behind its dependent chains, holds 40 more
+    // values across it: 460 registers in this function, and the calling kernel's allocation pays — 14.2 -> 15.0 ms per launch)
+    const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
+    ctl_lat(tab, M, dT, v, lat_req, ctl_lat_gains(tab, v, lat_req));
     FB_X2_STAMP(25);
+    return {{clampd(M.S(FB_CS_THROTTLE_CMD), 0, 1), clampd(M.S(FB_CS_AILERON_CMD), -1, 1), clampd(M.S(FB_CS_ELEVATOR_CMD), -1, 1), clampd(M.S(FB_CS_RUDDER_CMD), -1, 1)}};
 }
 
 // f_ode!(world): xdot (optional) and the output record y
@@ -590,11 +592,13 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
 #pragma unroll
                         for (int k = 0; k < 4; k++) { v.pos[k] = clampd(xa[k], k == FB_ACT_THROTTLE ? 0.0 : -1.0, 1.0); v.cmd[k] = ca[k]; }   // (InputsX::pos)
                         v.on_gnd = GROUND && aux.wow != 0;   // is_on_gnd: any strut with weight on wheels (c172.jl:998-1001)
-                        const CtlCall cc = {a.cu, a.cs, a.gains, a.n, a.ctl_dT, a.ctl_off};
-                        x2_periodic(cc, i, v);
+                        auto pk = [&](int k) { return (uint32_t)a.ctl_off.off[k] | ((uint32_t)a.ctl_off.off[k + 1] << 16); };
+                        const CtlOut co = x2_periodic(a.cu, a.cs, a.gains, a.n, a.ctl_dT, pk(0), pk(2), pk(4), pk(6), pk(8),
+                                                      (uint32_t)a.ctl_off.total | ((uint32_t)a.ctl_off.same_grid << 16), i, v);
                         FB_X2_STAMP(26);
+                        static_assert(FB_ACT_THROTTLE == 0 && FB_ACT_AILERON == 1 && FB_ACT_ELEVATOR == 2 && FB_ACT_RUDDER == 3, "CtlOut order");
 #pragma unroll
-                        for (int k = 0; k < NAL; k++) ca[k] = x2_command(a, i, k);   // the commands in force from the next stage on
+                        for (int k = 0; k < 4; k++) ca[k] = co.cmd[k];   // the commands in force from the next stage on (flaps and brakes are inputs: unchanged)
                     }
                 }
                 auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none

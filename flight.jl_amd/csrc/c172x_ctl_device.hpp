@@ -361,7 +361,6 @@ FBD void gdc_update(const MEM& M, const CtlIn& v) {
 
 // ---- lateral channel -----------------------------------------------------------------------------------------------
 // the gains the lateral mode may need — one eight-state LQR record and one PID record, chosen per lane — fetched in one block
-// (and, by x2_periodic, AHEAD of the longitudinal channel, whose dependent chains then hide the gathers)
 struct LatGains { double g8[FB_CTL_LQR8_REC]; PidGains P; };
 template <class TAB>
 FBD LatGains ctl_lat_gains(const TAB& T, const CtlIn& v, int mode_req) {
