@@ -70,7 +70,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double i_a_snd = (1 / sqrt_gR) * rs_T;
         emit.xput(XD_RHO, rho); emit.xput(XD_HO, h_o);
         if (st != 0) emit.xstatus(st);
-        emit.xsync();   // ----- barrier A -----
+        emit.xsync(1);   // ----- barrier A -----
 
         // ----- propeller (propellers.jl:405-452) -----
         const double w_prop = w_eng;  // gear ratio 1
@@ -120,7 +120,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
         const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
         const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
-        emit.xsync();   // ----- barrier B (role D has finished its aerodynamics by about now) -----
+        emit.xsync(2);   // ----- barrier B (role D has finished its aerodynamics by about now) -----
         const double k_f = rsqrt(rho * (1 / isa::rho_std));
         const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
         const double f_run = mix_auto ? f_lean + mixture * (f_rich - f_lean) : k_f * (f_rich * (0.5 * (mixture + 1)));
@@ -203,7 +203,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double cy_p = lerp2(A + AT_CY_P_V, 2, l_al2, l_df2), cy_r = lerp2(A + AT_CY_R_V, 2, l_al2, l_df2);
         const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
         const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
-        emit.xsync();   // ----- barrier A -----
+        emit.xsync(1);   // ----- barrier A -----
         const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         const double q_dyn = 0.5 * rho * (TAS * TAS);
@@ -265,7 +265,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         aux.wow = 0;
         aux.crash = 0;
         if (!(h_o - env.h_trn > 10.0)) st |= FB_ST_INTERNAL_REDO;
-        emit.xsync();   // ----- barrier B -----
+        emit.xsync(2);   // ----- barrier B -----
         const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
         const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
         const v3 h_rot = {emit.xget(XD_HROT), 0.0, 0.0};

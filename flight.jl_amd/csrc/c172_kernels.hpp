@@ -744,6 +744,24 @@ struct InputsDuoD {
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
 };
+// A workgroup barrier of the wave-specialised stepper. Diagnostic builds (-DFB_STAMP -DFB_DUO_WAITPROF, tools/duo_waitprof.py): wave 0
+// (role P) and wave 4 (role D) of workgroup 0 add the cycles they spend INSIDE barrier `slot` (0 top, 1 A, 2 B, 3 ahead of f_step!) to
+// g_stamp_acc[slot] / [8 + slot]: how long each role waits for the other.
+FBD void duo_barrier(int slot) {
+#if defined(FB_STAMP) && defined(FB_DUO_WAITPROF)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == DUO_B)) {
+        const int k = slot + (threadIdx.x ? 8 : 0);
+        g_stamp_acc[k] += t1 - t0; g_stamp_cnt[k] += 1;
+    }
+#else
+    (void)slot;
+    __syncthreads();
+#endif
+}
+
 template <int ROLE>
 struct DuoEmit {
     static constexpr int role = ROLE;
@@ -798,7 +816,7 @@ struct DuoEmit {
     }
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
-    __device__ __forceinline__ void xsync() const { __syncthreads(); }
+    __device__ __forceinline__ void xsync(int slot) const { duo_barrier(slot); }
     __device__ __forceinline__ void xstatus(int32_t st) const { *dst_p |= (st & 3) << DUO_D_PST_SHIFT; }   // (FB_ST_ALT_RANGE | FB_ST_ISA_RANGE)
 };
 // every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
@@ -876,7 +894,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
 #pragma unroll 1
         while (true) {
-            __syncthreads();   // the previous evaluation's emits, and D's flag / control words, are visible
+            duo_barrier(0);   // the previous evaluation's emits, and D's flag / control words, are visible
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
             if (c & DUO_C_EXIT) break;
@@ -901,8 +919,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     const SV xv = {sk.xrd_l + t + lds_off};
                     rhs_duo<1>(xv, 0, eng, inl, a.env, T, emit, aux);
                 }
-            } else { __syncthreads(); __syncthreads(); }   // (barriers A and B of an evaluation nobody runs)
-            if (c & DUO_C_CB) __syncthreads();
+            } else { duo_barrier(1); duo_barrier(2); }   // (barriers A and B of an evaluation nobody runs)
+            if (c & DUO_C_CB) duo_barrier(3);
         }
         return;
     }
@@ -950,7 +968,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
 #pragma unroll 1
     while (true) {
-        __syncthreads();
+        duo_barrier(0);
         if (exit_) break;
         const bool cb = stage == 0 && pending_cb && !redoing;
         const StageK sk = stage_k(stage);
@@ -970,8 +988,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 const SV xv = {sk.xrd_l + t + lds_off};
                 bits = rhs_duo<2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
             }
-        } else { __syncthreads(); __syncthreads(); }
-        if (cb) __syncthreads();   // role P has read x_{n+1} for the last time: f_step! may modify it
+        } else { duo_barrier(1); duo_barrier(2); }
+        if (cb) duo_barrier(3);   // role P has read x_{n+1} for the last time: f_step! may modify it
         int d = dst_l[t];
         if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
         if (run && (bits & FB_ST_INTERNAL_REDO)) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }   // nothing is committed for this lane
