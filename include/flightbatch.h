@@ -155,7 +155,8 @@ enum {
  * ar2ar,φβ2ar,p2φ,χ2φ}.h5, loaded by c172x_ctl.jl:208-213,816-819]. Each lookup = 6 doubles (n_EAS, n_h, EAS_lo, EAS_hi,
  * h_lo, h_hi: the `bounds` dataset and the grid size) followed by n_EAS*n_h records, EAS index fastest. LQR record:
  * K_fbk [2 x NX] column-major, K_fwd [2 x 2], K_int [2 x 2], x_trim [NX], u_trim [2], z_trim [2]; PID record: k_p k_i k_d tau_f.
- * Interpolation: linear in (EAS, h_e), Flat extrapolation (FP/control.jl:950-966). */
+ * Interpolation: linear in (EAS, h_e), Flat extrapolation (FP/control.jl:950-966). The lookups may sit on different grids;
+ * when all ten headers are equal (the reference's data files) the library locates the grid cell once per control update. */
 enum { FB_CTL_GRID_HDR = 6, FB_CTL_LQR8_REC = 36, FB_CTL_LQR9_REC = 39, FB_CTL_PID_REC = 4 };
 
 /* ---- Robot2D (FB_MODEL_ROBOT2D; FA/robot2d/robot2d.jl) ------------------------------------------------
