@@ -22,7 +22,7 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
 }
 
 constexpr int CTL_GAINS_MAX = 6144;   // doubles of LDS reserved for the gains blob (the shipped lookups need 5744)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_x2_ctl(KArgs a, CtlArgs c) {
+__global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
     // The partial sink needs none of the aero / engine / propeller tables (everything that reads them is dead code here), so
     // they are not staged; the pointers below are never dereferenced.
     __shared__ double gains_l[CTL_GAINS_MAX];
