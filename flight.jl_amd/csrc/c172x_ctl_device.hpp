@@ -5,9 +5,10 @@
 // FlightPhysics/src/control.jl:161-183 (Integrator), :431-471 (PID), :708-743 (LQR), :950-994 (gain lookups: linear in
 // (EAS, h_e), Flat extrapolation); c172x2.jl:27-50 (Avionics: guidance in `direct` mode is a no-op).
 // Per-aircraft data lives in global memory, structure-of-arrays: inputs cu [FB_NCU x n], record cs [FB_NCS x n]
-// (include/flightbatch.h). The update runs ~1-2 k flops once per Δt, against ~12 k flops per RK4 step: it is kept in its
-// own small kernel (k_x2_ctl) so that the stepping kernel's register budget is untouched; lanes of one wave may sit in
-// different modes — the branches below are the price, paid once per Δt.
+// (include/flightbatch.h). The update runs ~2 k instructions once per Δt, against ~9 k per RK4 step. Two callers: x2_periodic
+// (c172_kernels.hpp), out of line inside the stepping kernels so that their register allocation is untouched, with the record
+// cached in registers; and k_x2_ctl (c172x_kernels.hpp), the fb_f_periodic verb as a kernel of its own. Lanes of one wave may sit
+// in different modes — the branches below are the price, paid once per Δt.
 #pragma once
 #include "c172_device.hpp"
 
@@ -91,8 +92,8 @@ typedef CtlMemT<double*> CtlMem;
 // were four of them in a row (guidance inputs, longitudinal inputs, lateral inputs, compensator states): 15.32 -> 15.17 ms per launch
 // of 25 updates — a modest gain, because the burst reads all 94 rows where the laws touched ~60 (writing everything back in one burst
 // at the end as well costs another 1.0 ms: HBM bandwidth). Reads come from the cache, writes go to both (write-through). The
-// per-phase cycle profile of one update (tools/stamp_x2.py, -DFB_STAMP build): record burst 2.9 k, guidance 1.3 k, longitudinal
-// channel 24 k (outer loops 8 k, LQR lookup 4 k, LQR run and stores 10 k), lateral 10 k, call and return 6 k cycles.
+// per-phase cycle profile of one update (tools/stamp_x2.py, -DFB_STAMP build; profiles/r02_x2_update_stamps.txt): record burst
+// 2.3 k, guidance 1.2 k, longitudinal channel 20 k, lateral 7.6 k, call and return 5.4 k cycles.
 // Every index the laws pass is a compile-time constant after inlining, so the cache is 94 register pairs, not an array in scratch.
 template <class P>
 struct CtlMemCachedT {
