@@ -68,6 +68,7 @@ def _load():
         "fb_log_read": ([H, I64, I64, D, D], C.c_int32),
         "fb_comm_unique_id": ([C.c_char_p], C.c_int32),
         "fb_comm_init": ([H, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(VP)], C.c_int32),
+        "fb_comm_shard_sizes": ([VP, C.POINTER(I64), C.POINTER(I64)], C.c_int32),
         "fb_gather_state": ([H, VP, VP], C.c_int32),
         "fb_comm_destroy": ([VP], C.c_int32),
         "fb_timing_begin": ([H], C.c_int32),

@@ -23,8 +23,12 @@ module FlightBatch
 
 using Flight.FlightCore.Modeling: ModelDefinition
 import Flight.FlightCore.Modeling: f_init!, f_ode!, f_step!, f_periodic!
+using Flight: FlightPhysics
 using Flight.FlightApps: C172
-using Flight.FlightPhysics: Propellers, Piston, Geodesy, Control
+using Flight.FlightPhysics: Propellers, Piston, Control
+using Flight.FlightPhysics.Kinematics: WA, ECEF, NED                   # kinematic descriptors (exported at FP/kinematics.jl:11)
+using Flight.FlightApps.C172.C172S.C172Sv0: Cessna172Sv0               # FA/c172/c172s/c172s0.jl:9,14-18
+using Flight.FlightApps.C172.C172X.C172Xv2: Cessna172Xv2               # FA/c172/c172x/c172x2.jl:12,54-59
 
 const lib = get(ENV, "FLIGHTBATCH_LIB", "libflightbatch")
 
@@ -108,7 +112,9 @@ end
 function upload_tables!(w::BatchedWorld)
     # EGM96: the Float32 721 x 1441 grid behind Geodesy.egm96_interp (geodesy.jl:186-198)
     egm = Matrix{Float32}(undef, 721, 1441)
-    read!(joinpath(dirname(pathof(Geodesy.eval(:(@__MODULE__)))), "data", "ww15mgh_le.bin"), egm)
+    # the file Geodesy itself reads: joinpath(dirname(@__FILE__), "data", "ww15mgh_le.bin") in FP/geodesy.jl:166, i.e. next to the
+    # package's entry file (pathof works on the package module FlightPhysics, not on its submodule Geodesy)
+    read!(joinpath(dirname(pathof(FlightPhysics)), "data", "ww15mgh_le.bin"), egm)
     set_table!(w, TABLE_EGM96, egm)
     # propeller: Lookup(2, Blade()).data, six 21 x 21 x 1 arrays (propellers.jl:235-250) -> [21, 21, 6]
     lookup = Propellers.Lookup(2, Propellers.Blade())
@@ -128,7 +134,7 @@ end
 #   extrapolate(scale(interpolate(A, BSpline(Linear())), ranges...), Line()): .itp.ranges, .itp.itp.coefs (see scaled_coefs above)
 gridded_knots(e) = e.itp.knots
 gridded_coefs(e) = e.itp.coefs
-put!(b::Vector{Float64}, off0::Integer, a) = (v = vec(collect(Float64, a)); b[off0 + 1 : off0 + length(v)] .= v; b)
+put_at!(b::Vector{Float64}, off0::Integer, a) = (v = vec(collect(Float64, a)); b[off0 + 1 : off0 + length(v)] .= v; b)
 
 # csrc/tables.h PT_* offsets
 const PT_DELTA_WOT_V, PT_MU_WOT_V, PT_PISTD_N_K, PT_PISTD_MU_K, PT_PISTD_V, PT_PIWOT_N_K, PT_PIWOT_D_K, PT_PIWOT_V = 0, 18, 36, 49, 52, 91, 96, 99
@@ -139,16 +145,16 @@ function pack_piston(l)::Vector{Float64}
     # δ_wot(n, μ), μ_wot(n, δ): scaled B-splines on fixed ranges the kernels know (piston.jl:78-79, 92-93); only the 2 x 9 samples travel
     @assert scaled_ranges(l.δ_wot) == (range(0.667, 1, length = 2), range(0.401, 0.936, length = 9))
     @assert scaled_ranges(l.μ_wot) == (range(0.667, 1, length = 2), range(0.441, 1, length = 9))
-    put!(b, PT_DELTA_WOT_V, scaled_coefs(l.δ_wot)); put!(b, PT_MU_WOT_V, scaled_coefs(l.μ_wot))
+    put_at!(b, PT_DELTA_WOT_V, scaled_coefs(l.δ_wot)); put_at!(b, PT_MU_WOT_V, scaled_coefs(l.μ_wot))
     n13, μ3 = gridded_knots(l.π_std)                       # π_std(n, μ): 13 x 3, Flat (piston.jl:110-133)
-    put!(b, PT_PISTD_N_K, n13); put!(b, PT_PISTD_MU_K, μ3); put!(b, PT_PISTD_V, gridded_coefs(l.π_std))
+    put_at!(b, PT_PISTD_N_K, n13); put_at!(b, PT_PISTD_MU_K, μ3); put_at!(b, PT_PISTD_V, gridded_coefs(l.π_std))
     n5, δ3 = gridded_knots(l.π_wot)                        # π_wot(n, δ): 5 x 3 (piston.jl:140-149)
-    put!(b, PT_PIWOT_N_K, n5); put!(b, PT_PIWOT_D_K, δ3); put!(b, PT_PIWOT_V, gridded_coefs(l.π_wot))
+    put_at!(b, PT_PIWOT_N_K, n5); put_at!(b, PT_PIWOT_D_K, δ3); put_at!(b, PT_PIWOT_V, gridded_coefs(l.π_wot))
     (f11,) = gridded_knots(l.π_ratio)                      # π_ratio(f), sfc_ratio(f): 11 knots shared (piston.jl:157-172)
     @assert gridded_knots(l.sfc_ratio)[1] == f11
-    put!(b, PT_F_K, f11); put!(b, PT_PI_RATIO_V, gridded_coefs(l.π_ratio)); put!(b, PT_SFC_RATIO_V, gridded_coefs(l.sfc_ratio))
+    put_at!(b, PT_F_K, f11); put_at!(b, PT_PI_RATIO_V, gridded_coefs(l.π_ratio)); put_at!(b, PT_SFC_RATIO_V, gridded_coefs(l.sfc_ratio))
     nsfc, πsfc = gridded_knots(l.sfc_pow)                  # sfc_pow(n, π): 5 x 8, Line (piston.jl:179-189)
-    put!(b, PT_SFC_N_K, nsfc); put!(b, PT_SFC_PI_K, πsfc); put!(b, PT_SFC_POW_V, gridded_coefs(l.sfc_pow))
+    put_at!(b, PT_SFC_N_K, nsfc); put_at!(b, PT_SFC_PI_K, πsfc); put_at!(b, PT_SFC_POW_V, gridded_coefs(l.sfc_pow))
     return b
 end
 
@@ -162,17 +168,17 @@ function pack_aero(l)::Vector{Float64}
     b = zeros(AT_SIZE)
     k1(e) = gridded_knots(e)[1]
     @assert k1(C_D.ge) == k1(C_L.ge)                        # ground-effect tables share their 13 knots (c172.jl:67, 117)
-    put!(b, AT_GE_K, k1(C_D.ge)); put!(b, AT_CD_GE_V, gridded_coefs(C_D.ge)); put!(b, AT_CL_GE_V, gridded_coefs(C_L.ge))
+    put_at!(b, AT_GE_K, k1(C_D.ge)); put_at!(b, AT_CD_GE_V, gridded_coefs(C_D.ge)); put_at!(b, AT_CL_GE_V, gridded_coefs(C_L.ge))
     @assert k1(C_D.δf) == k1(C_L.δf) == k1(C_m.δf) == gridded_knots(C_D.α_δf)[2]
-    put!(b, AT_DF4_K, k1(C_D.δf)); put!(b, AT_CD_DF_V, gridded_coefs(C_D.δf)); put!(b, AT_CL_DF_V, gridded_coefs(C_L.δf)); put!(b, AT_CM_DF_V, gridded_coefs(C_m.δf))
+    put_at!(b, AT_DF4_K, k1(C_D.δf)); put_at!(b, AT_CD_DF_V, gridded_coefs(C_D.δf)); put_at!(b, AT_CL_DF_V, gridded_coefs(C_L.δf)); put_at!(b, AT_CM_DF_V, gridded_coefs(C_m.δf))
     @assert k1(C_D.δe) == k1(C_D.β)
-    put!(b, AT_UNIT3_K, k1(C_D.δe)); put!(b, AT_CD_DE_V, gridded_coefs(C_D.δe)); put!(b, AT_CD_BETA_V, gridded_coefs(C_D.β))
-    put!(b, AT_CD_ALPHA_K, gridded_knots(C_D.α_δf)[1]); put!(b, AT_CD_ALPHA_DF_V, gridded_coefs(C_D.α_δf))       # 26 x 4
-    put!(b, AT_CY_BETA_K, gridded_knots(C_Y.β_δf)[1]); put!(b, AT_DF2_K, gridded_knots(C_Y.β_δf)[2]); put!(b, AT_CY_BETA_DF_V, gridded_coefs(C_Y.β_δf))   # 3 x 2
+    put_at!(b, AT_UNIT3_K, k1(C_D.δe)); put_at!(b, AT_CD_DE_V, gridded_coefs(C_D.δe)); put_at!(b, AT_CD_BETA_V, gridded_coefs(C_D.β))
+    put_at!(b, AT_CD_ALPHA_K, gridded_knots(C_D.α_δf)[1]); put_at!(b, AT_CD_ALPHA_DF_V, gridded_coefs(C_D.α_δf))       # 26 x 4
+    put_at!(b, AT_CY_BETA_K, gridded_knots(C_Y.β_δf)[1]); put_at!(b, AT_DF2_K, gridded_knots(C_Y.β_δf)[2]); put_at!(b, AT_CY_BETA_DF_V, gridded_coefs(C_Y.β_δf))   # 3 x 2
     @assert gridded_knots(C_Y.p) == gridded_knots(C_Y.r) == gridded_knots(C_l.r) && gridded_knots(C_Y.p)[2] == gridded_knots(C_Y.β_δf)[2]
-    put!(b, AT_ALPHA2_K, gridded_knots(C_Y.p)[1]); put!(b, AT_CY_P_V, gridded_coefs(C_Y.p)); put!(b, AT_CY_R_V, gridded_coefs(C_Y.r)); put!(b, AT_CL_R_V, gridded_coefs(C_l.r))
-    put!(b, AT_CL_ALPHA_K, gridded_knots(C_L.α)[1]); put!(b, AT_CL_ALPHA_V, gridded_coefs(C_L.α))                 # 17 x 2 (stall 0 / 1)
-    put!(b, AT_SCALARS, Float64[C_D.z, C_Y.δr, C_Y.δa, C_L.δe, C_L.q, C_L.α_dot, C_l.δa, C_l.δr, C_l.β, C_l.p,          # AS_* order of csrc/tables.h
+    put_at!(b, AT_ALPHA2_K, gridded_knots(C_Y.p)[1]); put_at!(b, AT_CY_P_V, gridded_coefs(C_Y.p)); put_at!(b, AT_CY_R_V, gridded_coefs(C_Y.r)); put_at!(b, AT_CL_R_V, gridded_coefs(C_l.r))
+    put_at!(b, AT_CL_ALPHA_K, gridded_knots(C_L.α)[1]); put_at!(b, AT_CL_ALPHA_V, gridded_coefs(C_L.α))                 # 17 x 2 (stall 0 / 1)
+    put_at!(b, AT_SCALARS, Float64[C_D.z, C_Y.δr, C_Y.δa, C_L.δe, C_L.q, C_L.α_dot, C_l.δa, C_l.δr, C_l.β, C_l.p,          # AS_* order of csrc/tables.h
                                 C_m.z, C_m.δe, C_m.α, C_m.q, C_m.α_dot, C_n.δr, C_n.δa, C_n.β, C_n.p, C_n.r])
     return b
 end
@@ -198,7 +204,7 @@ function f_init!(w::BatchedWorld, trim::C172.TrimParameters)
     tp[:, 7] .= trim.γ_wb_n; tp[:, 8] .= trim.ψ_wb_dot; tp[:, 9] .= trim.θ_wb_dot; tp[:, 10] .= trim.β_a
     tp[:, 11] .= Float64(trim.fuel_load); tp[:, 12] .= Float64(trim.mixture); tp[:, 13] .= Float64(trim.flaps)
     p = trim.payload
-    tp[:, 14:18] .= Float64[p.m_pilot p.m_copilot p.m_lpass p.m_rpass p.m_baggage]
+    tp[:, 14:18] .= Float64[Float64(p.m_pilot) Float64(p.m_copilot) Float64(p.m_lpass) Float64(p.m_rpass) Float64(p.m_baggage)]
     ts = repeat(collect(C172.TrimState())', w.n)          # initial guess, c172.jl:796-804
     ok = Vector{Int32}(undef, w.n); cost = Vector{Float64}(undef, w.n)
     check(ccall((:fb_trim, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}), w.handle, tp, ts, ok, cost))
@@ -248,7 +254,13 @@ function comm_init(w::BatchedWorld, nranks::Integer, rank::Integer, id::Vector{U
     check(ccall((:fb_comm_init, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ptr{Ptr{Cvoid}}), w.handle, nranks, rank, id, comm))
     return comm[]
 end
-"all-gather of the device-layout state into `recv_dev` (device pointer to nranks x Nx x N doubles), asynchronous on the world's stream"
+"shard sizes of all ranks, exchanged by `comm_init`: `(n_of, n_max)`"
+function comm_shard_sizes(comm::Ptr{Cvoid}, nranks::Integer)
+    n_of = Vector{Int64}(undef, nranks); n_max = Ref{Int64}(0)
+    check(ccall((:fb_comm_shard_sizes, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), comm, n_of, n_max))
+    return n_of, n_max[]
+end
+"all-gather of the device-layout state into `recv_dev` (device pointer to nranks x Nx x n_max doubles; equal shards: n_max = N), asynchronous on the world's stream"
 gather_state!(w::BatchedWorld, comm::Ptr{Cvoid}, recv_dev::Ptr{Cvoid}) =
     check(ccall((:fb_gather_state, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), w.handle, comm, recv_dev))
 

@@ -298,11 +298,17 @@ int32_t fb_status(fb_handle h, int32_t* status);
 
 /* Trajectory collection across GPUs: one RCCL all-gather of the state panels over xGMI; no other
  * communication exists on this path. One process per GPU; rank 0 calls fb_comm_unique_id and the host distributes the 128
- * bytes out of band; every rank calls fb_comm_init (collective), then fb_gather_state enqueues, on the handle's stream,
- * an all-gather of its x (DEVICE layout, [N x FB_NX] or [N x FB_X2_NX] doubles, see fb_attach_state) into recv_dev
- * [world x Nx x N] (device memory, rank-major). RCCL is loaded on first use. */
+ * bytes out of band; every rank calls fb_comm_init (collective: it also exchanges the ranks' shard sizes, readable through
+ * fb_comm_shard_sizes), then fb_gather_state enqueues, on the handle's stream, an all-gather of its x (DEVICE layout,
+ * [N x FB_NX] or [N x FB_X2_NX] doubles, see fb_attach_state) into recv_dev (device memory, rank-major)
+ * [world x Nx x n_max], n_max = the largest shard. Equal shards (n_of[r] == N on every rank): exactly [world x Nx x N], gathered
+ * in place from x. Ragged shards: every rank's rows are padded to n_max through a staging copy; rank r's row k holds
+ * n_of[r] valid entries at recv_dev[(r * Nx + k) * n_max ...], the rest of the row is unspecified. The handle passed to
+ * fb_gather_state must be the one the communicator was initialised with (same N), otherwise the call fails. RCCL is loaded on
+ * first use. */
 int32_t fb_comm_unique_id(char* id128);
 int32_t fb_comm_init(fb_handle h, int32_t world, int32_t rank, const char* id128, void** comm);
+int32_t fb_comm_shard_sizes(void* comm, int64_t* n_of /* [world] or NULL */, int64_t* n_max /* or NULL */);
 int32_t fb_gather_state(fb_handle h, void* comm, double* recv_dev);
 int32_t fb_comm_destroy(void* comm);
 

@@ -568,7 +568,8 @@ def test_rccl_gather_state_single_rank(fb):
 def test_rccl_gather_state_two_ranks(fb):
     """fb_comm_init / fb_gather_state with world = 2: two child processes, one GPU each, the unique id handed over through a file.
     Needs two visible devices (the per-round GPU box has one: skipped there; the 8-GPU node runs it). Rank r trims its own shard
-    (flightbatch.sharding.shard_range of 8192 aircraft) and both must end up with the same gathered [2][27][n] panel."""
+    (flightbatch.sharding.shard_range of 8191 aircraft: RAGGED shards, 4096 + 4095) and both must end up with the same gathered
+    [2][27][n_max] panel, rank r's rows holding n_of[r] valid entries (fb_comm_shard_sizes)."""
     import os
     import subprocess
     import sys
@@ -583,7 +584,7 @@ def test_rccl_gather_state_two_ranks(fb):
         sys.path.insert(0, os.path.join(os.getcwd(), "flight.jl_amd"))
         import flightbatch as fb
         hip = C.CDLL("libamdhip64.so")
-        N = 8192
+        N = 8191
         lo, hi = fb.sharding.shard_range(N, rank, 2)
         n = hi - lo
         w = fb.BatchedWorld(n, device=rank)
@@ -602,13 +603,17 @@ def test_rccl_gather_state_two_ranks(fb):
             uid = C.create_string_buffer(open(idfile, "rb").read(), 128)
         comm = C.c_void_p()
         fb._lib.check(fb.lib.fb_comm_init(w._h, 2, rank, uid, C.byref(comm)))
+        n_of = (C.c_int64 * 2)(); n_max = C.c_int64()
+        fb._lib.check(fb.lib.fb_comm_shard_sizes(comm, n_of, C.byref(n_max)))
+        assert list(n_of) == [4096, 4095] and n_max.value == 4096 and n_of[rank] == n
         recv = C.c_void_p()
-        assert hip.hipSetDevice(rank) == 0 and hip.hipMalloc(C.byref(recv), C.c_size_t(2 * 27 * n * 8)) == 0
+        assert hip.hipSetDevice(rank) == 0 and hip.hipMalloc(C.byref(recv), C.c_size_t(2 * 27 * n_max.value * 8)) == 0
         fb._lib.check(fb.lib.fb_gather_state(w._h, comm, recv))
         w.sync()
-        out = np.zeros((2, 27, n))
+        out = np.zeros((2, 27, n_max.value))
         assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), recv, C.c_size_t(out.nbytes), 2) == 0
-        assert np.array_equal(out[rank], w.x), "own shard differs in the gathered panel"
+        assert np.array_equal(out[rank][:, :n], w.x), "own shard differs in the gathered panel"
+        out[1][:, n_of[1]:] = 0.0      # (the padding of the shorter shard is unspecified)
         np.save(outfile, out)
         fb._lib.check(fb.lib.fb_comm_destroy(comm))
         print("RANK_OK", rank)

@@ -37,9 +37,14 @@ def test_no_cpu_fallback(fb):
     if not torch.cuda.is_available():
         with pytest.raises(fb.FlightBatchError, match="requires a GPU|no HIP device"):
             fb.BatchedWorld(8)
-    # unsupported models / dtypes are refused, not silently substituted
-    assert fb.lib.fb_create(fb.K["FB_MODEL_ROBOT2D"], 0, 0, 8, 0, C.byref(h)) != 0
-    assert fb.lib.fb_create(0, 0, fb.K["FB_F32"], 8, 0, C.byref(h)) != 0
+    # unknown models / mechanisations / dtypes and unsupported combinations are refused before anything touches a device (so this
+    # holds with and without a GPU, and no handle is ever created here), not silently substituted
+    for args, msg in (((99, 0, fb.K["FB_F64"], 8, 0), b"unknown model id"), ((fb.K["FB_MODEL_C172S0"], 7, fb.K["FB_F64"], 8, 0), b"unknown kinematics id"),
+                      ((fb.K["FB_MODEL_C172S0"], 0, 5, 8, 0), b"unknown dtype"), ((fb.K["FB_MODEL_C172S0"], 0, fb.K["FB_F64"], 0, 0), b"n must be positive"),
+                      ((fb.K["FB_MODEL_C172X2"], 0, fb.K["FB_F32"], 8, 0), b"only FB_F64"),
+                      ((fb.K["FB_MODEL_C172S0"], fb.K["FB_KIN_NED"], fb.K["FB_F32"], 8, 0), b"only FB_KIN_WA")):
+        assert fb.lib.fb_create(*args, C.byref(h)) != 0 and msg in fb.lib.fb_last_error(), (args, fb.lib.fb_last_error())
+        assert not h.value
 
 
 def test_product_does_not_link_or_import_the_oracle(fb):
