@@ -41,7 +41,7 @@ BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flag
 BYTES_PER_X2_STEP = 756.0         # Cessna172Xv2
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r02_counters.json"   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r03_counters.json"   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
 
 
 def lattice(seed_offset: int = 0, n: int = N_TOTAL):
@@ -149,10 +149,15 @@ def parity_sample(fb, x0, u0, ui0, s0, cell, dtype, nsteps=1000):
     sim = fb.Simulation(w, dt=DT, save_on=False, steps_per_launch=50)
     fb.step(sim, nsteps * DT); w.sync()
     xo, so, sto = orc.step(xs, us, uis, ss, orc.default_env(), DT, nsteps, threads=min(orc.max_threads(), usable_cores()))
-    ok = (sto == 0) & (w.status == 0)
-    err = float(scaled_error(w.x, xo)[:, ok].max())
+    # every aircraft of the sample is compared, terminated ones included: the oracle stops an aircraft where the reference stops it
+    # (FC/sim.jl:561-570) and so must the GPU — same status word, same frozen state
+    st = w.status
+    same_status = bool(np.array_equal(st, sto)) if dtype == "f64" else bool(np.array_equal(st != 0, sto != 0))
+    ok = np.ones(m, bool) if dtype == "f64" else (sto == 0) & (st == 0)
+    err = float(scaled_error(w.x, xo)[:, ok].max()) if same_status else float("inf")
     w.close()
     return {"max_scaled_error": err, "against": "oracle/ (C++ port of the reference path; the Julia reference cannot run here)",
+            "status_words_equal": same_status, "terminated_in_sample": int((sto != 0).sum()),
             "sample": f"{int(ok.sum())} aircraft (4 per (EAS, h) cell over the whole batch) x {nsteps} RK4 steps, fp64 oracle",
             "cells_covered": int(np.unique(cell[sel]).size), "tolerance": 1e-6 if dtype == "f64" else None}
 
@@ -234,39 +239,79 @@ def check_valid(m, what):
             raise SystemExit(f"INVALID RUN ({what}): {key} = {m[key]} of {n} aircraft — refusing to report a throughput")
 
 
-def extra_x2(fb, C, args):
-    """BASELINE.json configs[3], one GPU's share: 524 288 Cessna172Xv2, autopilot every 2 steps, README example 2 scenario."""
+def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
+    """BASELINE.json configs[3], one GPU's share per rank: 524 288 Cessna172Xv2, autopilot every 2 steps, README example 2 scenario.
+    With `world` ranks this IS configs[3] at world = 8 (4 194 304 aircraft): same barrier + max-over-ranks timing as the headline, and
+    the final-state gather (one RCCL all-gather of the 34-row state panels) timed behind it."""
     n = N_TOTAL // 2
-    w = fb.Cessna172Xv2World(n)
+    w = fb.Cessna172Xv2World(n, device=local_rank)
+    x_dev = None
+    if world > 1:   # the state in a torch tensor, so that RCCL gathers it in place
+        x_dev = torch.zeros((fb.K["FB_X2_NX"], n), dtype=torch.float64, device="cuda")
+        s_dev = torch.zeros((fb.K["FB_NS"], n), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        fb._lib.check(fb.lib.fb_attach_state(w._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(s_dev.data_ptr())))
     w.set_params(wind_ned=(1.0, 0.5, 0.0))
     sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=args.x2_inner)
     fb.init(sim, fb.TrimParameters())
     assert w.trim_success.all()
     w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
     w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        w.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+
     block = 0.5
-    fb.step(sim, 2 * block); w.sync()
+    fb.step(sim, 2 * block)
+    barrier()
     fb.lib.fb_timing_begin(w._h)
     t0 = time.perf_counter()
     blocks = 6
     for _ in range(blocks):
         fb.step(sim, block)
-    w.sync()
+    barrier()
     el = time.perf_counter() - t0
     ms = C.c_float(); nl = C.c_int64()
     fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
     steps = int(round(block / DT)) * blocks
     bad = int((w.status != 0).sum())
+    n_total, gather_ms = n, None
+    if world > 1:
+        t = torch.tensor([el, float(bad)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        el = max(float(e[0].item()) for e in every); bad = int(sum(float(e[1].item()) for e in every))
+        n_total = n * world
+        torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
+        gathered = fb.sharding.all_gather_state(x_dev, n_total)
+        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - g0) * 1e3
+        assert gathered.shape == (fb.K["FB_X2_NX"], n_total)
+        del gathered
     w.close()
-    value = n * steps / el
+    value = n_total * steps / el
     gbs = BYTES_PER_X2_STEP * value / 1e9
-    out = {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64",
-           "config": {"workload": f"N={n} Cessna172Xv2 (one GPU's share of configs[3]: 4 194 304 over 8), default trim, README example 2 scenario "
+    out = {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64", "n_gpus": world,
+           "config": {"workload": (f"N={n_total} Cessna172Xv2 over {world} GPUs, {n} per GPU (BASELINE.json configs[3]" + (")" if world == 8 else f" at {world} of its 8 GPUs)")
+                                   if world > 1 else f"N={n} Cessna172Xv2 (one GPU's share of configs[3]: 4 194 304 over 8)") +
+                                  ", default trim, README example 2 scenario "
                                   "(wind, EAS + climb-rate and bank + sideslip modes), autopilot every 2 steps (Δt = 0.02), fp64, dt = 0.01",
                       "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
            "stepping_launches": int(nl.value), "kernel_ms": ms.value / max(nl.value, 1), "stream_ms_per_rk4_step": ms.value / steps,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                         "note": "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d)"}}
+    if gather_ms is not None:
+        out["gather_ms"] = gather_ms
+    return out
+
+
+def extra_x2(fb, C, args, timed=None):
+    """`extra.x2` of the bench line: the timing of time_x2 (measured here on one GPU, or handed in from the multi-rank run) and a
+    parity sample against the oracle."""
+    out = timed if timed is not None else time_x2(fb, None, None, C, args)
     # parity sample: 512 aircraft on randomised trims, every aircraft in its own pair of modes, 500 closed-loop steps vs the oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import OracleX
@@ -293,12 +338,12 @@ def extra_x2(fb, C, args):
     o["x"][perm] = ws.x; o["cs"] = ws.cs; o["u"] = ws.u; o["ui"] = ws.ui; o["s"] = ws.s
     fb.step(sims, 5.0); ws.sync()
     X.step(o, env, DT, 2, 500, threads=min(orc.max_threads(), usable_cores()))
-    ok = (ws.status == 0) & (o["status"] == 0)
+    same_status = bool(np.array_equal(ws.status, o["status"]))   # terminated aircraft are compared like the rest (frozen where the reference stops)
     xo = o["x"][perm]                                   # oracle rows (27 Sv0 rows, then the actuators) in the C ABI's reference order
     sc = np.ones_like(o["x"]); sc[:27] = state_floor(o["x"][:27])
-    err = (np.abs(ws.x - xo) / sc[perm])[:, ok]
-    out["rel_err_vs_cpu"] = {"max_scaled_error": float(err.max()),
-                             "sample": f"{int(ok.sum())} aircraft, randomised trims and control modes x 500 closed-loop RK4 steps, fp64 oracle (C++ port)",
+    err = np.abs(ws.x - xo) / sc[perm]
+    out["rel_err_vs_cpu"] = {"max_scaled_error": float(err.max()) if same_status else float("inf"), "status_words_equal": same_status,
+                             "sample": f"{m} aircraft, randomised trims and control modes x 500 closed-loop RK4 steps, fp64 oracle (C++ port)",
                              "tolerance": 1e-6}
     ws.close()
     return out
@@ -426,10 +471,23 @@ def main():
         achieved_gbs = BYTES_PER_AIRCRAFT_STEP * units_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         valu = None
+        counters_note = None
         prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
-        if os.path.exists(prof) and args.dtype == "f64":   # the committed counters describe the fp64 kernel
+        duo_on = os.environ.get("FLIGHTBATCH_DUO", "1") != "0"
+        if not os.path.exists(prof):
+            counters_note = "profiles/" + PROFILE_COUNTERS + " is absent: no PMC-derived figures"
+        elif args.dtype != "f64" or not duo_on:
+            counters_note = "the committed PMC counters describe the fp64 k_step_duo kernel, not the one this run timed"
+        else:
             pj = json.load(open(prof))
-            if pj.get("inner") == args.inner and pj.get("n"):
+            # the PMC figures are quoted only next to the code they were measured on: tools/summarize_profile.py stores a hash of
+            # flight.jl_amd/csrc/* + the compiler flags (__graft_entry__.source_hash) and a stale file is refused, not silently reused
+            import __graft_entry__ as _ge
+            here = _ge.source_hash()
+            if pj.get("source_hash") != here:
+                counters_note = (f"profiles/{PROFILE_COUNTERS} was collected on source hash {pj.get('source_hash')}, this tree is {here}: "
+                                 "traffic and roofline_valu withheld (re-run tools/collect_profile.sh)")
+            elif pj.get("inner") == args.inner and pj.get("n"):
                 scale = n / pj["n"]                        # counters are per launch of pj["n"] aircraft; traffic and flops are proportional to n
                 traffic = pj.get("hbm_bytes_per_launch") * scale if pj.get("hbm_bytes_per_launch") else None
                 if pj.get("fp64_flops_per_launch"):
@@ -437,7 +495,8 @@ def main():
                     valu = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_aircraft_step": pj["fp64_flops_per_launch"] / (pj["n"] * pj["inner"]),
                             "valu_insts_per_aircraft_step": pj.get("valu_insts_per_aircraft_step"),
-                            "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS}
+                            "valu_busy": pj.get("valu_busy"),
+                            "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS + " (source hash " + here + ")"}
         line = {
             "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True,
@@ -457,6 +516,8 @@ def main():
                                  "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,
         }
+        if counters_note:
+            line["roofline"]["traffic_note"] = counters_note
         if world > 1:
             per = head["elapsed_per_rank"]
             line["gather_ms"] = head["gather_ms"]
@@ -466,17 +527,27 @@ def main():
                 "value": float(other["n_total"]) * args.inner * args.steps / other["elapsed"], "unit": "aircraft-steps/s",
                 "aircraft_total": other["n_total"], "aircraft_per_gpu": other["n"], "ms_per_step": other["elapsed"] / args.steps * 1e3,
                 "kernel_ms": other["kernel_ms"], "gather_ms": other["gather_ms"]}
+    x2_timed = None
     if world > 1:
+        if not args.no_extra and args.dtype == "f64":
+            x2_timed = time_x2(fb, torch, dist, C, args, local_rank, world)   # configs[3] at this node's split: every rank takes part
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        # the CPU baseline and the parity sample ride on every line, multi-GPU ones included: rank 0, on its own shard, after the
+        # process group is gone (nothing of this is inside a timed region)
+        if not args.no_cpu_baseline:
             x0, s0, u0, ui0 = head["ic"]
             line["cpu_baseline"] = cpu_baseline(x0, u0, ui0, s0)
             line["rel_err_vs_cpu"] = parity_sample(fb, x0, u0, ui0, s0, head["cell"], args.dtype)
-        if world == 1 and not args.no_extra and args.dtype == "f64":
+            if world > 1:
+                line["cpu_baseline"]["sample"] += f"; timed on rank 0's host share while the other {world - 1} ranks idle"
+                line["rel_err_vs_cpu"]["sample"] += " (rank 0's shard)"
+        if not args.no_extra and args.dtype == "f64":
             head.pop("ic", None)
-            line["extra"] = {"x2": extra_x2(fb, C, args), "fleet": extra_fleet(fb, C, args)}
+            line["extra"] = {"x2": extra_x2(fb, C, args, timed=x2_timed)}
+            if world == 1:
+                line["extra"]["fleet"] = extra_fleet(fb, C, args)
         print(json.dumps(line), flush=True)
 
 

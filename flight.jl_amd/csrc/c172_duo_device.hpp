@@ -264,7 +264,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         // ----- landing gear: the high-clearance shortcut of rhs() (no wheel can touch within 10 m of clearance) -----
         aux.wow = 0;
         aux.crash = 0;
-        if (!(h_o - env.h_trn > 10.0)) st |= FB_ST_INTERNAL_REDO;
+        if (!(fmin(h_o - env.h_trn, h_e - H_MIN) > 10.0)) st |= FB_ST_INTERNAL_REDO;   // (within reach of the ground, or of the altitude floor: rhs(), "high-clearance shortcut")
         emit.xsync(2);   // ----- barrier B -----
         const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
         const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};

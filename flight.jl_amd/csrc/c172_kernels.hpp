@@ -136,7 +136,21 @@ struct KArgs {
     double* ctl_bak;      // [(FB_NCS + FB_NCU) x n] the airborne pass's copy of cs | cu at launch start (restored for lanes it hands over)
     double* duo_pld;      // [DUO_NCONST x n] k_step_duo: per-aircraft constants of the launch (the deflection-only aerodynamic terms),
                           // written by its prologue and fetched at the start of every evaluation's aerodynamics block
+    // the termination record (fb_get_termination): written once, when an aircraft's simulation ends
+    long long* term_step; // [n] RK updates completed since the last init when the exception was thrown
+    int32_t* term_where;  // [n] FB_TERM_*
+    long long step0;      // steps taken since the last init when the launch starts
 };
+// The one exception the reference would have thrown out of an f_ode! whose checks raised `bits`: kinematics and air data come first
+// (altitude below h_min: FP/kinematics.jl:190,199 -> geodesy.jl:218-221; ISA range: atmosphere.jl:133), the struts after them
+// (landinggear.jl:240, 321), the centre of mass last (dynamics.jl:477-486). (A strut's assertion ahead of a LATER strut's altitude
+// error is not told apart: both need the wheels on the ground AND below h_min.)
+FBD int32_t first_exception(int32_t bits) {
+    if (bits & FB_ST_ALT_RANGE) return FB_ST_ALT_RANGE;
+    if (bits & FB_ST_ISA_RANGE) return FB_ST_ISA_RANGE;
+    if (bits & FB_ST_CONTACT_ASSERT) return FB_ST_CONTACT_ASSERT;
+    return bits;
+}
 
 constexpr int STEP_BLOCK = 256;  // lanes per workgroup of the stepping kernel
 constexpr int DUO_NCONST = 12;   // rows of KArgs::duo_pld: 8 aerodynamic sums, 2 x (interval, weight) of the flap-axis locations
@@ -454,22 +468,43 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     const int t = threadIdx.x;
     double acc_r[ACC_REGS ? NR : 1];
     const AccStore<B, ACC_REGS> acc = [&] { if constexpr (ACC_REGS) return AccStore<B, true>{acc_r}; else return AccStore<B, false>{(lds_ptr)acc_l, t}; }();
-    bool to_ground = false;
+    // ---- termination (FC/sim.jl:561-570; include/flightbatch.h FB_TERM_*) ----
+    // The reference stops at the first exception and leaves mdl.x as it stands at the throw: for an f_ode! that threw at an RK stage,
+    // that stage's ARGUMENT. An evaluation here updates its argument panel in place, so by the time its status bits are known the
+    // argument is gone. The airborne instance therefore hands every lane that raises a bit over (nothing committed, like a lane that
+    // comes within reach of the ground); the ground-capable instance notes WHERE the lane threw (tkey = completed steps * 8 + FB_TERM_*
+    // code) and, once the wave is through its launch, steps the lane again from the launch-start state — same inputs, same code, bit
+    // for bit the same path — up to the evaluation that threw, and freezes it in front of it (`replaying`, below).
+    constexpr int TKEY_NONE = 0x7fffffff;
+    [[maybe_unused]] int tkey = TKEY_NONE;     // per lane
+    [[maybe_unused]] bool replaying = false;   // wave-uniform
+    bool mine = true;                          // per lane: this pass steps the lane
+restart:
+    if (mine) {
+        bool to_ground = false;
 #pragma unroll
-    for (int k = 0; k < FB_NX; k++) {
-        const double v = a.x[(int64_t)k * a.n + i];
-        if (SV::skip(k)) to_ground = to_ground || (v != 0.0);
-        else { xs_l[SV::row(k) * B + t] = v; acc.set(SV::row(k), 0.0); }
+        for (int k = 0; k < FB_NX; k++) {
+            const double v = a.x[(int64_t)k * a.n + i];
+            if (SV::skip(k)) to_ground = to_ground || (v != 0.0);
+            else { xs_l[SV::row(k) * B + t] = v; acc.set(SV::row(k), 0.0); }
+        }
+        if (to_ground) { a.redo[i] = 1; return; }   // (airborne instance only: the ground-capable one skips no row)
     }
-    if (to_ground) { a.redo[i] = 1; return; }
-    if constexpr (X && !GROUND) {
-        // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass must
-        // find them as they were at launch start
-        if (a.ctl_ratio > 0) {
+    if constexpr (X) {
+        // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass, or stepped
+        // a second time up to the evaluation that threw, must find them as they were at launch start
+        if (a.ctl_ratio > 0 && mine) {
+            if (!replaying) {
 #pragma unroll 1
-            for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
+                for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
 #pragma unroll 1
-            for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+                for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
+#pragma unroll 1
+                for (int k = 0; k < FB_NCU; k++) const_cast<double*>(a.cu)[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i];
+            }
         }
     }
     InT in;
@@ -500,11 +535,11 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     // be re-evaluated for it, the other lanes of its wave sit out that one evaluation (`run` false) instead of moving on.
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false;      // uniform
-    bool alive = true, dead = false, run = true, handoff = false;   // per lane
+    bool alive = mine, dead = false, run = mine, handoff = false;   // per lane
     if constexpr (X) {
         // FSAL across launches: the previous launch's last evaluation sat at this very state. A wave whose lanes all
         // hold a valid k1 starts at stage 1; otherwise the lanes without one evaluate it first while the others sit out.
-        const bool have_k1 = a.k1 && a.k1_valid[i];
+        const bool have_k1 = mine && a.k1 && a.k1_valid[i];
         if (have_k1) {
 #pragma unroll
             for (int j = 0; j < FB_NX; j++) {
@@ -515,8 +550,8 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                 xc_l[idx] = xs_l[idx] + hdt * kj;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(!have_k1) == 0) stage = 1;
-        else { run = !have_k1; redoing = true; }
+        if (__builtin_amdgcn_ballot_w64(mine && !have_k1) == 0) stage = 1;
+        else { run = mine && !have_k1; redoing = true; }
     }
 #pragma unroll 1
     while (true) {
@@ -533,6 +568,29 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
         int32_t bits = 0;
         [[maybe_unused]] CtlSink tap;
         [[maybe_unused]] const bool tap_now = X && a.ctl_ratio > 0 && stage == 0 && pending_cb && !redoing && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
+        // which evaluation of the reference's schedule this is (wave-uniform): the one at the new state of an RK update that has just
+        // been made — `step` counts the callbacks that have run, so one update more is complete — a re-evaluation at the accepted state, or
+        // RK stage k2..k4 (FB_TERM_* codes)
+        [[maybe_unused]] const bool at_new = stage == 0 && pending_cb && !redoing;
+        [[maybe_unused]] const int ev_done = step + (at_new ? 1 : 0);
+        [[maybe_unused]] const int ev_key = ev_done * 8 + (stage != 0 ? stage + 1 : (at_new ? (int)FB_TERM_F_ODE_NEW : (int)FB_TERM_F_ODE_REEVAL));
+        static_assert(FB_TERM_F_ODE_K2 == 2 && FB_TERM_F_ODE_K3 == 3 && FB_TERM_F_ODE_K4 == 4, "stage + 1");
+        if constexpr (GROUND) {
+            if (replaying && run && tkey == ev_key) {
+                // this is the evaluation that threw: the lane stops in front of it, with mdl.x = its argument (FC/sim.jl:306)
+                if (stage != 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) xs_l[r * B + t] = xc_l[r * B + t];
+                    if constexpr (X) {
+                        const double ms = stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4);
+#pragma unroll
+                        for (int k = 0; k < NAL; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                    }
+                }
+                if constexpr (X) { if (a.k1) a.k1_valid[i] = 0; }
+                alive = false; run = false; dead = true;
+            }
+        }
         if (run) {
             InT inl = in;                   // and keeps products of the per-lane inputs from being hoisted out of it
             double xa_s[X ? FB_NACT : 1];
@@ -555,9 +613,24 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                 else bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
             } else
                 bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
-            if (!GROUND && (bits & FB_ST_INTERNAL_REDO)) { handoff = true; alive = false; run = false; bits = 0; }   // nothing is committed for this lane
+            if constexpr (!GROUND) {
+                // within reach of the ground, or an exception: nothing is committed for this lane, the ground-capable pass takes it over
+                if (bits != 0) { handoff = true; alive = false; run = false; bits = 0; }
+            } else {
+                if (bits != 0) {   // f_ode! threw (altitude / ISA range, contact assertion): the simulation of this aircraft ends HERE
+                    if (!replaying) {
+                        tkey = ev_key;
+                        a.status[i] |= first_exception(bits);
+                        a.term_where[i] = ev_key & 7;
+                        a.term_step[i] = a.step0 + ev_done;
+                    }
+                    // (second pass: the lane follows the first pass bit for bit and is frozen in front of this evaluation, so nothing
+                    // can be raised there; a lane that did would simply stop as it stands)
+                    alive = false; run = false; bits = 0;
+                }
+            }
             if constexpr (X) {
-                if (last) {
+                if (last && run) {
                     const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
 #pragma unroll
                     for (int k = 0; k < NAL; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * P;
@@ -573,12 +646,12 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
             bool mod = false;
             // Cessna172X: f_periodic! follows f_step! (FC/sim.jl:204-218) but reads the outputs of the step's last f_ode!, i.e. of this
             // evaluation at x_{n+1}, taken before f_step! renormalises the quaternions: tap them first
-            // (a lane that f_step! is about to terminate — status bits from this evaluation, a crash flag — gets no update: the reference
-            // throws out of cb_step before cb_periodic runs)
+            // (a lane that f_step! is about to terminate — a crash flag — gets no update: the reference throws out of cb_step before
+            // cb_periodic runs; a lane whose evaluation threw is not running any more)
             const bool ctl_now = X && a.ctl_ratio > 0 && (a.ctl_phase + step) % a.ctl_ratio == 0;   // wave-uniform
             if (run) {
                 if constexpr (X) {
-                    if (ctl_now && bits == 0 && !aux.crash) {
+                    if (ctl_now && !aux.crash) {
                         CtlIn v;
                         v.lat = tap.lat; v.lon = tap.lon;
                         v.EAS = tap.EAS; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
@@ -617,10 +690,15 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                 const int stall0 = stall, eng0 = eng;
                 if (aux.alpha > c172::alpha_stall_hi) stall = 1;
                 else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
-                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
-                if constexpr (GROUND) {   // the friction regulators of a unit without weight on its wheel are reset (landinggear.jl:479-483)
+                [[maybe_unused]] bool crashed = false;
+                if constexpr (GROUND) {
+                    // landing gear, unit by unit (c172.jl:485; landinggear.jl:539-548): a strut's crash check THROWS GroundCrash, and what
+                    // follows it in the reference's order — this unit's regulator reset, the later units, the engine's state machine,
+                    // f_periodic! — does not run; the friction regulators of a unit without weight on its wheel are reset (:479-483)
 #pragma unroll
                     for (int g = 0; g < 3; g++) {
+                        if (crashed) continue;
+                        if (aux.crash & (1 << g)) { crashed = true; continue; }
                         if (!(aux.wow & (1 << g))) {
                             const int i0 = SV::row(FB_X_LDG_FRC + 2 * g) * B + t, i1 = SV::row(FB_X_LDG_FRC + 2 * g + 1) * B + t;
                             if (xs_l[i0] != 0.0 || xs_l[i1] != 0.0) mod = true;
@@ -628,14 +706,23 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                         }
                     }
                 }
-                const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
-                const bool fuel = aux.m_avail > 0;
-                const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
-                if (eng == 0) { if (start) eng = 1; }
-                else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
-                else if (stop || w < c172::w_stall || !fuel) eng = 0;
+                if (!crashed) {
+                    const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
+                    const bool fuel = aux.m_avail > 0;
+                    const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
+                    if (eng == 0) { if (start) eng = 1; }
+                    else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
+                    else if (stop || w < c172::w_stall || !fuel) eng = 0;
+                }
                 mod = mod || stall != stall0 || eng != eng0;
-                if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
+                if constexpr (GROUND) {
+                    if (crashed) {   // the simulation of this aircraft ends inside f_step! (FB_TERM_F_STEP), `step` RK updates complete
+                        a.status[i] |= FB_ST_GROUND_CRASH;
+                        a.term_where[i] = FB_TERM_F_STEP;
+                        a.term_step[i] = a.step0 + step;
+                        dead = true;
+                    }
+                }
                 if constexpr (X) {
                     if (a.k1 && (dead || step == nsteps)) {   // this evaluation's derivatives (acc = k at stage 0) are the next launch's k1 unless something changed
                         const bool keep = !dead && !mod;
@@ -649,7 +736,17 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                 }
                 if (dead) { alive = false; run = false; mod = false; }
             }
-            if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
+            if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) {
+                if constexpr (GROUND) {
+                    // lanes whose f_ode! threw are stepped once more, up to that evaluation (see `tkey` above)
+                    if (!replaying && __builtin_amdgcn_ballot_w64(tkey != TKEY_NONE) != 0) {
+                        replaying = true;
+                        mine = tkey != TKEY_NONE;
+                        goto restart;
+                    }
+                }
+                break;
+            }
             if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
                 if (mod) {
 #pragma unroll
@@ -659,7 +756,6 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
                 continue;
             }
         }
-        if (bits != 0) { a.status[i] |= bits; dead = true; }
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }
@@ -927,7 +1023,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // ================= role D =================
     // The lane's bookkeeping state lives in an LDS word between evaluations (D_* bits): kept in registers it is what the allocator
     // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
-    enum { D_ALIVE = 1, D_DEAD = 2, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };
+    enum { D_ALIVE = 1, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };   // (no lane ends its simulation here: a status bit is a hand-over)
     InputsDuoD in;
     in.pld_l = (lds_cptr)pld_l + t; in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
     {
@@ -992,7 +1088,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         if (cb) duo_barrier(3);   // role P has read x_{n+1} for the last time: f_step! may modify it
         int d = dst_l[t];
         if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
-        if (run && (bits & FB_ST_INTERNAL_REDO)) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }   // nothing is committed for this lane
+        // within reach of the ground, or an exception (altitude / ISA range): nothing is committed for this lane, the ground-capable pass
+        // steps it again from the launch-start state and ends its simulation where the reference would (see k_step_air, `tkey`)
+        if (run && bits != 0) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }
         bool zero_acc = false, advance = true;
         if (redoing) { redoing = false; run = d & D_ALIVE; }   // the lanes that sat out the re-evaluation of k1 join again
         else if (stage == 0 && pending_cb) {
@@ -1017,7 +1115,6 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 const int stall0 = stall, eng0 = eng;
                 if (aux.alpha > c172::alpha_stall_hi) stall = 1;
                 else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
-                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
                 const double w = xs_l[SV::row(FB_X_ENG_OMEGA) * B + t];
                 const bool fuel = aux.m_avail > 0;
                 const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
@@ -1026,8 +1123,6 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 else if (stop || w < c172::w_stall || !fuel) eng = 0;
                 mod = mod || stall != stall0 || eng != eng0;
                 d = (d & ~(D_STALL | (3 << D_ENG_SHIFT))) | (stall ? D_STALL : 0) | (eng << D_ENG_SHIFT);
-                if (bits != 0) { a.status[i] |= bits; d |= D_DEAD; bits = 0; }
-                if (d & D_DEAD) { d &= ~D_ALIVE; run = false; mod = false; }
             }
             if (step == nsteps || __builtin_amdgcn_ballot_w64(d & D_ALIVE) == 0) { exit_ = true; advance = false; }
             else if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
@@ -1039,7 +1134,6 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             }
         }
         if (advance) {
-            if (bits != 0) { a.status[i] |= bits; d |= D_DEAD; }
             stage = (stage + 1) & 3;
             pending_cb = (stage == 0);
         }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
     // wave-uniform stage machine and branch-free emit, as in fbd::k_step_air (see there)
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false;
-    bool alive = true, dead = false, run = true, handoff = false;
+    bool alive = true, run = true, handoff = false;   // (no lane ends its simulation in this kernel: a status bit is a hand-over)
 #pragma unroll 1
     while (true) {
         StepAux aux;
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
                                      (typename F32Emit<B>::lf_ptr)xc_l, eb, ee, eed, last, t};
             const SV xv = {(lds_cptr)xc_l + t + lds_off};
             bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
-            if (bits & FB_ST_INTERNAL_REDO) { handoff = true; alive = false; run = false; bits = 0; }   // within reach of the ground: the fp64 kernel takes this lane over
+            // within reach of the ground, or an exception (altitude / ISA range): nothing is committed, the fp64 ground-capable kernel takes
+            // this lane over and — if the exception is real in fp64 too — ends its simulation where the reference would
+            if (bits != 0) { handoff = true; alive = false; run = false; bits = 0; }
         }
         if (redoing) { redoing = false; run = alive; }
         else if (stage == 0 && pending_cb) {   // f_step! on x_{n+1} = the x_n panels (aircraftbase.jl:172-181; kinematics.jl:226-229; c172.jl:375-384,715-724; piston.jl:428-453)
@@ -184,7 +186,6 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
                 const int stall0 = stall, eng0 = eng;
                 if (aux.alpha > c172::alpha_stall_hi) stall = 1;
                 else if (aux.alpha < c172::alpha_stall_lo) stall = 0;
-                if (aux.crash) bits |= FB_ST_GROUND_CRASH;
                 const float w = xs_l[xsrow(SV::row(FB_X_ENG_OMEGA)) * B + t];
                 const bool fuel = aux.m_avail > 0;
                 const bool start = in.ui & FB_UI_ENG_START, stop = in.ui & FB_UI_ENG_STOP;
@@ -192,8 +193,6 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
                 else if (eng == 1) { if (!start) eng = 0; if (w > c172::w_idle && fuel) eng = 2; }
                 else if (stop || w < c172::w_stall || !fuel) eng = 0;
                 mod = mod || stall != stall0 || eng != eng0;
-                if (bits != 0) { a.status[i] |= bits; dead = true; bits = 0; }
-                if (dead) { alive = false; run = false; mod = false; }
             }
             if (step == nsteps || __builtin_amdgcn_ballot_w64(alive) == 0) break;
             if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}: put it back into the evaluation panel
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
                 continue;
             }
         }
-        if (bits != 0) { a.status[i] |= bits; dead = true; }
         stage = (stage + 1) & 3;
         pending_cb = (stage == 0);
     }

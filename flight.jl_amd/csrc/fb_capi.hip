@@ -42,6 +42,8 @@ struct fb_handle_s {
     double* u = nullptr;
     int32_t* ui = nullptr;
     int32_t* status = nullptr;
+    long long* term_step = nullptr;   // [n] termination record (fb_get_termination), valid where status != 0
+    int32_t* term_where = nullptr;    // [n]
     double* y = nullptr;      // [FB_NY x n], allocated on first use
     double* xdot = nullptr;   // scratch [FB_NX x n]
     double* tables = nullptr; // LDS_TABLE_DOUBLES
@@ -88,6 +90,7 @@ static KArgs make_args(fb_handle h) {
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
     a.gains = h->gains; a.ctl_bak = h->ctl_bak; a.duo_pld = h->duo_pld;
+    a.term_step = h->term_step; a.term_where = h->term_where; a.step0 = h->steps_done;
     for (int k = 0; k < 10; k++) a.ctl_off.off[k] = (int)h->gains_off[k];
     a.ctl_off.total = (int)h->gains_total;
     a.ctl_off.same_grid = h->gains_same_grid ? 1 : 0;
@@ -218,7 +221,12 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
     HIPCHK(hipMalloc(&h->u, sizeof(double) * FB_NU * n));
     HIPCHK(hipMalloc(&h->ui, sizeof(int32_t) * n));
     HIPCHK(hipMalloc(&h->status, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->term_step, sizeof(long long) * n));
+    HIPCHK(hipMalloc(&h->term_where, sizeof(int32_t) * n));
+    HIPCHK(hipMemsetAsync(h->term_step, 0, sizeof(long long) * n, h->stream));
+    HIPCHK(hipMemsetAsync(h->term_where, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->redo, sizeof(int32_t) * n));
+    if (h->duo) HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * n));   // (here, not in the first fb_step: hipMalloc synchronises the device)
     HIPCHK(hipMemsetAsync(h->redo, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->tables, sizeof(double) * TABLE_BUF_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
@@ -256,7 +264,8 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (device_id >= ndev) return fail("device_id out of range");
     HIPCHK(hipSetDevice(device_id));
     fb_handle h = new fb_handle_s();
-    h->duo = env_step_duo();
+    // the wave-specialised stepper exists for Cessna172Sv0 / WA / fp64 only; every other handle steps with k_step_air and needs no duo_pld
+    h->duo = model_id == FB_MODEL_C172S0 && kin_id == FB_KIN_WA && dtype == FB_F64 && env_step_duo();
     h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
     h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
     h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
@@ -277,7 +286,7 @@ int32_t fb_destroy(fb_handle h) {
     hipStreamSynchronize(h->stream);
     log_free(h);
     r2_destroy(h);
-    hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->y); hipFree(h->xdot);
+    hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->term_step); hipFree(h->term_where); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
     hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
@@ -638,7 +647,6 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
         HIPCHK(hipMemcpy(h->tables_f32, f.data(), sizeof(float) * TABLE_BUF_DOUBLES, hipMemcpyHostToDevice));
         h->tables_f32_stale = false;
     }
-    if (h->duo && !h->duo_pld) HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * h->n));
     KArgs a = make_args(h);
     int64_t left = nsteps;
     // Cessna172Xv2: the control laws run inside the stepping kernels every Δt/dt steps (cb_periodic after cb_step, FC/sim.jl:204-218,
@@ -646,6 +654,7 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
     while (left > 0) {
         const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
         a.ctl_phase = a.ctl_ratio > 0 ? (int)(h->steps_done % a.ctl_ratio) : 0;
+        a.step0 = h->steps_done;
         FB_LAUNCH_STEP(grid_for(h->n, 256), a, k);
         left -= k;
         h->steps_done += k;
@@ -795,6 +804,24 @@ int32_t fb_status(fb_handle h, int32_t* status) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(status, h->status, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_get_termination(fb_handle h, int64_t* step, int32_t* where) {
+    if (!h) return fail("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int32_t> st((size_t)h->n);
+    std::vector<long long> ts(step ? (size_t)h->n : 0);
+    HIPCHK(hipMemcpyAsync(st.data(), h->status, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (step) HIPCHK(hipMemcpyAsync(ts.data(), h->term_step, sizeof(long long) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (where) HIPCHK(hipMemcpyAsync(where, h->term_where, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // the record is written when an aircraft terminates and means something only next to a termination bit (init clears the
+    // status words, not the record)
+    for (int64_t i = 0; i < h->n; i++) {
+        const bool term = (st[(size_t)i] & ~FB_ST_NAN) != 0;
+        if (step) step[i] = term ? (int64_t)ts[(size_t)i] : -1;
+        if (where && !term) where[i] = FB_TERM_NONE;
+    }
     return 0;
 }
 

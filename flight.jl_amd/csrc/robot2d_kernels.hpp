@@ -87,6 +87,8 @@ struct R2Args {
     T* r;              // [10 x n]
     const T* u;        // [4 x n]
     int32_t* status;   // [n]
+    long long* term_step;   // [n] termination record (fb_get_termination)
+    int32_t* term_where;    // [n]
     int64_t n;
     R2Params<T> p;
     T dt;
@@ -94,7 +96,9 @@ struct R2Args {
     int with_controller;
 };
 
-// nsteps x step!(sim): RK4 (OrdinaryDiffEq stage order) -> f_step! (LostBalance, robot2d.jl:553-561) -> f_periodic! at k Δt
+// nsteps x step!(sim): RK4 (OrdinaryDiffEq stage order) -> f_step! (LostBalance, robot2d.jl:553-561) -> f_periodic! at k Δt.
+// LostBalance is thrown out of cb_step right after the RK update of step k: the robot's simulation ends with x = x_k, before that
+// step's f_periodic! (FC/sim.jl:204-218, 561-570); the termination record says so (FB_TERM_F_STEP, k updates complete).
 template <class T>
 __global__ __launch_bounds__(256) void k_r2_step(R2Args<T> a, long long step0, int nsteps) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +127,11 @@ __global__ __launch_bounds__(256) void k_r2_step(R2Args<T> a, long long step0, i
 #pragma unroll
         for (int j = 0; j < 4; j++) r[j] = x[j] + dt6 * (2 * (k2[j] + k3[j]) + (k1[j] + k4[j]));
         if (a.with_controller) {
-            if (fabs((double)r[2]) > 45 * (3.14159265358979323846 / 180)) { st |= FB_ST_LOST_BALANCE; break; }
+            if (fabs((double)r[2]) > 45 * (3.14159265358979323846 / 180)) {
+                st |= FB_ST_LOST_BALANCE;
+                a.term_where[i] = FB_TERM_F_STEP; a.term_step[i] = step0 + k;
+                break;
+            }
             if (((step0 + k) % a.ratio) == 0) r2_f_periodic(a.p, (T)(a.dt * a.ratio), u, r);
         }
     }

@@ -58,6 +58,7 @@ def _load():
         "fb_sync": ([H], C.c_int32),
         "fb_time": ([H], C.c_double),
         "fb_status": ([H, I32], C.c_int32),
+        "fb_get_termination": ([H, C.POINTER(I64), I32], C.c_int32),
         "fb_get_step_count": ([H, C.POINTER(I64)], C.c_int32),
         "fb_set_step_count": ([H, I64, C.c_double], C.c_int32),
         "fb_set_status": ([H, I32], C.c_int32),

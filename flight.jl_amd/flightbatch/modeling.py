@@ -222,6 +222,15 @@ class BatchedWorld:
         check(lib.fb_status(self._h, _pi(st)))
         return st
 
+    @property
+    def termination(self):
+        """(step, where) of every aircraft: the number of RK updates completed when its simulation ended (-1: still running) and the
+        FB_TERM_* code of the place — ≙ sim.t and the frame of the exception the reference stops with (FC/sim.jl:561-570)."""
+        step = np.empty(self.n, dtype=np.int64)
+        where = np.empty(self.n, dtype=np.int32)
+        check(lib.fb_get_termination(self._h, step.ctypes.data_as(C.POINTER(C.c_int64)), _pi(where)))
+        return step, where
+
     def sync(self):
         check(lib.fb_sync(self._h))
 
@@ -337,11 +346,14 @@ class Simulation:
             want = int(np.ceil((self.t_end - self.t_start) / (self.save_every * self.dt))) + 2
             budget = int(log_capacity) if log_capacity else max(2, int(8e9 // (8 * self._rows.size * mdl.n)))   # <= 8 GB by default
             if log_capacity is None and budget < want:
-                # the reference's defaults (save_on, t_end = 10000) would need more device memory than the 8 GB default budget for a
-                # batch this large: refuse now instead of failing half-way through a step! with "log capacity exhausted"
-                raise ValueError(f"Simulation: saving {self._rows.size} rows of {mdl.n} vehicles every {self.save_every} steps until t_end = {self.t_end} "
-                                 f"needs {want} samples, the default 8 GB log holds {budget}; pass t_end / saveat / save_x=False / save_rows, "
-                                 f"log_capacity=<samples> (explicit), or save_on=False")
+                # the reference's defaults (save_on, t_end = 10000, every step) need more device memory than the 8 GB default budget for a
+                # batch this large. The log is capped at the budget and the run can go on until it is full (fb_step then fails with "log
+                # capacity exhausted", and says so): say it now, with the ways out, instead of refusing to construct the Simulation
+                import warnings
+                warnings.warn(f"Simulation: saving {self._rows.size} rows of {mdl.n} vehicles every {self.save_every} steps until t_end = {self.t_end} "
+                              f"needs {want} samples; the default 8 GB device log holds {budget}, i.e. the run can be stepped to "
+                              f"t = {self.t_start + (budget - 1) * self.save_every * self.dt:g}. Pass t_end / saveat / save_x=False / save_rows, "
+                              f"log_capacity=<samples>, or save_on=False", stacklevel=2)
             self.capacity = min(want, budget)
             # with a user callback the sample must be taken AFTER it (CallbackSet order cb_step, cb_periodic, cb_user, cb_save: FC/sim.jl:204-218):
             # the device log is then driven from step() instead of from inside fb_step

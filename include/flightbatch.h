@@ -79,6 +79,31 @@ enum {
     FB_ST_CONTACT_ASSERT = 16, /* @assert, FP/landinggear.jl:321 */
     FB_ST_LOST_BALANCE = 32    /* LostBalance, FA/robot2d/robot2d.jl:531-561 (Robot2D only) */
 };
+/* ---- where a terminated aircraft stopped (fb_get_termination) ----
+ * The reference stops a simulation at the first exception (FC/sim.jl:561-570); what it leaves behind is mdl.x / mdl.s as they stand
+ * at the throw (sim.x forwards to mdl.x, FC/sim.jl:261-275). A terminated aircraft of the batch is frozen in exactly that condition:
+ *   - f_ode! threw (ArgumentError of FP/geodesy.jl:218-221 or FP/atmosphere.jl:133, @assert of FP/landinggear.jl:321) while the
+ *     integrator evaluated RK stage k2, k3 or k4 of the step from t_step to t_step + dt: x = the ARGUMENT of that evaluation
+ *     (x_step + c dt k_{j-1}; f_ode_wrapper! has copied it into mdl.x, FC/sim.jl:306), s unchanged, `step` RK updates completed;
+ *   - f_ode! threw at the new state x_step right after the RK update (OrdinaryDiffEq's evaluation of f at the new u, whose outputs
+ *     the callbacks read), before any callback of that step ran: x = x_step;
+ *   - f_step! threw (GroundCrash, FP/landinggear.jl:331-347; LostBalance, FA/robot2d/robot2d.jl:553-561) at x_step: x and s carry the
+ *     part of f_step! that precedes the throw in the reference's order — quaternion renormalisation (FP/aircraftbase.jl:178), stall
+ *     flag (FA/c172/c172.jl:720), the contact-regulator resets of the landing-gear units ahead of the one that threw
+ *     (FA/c172/c172.jl:485, FP/landinggear.jl:539-548) — and not what follows it (engine state machine, f_periodic!);
+ *   - f_ode! threw at x_step after the step's callbacks had run: the re-evaluation of a state f_step! modified, or the first
+ *     evaluation after init / after the host changed the state.
+ * The status word holds the single bit of that first exception. (FB_ST_NAN is this library's own check at the end of a launch and
+ * has no termination record.) */
+enum {
+    FB_TERM_NONE = 0,
+    FB_TERM_F_ODE_K2 = 2,
+    FB_TERM_F_ODE_K3 = 3,
+    FB_TERM_F_ODE_K4 = 4,
+    FB_TERM_F_ODE_NEW = 5,
+    FB_TERM_F_STEP = 6,
+    FB_TERM_F_ODE_REEVAL = 7
+};
 /* ---- output record y[FB_NY] (what cb_save logs of `mdl.y`, FC/sim.jl:345-347) ---- */
 enum {
     FB_Y_KIN = 0,    /* KinData, 40 doubles, FP/kinematics.jl:46-63:
@@ -295,6 +320,10 @@ int32_t fb_log_read(fb_handle h, int64_t first, int64_t count, double* t, double
 
 /* SimulationTermination / ArgumentError mapping: per-aircraft sticky status bits (FB_ST_*). */
 int32_t fb_status(fb_handle h, int32_t* status);
+/* The termination record of every aircraft: step [N] = number of RK updates completed since the last init when the exception was
+ * thrown (-1: not terminated), where [N] = FB_TERM_* (see above). Either pointer may be NULL. ≙ sim.t and the stack frame of the
+ * exception the reference reports (FC/sim.jl:561-570). */
+int32_t fb_get_termination(fb_handle h, int64_t* step, int32_t* where);
 
 /* Trajectory collection across GPUs: one RCCL all-gather of the state panels over xGMI; no other
  * communication exists on this path. One process per GPU; rank 0 calls fb_comm_unique_id and the host distributes the 128

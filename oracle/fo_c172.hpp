@@ -223,7 +223,7 @@ inline int32_t c172_f_ode(const C172Model& M, const Env& env, const C172Inputs& 
         for (int k = 0; k < 9; k++) xdot[X_KIN + k] = 0;
         if (M.kin == KIN_ECEF) ecef_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
         else ned_f_ode(x + X_KIN, x + X_DYN, xdot + X_KIN, y.kin);
-        if (!(y.kin.h_e >= H_MIN) || !(y.kin.h_o >= H_MIN)) st |= ST_ALT_RANGE;
+        if (!(y.kin.h_e >= H_MIN) || !(y.kin.h_o >= H_MIN)) raise_status(st, ST_ALT_RANGE);
     }
     y.air = air_data(env, y.kin, st);
 
@@ -296,7 +296,7 @@ inline int32_t c172_f_ode(const C172Model& M, const Env& env, const C172Inputs& 
     du.ho_S_b = y.pwp.propeller.hr_b;
     du.q_eb = y.kin.q_eb;
     du.r_eb_e = y.kin.r_eb_e;
-    dynamics_f_ode(x + X_DYN, du, xdot + X_DYN, y.dyn);
+    st |= dynamics_f_ode(x + X_DYN, du, xdot + X_DYN, y.dyn);
     return st;
 }
 
@@ -326,37 +326,67 @@ inline int32_t c172_f_step(const C172Model& M, const C172Inputs& u, C172Disc& s,
     return st;
 }
 
+// Where a terminated simulation stopped (the FB_TERM_* codes of include/flightbatch.h, shared with the product).
+struct Term {
+    int32_t status = 0;   // the single status bit of the exception
+    int where = 0;        // 0 none | 2-4 f_ode! at RK stage k2..k4 | 5 f_ode! at the new state | 6 f_step! | 7 f_ode! re-evaluation
+    bool advanced = false;   // the RK update of this step was made before the throw (where >= 5 inside the step)
+};
+enum { TERM_NONE = 0, TERM_K2 = 2, TERM_K3 = 3, TERM_K4 = 4, TERM_NEW = 5, TERM_F_STEP = 6, TERM_REEVAL = 7 };
+
 // One fixed-step RK4 step followed by the discrete callbacks (sim.jl:204-218, 318-328).
 // OrdinaryDiffEqLowOrderRK RK4 perform_step!: k1 = f(x_n) [FSAL: re-evaluated after the u-modifying
 // step callback], k2 = f(x + dt/2 k1), k3 = f(x + dt/2 k2), k4 = f(x + dt k3),
 // x_{n+1} = x + dt/6 (2(k2 + k3) + (k1 + k4)), then f(x_{n+1}) (fills y), then callbacks.
 // `n_rhs` counts RHS evaluations the reference would make (6 per step).
+//
+// TERMINATION (sim.jl:561-570): the first exception ends the simulation, and what the reference leaves behind is mdl.x / mdl.s as
+// they stand at the throw. f_ode_wrapper! copies the integrator's argument into mdl.x before it calls f_ode! (sim.jl:306), so after an
+// exception inside a stage evaluation mdl.x IS that stage's argument; an exception out of f_step! (cb_step_affect!, sim.jl:318-328)
+// leaves x_{n+1} with the part of f_step! that ran before it. The restatement runs in throwing mode and catches where step!(sim) is
+// left: x holds mdl.x, `term` says where. Returns the status bit (0: the step completed).
 inline int32_t c172_step(const C172Model& M, const Env& env, const C172Inputs& u, C172Disc& s, double* x, double dt,
-                         C172Y& y, long* n_rhs = nullptr, bool reference_like = true) {
-    int32_t st = 0;
+                         C172Y& y, long* n_rhs = nullptr, bool reference_like = true, Term* term = nullptr) {
+    ThrowScope throwing;
     double k1[NX], k2[NX], k3[NX], k4[NX], xt[NX];
     C172Y yt;
-    st |= c172_f_ode(M, env, u, s, x, k1, yt);
-    const double hdt = dt / 2;
-    for (int i = 0; i < NX; i++) xt[i] = x[i] + hdt * k1[i];
-    st |= c172_f_ode(M, env, u, s, xt, k2, yt);
-    for (int i = 0; i < NX; i++) xt[i] = x[i] + hdt * k2[i];
-    st |= c172_f_ode(M, env, u, s, xt, k3, yt);
-    for (int i = 0; i < NX; i++) xt[i] = x[i] + dt * k3[i];
-    st |= c172_f_ode(M, env, u, s, xt, k4, yt);
-    for (int i = 0; i < NX; i++) x[i] = x[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
-    st |= c172_f_ode(M, env, u, s, x, k1, y);  // evaluation at the new state: y seen by f_step!, and logged
-    st |= c172_f_step(M, u, s, x, y);
-    if (n_rhs) *n_rhs += reference_like ? 6 : 5;
-    if (reference_like) {
-        // reeval_internals_due_to_modification!: fsalfirst = f(u_modified) — the 6th evaluation.
-        // It has no effect on the state trajectory (f is a pure function of x,u,s) and is only
-        // executed so that the CPU baseline does the same amount of work as the reference.
-        C172Y y2;
-        double kk[NX];
-        c172_f_ode(M, env, u, s, x, kk, y2);
+    int where = TERM_REEVAL;   // k1 at x_n: the re-evaluation that follows the previous step's callbacks (or the first one after init)
+    bool advanced = false;
+    try {
+        c172_f_ode(M, env, u, s, x, k1, yt);
+        const double hdt = dt / 2;
+        for (int i = 0; i < NX; i++) xt[i] = x[i] + hdt * k1[i];
+        where = TERM_K2;
+        c172_f_ode(M, env, u, s, xt, k2, yt);
+        for (int i = 0; i < NX; i++) xt[i] = x[i] + hdt * k2[i];
+        where = TERM_K3;
+        c172_f_ode(M, env, u, s, xt, k3, yt);
+        for (int i = 0; i < NX; i++) xt[i] = x[i] + dt * k3[i];
+        where = TERM_K4;
+        c172_f_ode(M, env, u, s, xt, k4, yt);
+        for (int i = 0; i < NX; i++) x[i] = x[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
+        advanced = true;
+        where = TERM_NEW;
+        c172_f_ode(M, env, u, s, x, k1, y);  // evaluation at the new state: y seen by f_step!, and logged
+        where = TERM_F_STEP;
+        c172_f_step(M, u, s, x, y);
+        if (n_rhs) *n_rhs += reference_like ? 6 : 5;
+        if (reference_like) {
+            // reeval_internals_due_to_modification!: fsalfirst = f(u_modified) — the 6th evaluation.
+            // It has no effect on the state trajectory (f is a pure function of x,u,s) and is only
+            // executed so that the CPU baseline does the same amount of work as the reference.
+            where = TERM_REEVAL;
+            C172Y y2;
+            double kk[NX];
+            c172_f_ode(M, env, u, s, x, kk, y2);
+        }
+    } catch (const Termination& t) {
+        if (where >= TERM_K2 && where <= TERM_K4)
+            for (int i = 0; i < NX; i++) x[i] = xt[i];   // mdl.x .= u of the stage that threw (sim.jl:306)
+        if (term) { term->status = t.bit; term->where = where; term->advanced = advanced; }
+        return t.bit;
     }
-    return st;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -368,26 +368,43 @@ inline int32_t c172x_f_ode(const C172Model& M, const Env& env, const C172Inputs&
 }
 // One step!(sim): RK4 over the 34 states, evaluation at the new state, f_step!, then — when `periodic` — the control laws
 // (they read the y of that last evaluation, aircraftbase.jl:232-242; sim.jl:204-218).
+// Termination as in c172_step (fo_c172.hpp): the first exception ends the simulation with x = mdl.x at the throw; an exception out
+// of f_step! (cb_step) precedes cb_periodic, so the control laws are not updated in that step.
 inline int32_t c172x_step(const C172Model& M, const CtlGains& G, const Env& env, const C172Inputs& u, double* cu, double* cs,
-                          C172Disc& s, double* x, double dt, double dT, bool periodic, C172Y& y) {
-    int32_t st = 0;
+                          C172Disc& s, double* x, double dt, double dT, bool periodic, C172Y& y, Term* term = nullptr) {
+    ThrowScope throwing;
     double k1[NXX], k2[NXX], k3[NXX], k4[NXX], xt[NXX], cmd7[7];
     C172Y yt;
     x2_commands(u, cs, cmd7);
-    st |= c172x_f_ode(M, env, u, cmd7, s, x, k1, yt);
-    for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt / 2 * k1[i];
-    st |= c172x_f_ode(M, env, u, cmd7, s, xt, k2, yt);
-    for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt / 2 * k2[i];
-    st |= c172x_f_ode(M, env, u, cmd7, s, xt, k3, yt);
-    for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt * k3[i];
-    st |= c172x_f_ode(M, env, u, cmd7, s, xt, k4, yt);
-    for (int i = 0; i < NXX; i++) x[i] = x[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
-    st |= c172x_f_ode(M, env, u, cmd7, s, x, k1, y);
-    const CtlIn v = ctl_in_from(M, y, x, cmd7);  // vehicle.y as the periodic update will see it (before f_step! touches x)
-    C172Inputs uf = u;
-    st |= c172_f_step(M, uf, s, x, y);
-    if (periodic && st == 0) ctl_periodic(G, dT, v, cu, cs);
-    return st;
+    int where = TERM_REEVAL;
+    bool advanced = false;
+    try {
+        c172x_f_ode(M, env, u, cmd7, s, x, k1, yt);
+        for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt / 2 * k1[i];
+        where = TERM_K2;
+        c172x_f_ode(M, env, u, cmd7, s, xt, k2, yt);
+        for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt / 2 * k2[i];
+        where = TERM_K3;
+        c172x_f_ode(M, env, u, cmd7, s, xt, k3, yt);
+        for (int i = 0; i < NXX; i++) xt[i] = x[i] + dt * k3[i];
+        where = TERM_K4;
+        c172x_f_ode(M, env, u, cmd7, s, xt, k4, yt);
+        for (int i = 0; i < NXX; i++) x[i] = x[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
+        advanced = true;
+        where = TERM_NEW;
+        c172x_f_ode(M, env, u, cmd7, s, x, k1, y);
+        const CtlIn v = ctl_in_from(M, y, x, cmd7);  // vehicle.y as the periodic update will see it (before f_step! touches x)
+        C172Inputs uf = u;
+        where = TERM_F_STEP;
+        c172_f_step(M, uf, s, x, y);
+        if (periodic) ctl_periodic(G, dT, v, cu, cs);
+    } catch (const Termination& t) {
+        if (where >= TERM_K2 && where <= TERM_K4)
+            for (int i = 0; i < NXX; i++) x[i] = xt[i];
+        if (term) { term->status = t.bit; term->where = where; term->advanced = advanced; }
+        return t.bit;
+    }
+    return 0;
 }
 // f_init!(aircraft, trim) (aircraftbase.jl:255-265; c172x.jl:285-326): actuator states = commands = trim values, then ctl_init
 inline bool c172x_trim_init(const C172Model& M, const CtlGains& G, const Env& env, const TrimParams& tp, TrimState& ts, double dT,

@@ -99,7 +99,9 @@ struct DynamicsU {
     V3 r_eb_e;
 };
 // dynamics.jl:443-525. x_dyn = [w_eb_b(3), v_eb_b(3)]
-inline void dynamics_f_ode(const double* x_dyn, const DynamicsU& u, double* xdot_dyn, DynamicsData& y) {
+// Returns status bits: ltf(Oc) / gravity(Oc) convert the CoM position to Geographic, whose Altitude constructor throws below h_min (geodesy.jl:218-221).
+inline int32_t dynamics_f_ode(const double* x_dyn, const DynamicsU& u, double* xdot_dyn, DynamicsData& y) {
+    int32_t st = 0;
     const V3 w_eb_b = {x_dyn[0], x_dyn[1], x_dyn[2]};
     const V3 v_eb_b = {x_dyn[3], x_dyn[4], x_dyn[5]};
     const Quat q_eb = u.q_eb;
@@ -128,6 +130,7 @@ inline void dynamics_f_ode(const double* x_dyn, const DynamicsU& u, double* xdot
     const V3 r_bc_e = rotate(q_eb, r_bc_b);
     const V3 r_ec_e = u.r_eb_e + r_bc_e;
     const GeoNE Oc = geographic_from_cartesian(r_ec_e);
+    if (!(Oc.h_e >= H_MIN)) raise_status(st, ST_ALT_RANGE);
 
     const Quat q_el = ltf(Oc.n_e);
     const Quat q_be = inv(q_eb);
@@ -161,6 +164,7 @@ inline void dynamics_f_ode(const double* x_dyn, const DynamicsU& u, double* xdot
 
     y.wr_S_c = wr_S_c; y.wr_S_b = u.wr_S_b; y.mp_S_c = mp_S_c; y.mp_S_b = u.mp_S_b; y.ho_S_b = u.ho_S_b;
     y.wd_ec_c = wd_ec_c; y.vd_ec_c = vd_ec_c; y.g_c_c = g_c_c; y.wd_eb_b = wd_eb_b; y.vd_eb_b = vd_eb_b;
+    return st;
 }
 
 // =============================================================================================

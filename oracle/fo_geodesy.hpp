@@ -35,6 +35,21 @@ enum StatusBits : int32_t {
     ST_CONTACT_ASSERT = 16,  // landinggear.jl:321 assertion
 };
 
+// The reference THROWS at these sites and the simulation stops there (sim.jl:561-570). The steppers run the restatement in throwing
+// mode (ThrowScope) and catch Termination where step!(sim) would be left; the single-call entry points (f_ode, f_step: tests that
+// look at outputs next to the status word) keep collecting bits.
+struct Termination { int32_t bit; };
+inline thread_local bool tl_throw_mode = false;
+struct ThrowScope {
+    bool prev;
+    ThrowScope() : prev(tl_throw_mode) { tl_throw_mode = true; }
+    ~ThrowScope() { tl_throw_mode = prev; }
+};
+inline void raise_status(int32_t& st, int32_t bit) {
+    if (tl_throw_mode) throw Termination{bit};
+    st |= bit;
+}
+
 struct LatLon { double phi = 0, lam = 0; };
 
 // geodesy.jl:62-69 : n-vector straight from q_ew

@@ -84,7 +84,7 @@ inline int32_t wa_f_ode(const double* x_kin, const double* u_vel, double* xdot_k
     const V3 w_eb_b = {u_vel[0], u_vel[1], u_vel[2]};
     const V3 v_eb_b = {u_vel[3], u_vel[4], u_vel[5]};
     const double h_e = x_kin[8];
-    if (!(h_e >= H_MIN)) st |= ST_ALT_RANGE;
+    if (!(h_e >= H_MIN)) raise_status(st, ST_ALT_RANGE);
 
     const double psi_nw = psi_nw_from_qew(q_ew);
     const Quat q_nw = Rz(psi_nw);
@@ -96,7 +96,7 @@ inline int32_t wa_f_ode(const double* x_kin, const double* u_vel, double* xdot_k
     const V3 n_e = nvector_from_qew(q_ew);
     const LatLon ll = latlon_from_nvector(n_e);
     const double h_o = h_orth_from_ellip(h_e, n_e);
-    if (!(h_o >= H_MIN)) st |= ST_ALT_RANGE;
+    if (!(h_o >= H_MIN)) raise_status(st, ST_ALT_RANGE);
 
     const V3 v_eb_n = rotate(q_nb, v_eb_b);
     const V3 r_eb_e = cartesian_from_geographic(n_e, h_e);
@@ -260,7 +260,7 @@ inline ISAData isa_data(double h_geop, ISAData sl, int32_t& st) {
         const double p_ceil = isa_p_law(h_ceil, g0, p_base, T_base, h_base, beta);
         h_base = h_ceil; T_base = T_ceil; p_base = p_ceil;
     }
-    st |= ST_ISA_RANGE;
+    raise_status(st, ST_ISA_RANGE);
     return {T_base, p_base};
 }
 
@@ -274,7 +274,7 @@ struct Env {              // SimpleWorld defaults: atmosphere.jl:75-78,165 ; ter
 };
 // atmosphere.jl:269-278 ; position given as (n_e, orthometric altitude)
 inline AtmData atmospheric_data(const Env& env, double h_o, int32_t& st) {
-    if (!(h_o >= H_MIN)) st |= ST_ALT_RANGE;
+    if (!(h_o >= H_MIN)) raise_status(st, ST_ALT_RANGE);
     const double h_g = h_geop_from_orth(h_o);
     const ISAData d = isa_data(h_g, {env.T_sl, env.p_sl}, st);
     AtmData a;

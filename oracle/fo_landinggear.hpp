@@ -78,7 +78,7 @@ inline int32_t strut_f_ode(const GearUnitParams& gp, const GearUnitU& gu, const 
     const V3 r_sw0_e = sp.l_0 * ks_e;
     const V3 r_ew0_e = kin.r_eb_e + r_bs_e + r_sw0_e;
     const GeoNE Ow0 = geographic_from_cartesian(r_ew0_e);
-    if (!(Ow0.h_e >= H_MIN)) st |= ST_ALT_RANGE;
+    if (!(Ow0.h_e >= H_MIN)) raise_status(st, ST_ALT_RANGE);
     const double he_Ow0 = Ow0.h_e;
 
     const V3 loc_Ot = Ow0.n_e;
@@ -141,7 +141,7 @@ inline int32_t strut_f_ode(const GearUnitParams& gp, const GearUnitU& gu, const 
 
     const V3 v_ec_dmp_c = ks_c * y.xi_dot;
     const V3 v_ec_c = v_ec_c_body + v_ec_dmp_c;
-    if (!(std::fabs(v_ec_c.z) < 1e-8)) st |= ST_CONTACT_ASSERT;
+    if (!(std::fabs(v_ec_c.z) < 1e-8)) raise_status(st, ST_CONTACT_ASSERT);
     y.v_ec_xy[0] = v_ec_c.x; y.v_ec_xy[1] = v_ec_c.y;
     y.surface = env.surface;
     return st;
@@ -149,8 +149,8 @@ inline int32_t strut_f_ode(const GearUnitParams& gp, const GearUnitU& gu, const 
 // landinggear.jl:331-347
 inline int32_t strut_f_step(const StrutY& y) {
     int32_t st = 0;
-    if (y.wow && rad2deg(y.alpha_ts) > 60) st |= ST_GROUND_CRASH;
-    if (-y.xi_dot > 10) st |= ST_GROUND_CRASH;
+    if (y.wow && rad2deg(y.alpha_ts) > 60) raise_status(st, ST_GROUND_CRASH);
+    if (-y.xi_dot > 10) raise_status(st, ST_GROUND_CRASH);
     return st;
 }
 // landinggear.jl:411-476. x_frc[2]

@@ -85,8 +85,10 @@ inline void r2_init(const R2Vehicle& p, double u_m, double w, double eta, double
 }
 // nsteps x step!(sim): RK4, then f_step! (LostBalance), then f_periodic! when the step count hits a multiple of ratio.
 // step0 = number of steps already taken since init (the periodic counter must persist across calls).
+// LostBalance is thrown by f_step! (cb_step) right after the RK update of step k: the simulation ends with x = x_k, before that step's
+// f_periodic! (sim.jl:204-218, 561-570); *term_k = the number of RK updates completed (step0 + k).
 inline int32_t r2_step(const R2Vehicle& p, const R2Gains& g, double dt, int ratio, bool with_controller, const double* u, double* r,
-                       int64_t step0, int64_t nsteps) {
+                       int64_t step0, int64_t nsteps, int64_t* term_k = nullptr) {
     int32_t st = 0;
     for (int64_t k = 1; k <= nsteps && st == 0; k++) {
         double k1[4], k2[4], k3[4], k4[4], xt[4];
@@ -99,7 +101,7 @@ inline int32_t r2_step(const R2Vehicle& p, const R2Gains& g, double dt, int rati
         r2_f_ode(p, xt, r[4], k4);
         for (int i = 0; i < 4; i++) r[i] = r[i] + (dt / 6) * (2 * (k2[i] + k3[i]) + (k1[i] + k4[i]));
         if (with_controller) {
-            if (std::fabs(r[2]) > 45 * (3.14159265358979323846 / 180)) st |= R2_ST_LOST_BALANCE;  // robot2d.jl:553-561
+            if (std::fabs(r[2]) > 45 * (3.14159265358979323846 / 180)) { st |= R2_ST_LOST_BALANCE; if (term_k) *term_k = step0 + k; }  // robot2d.jl:553-561
             if (st == 0 && ((step0 + k) % ratio) == 0) r2_f_periodic(p, g, dt * ratio, u, r);
         }
     }

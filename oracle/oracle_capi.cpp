@@ -163,7 +163,10 @@ int32_t fo_c172_f_step(int64_t n, double* x, const double* u, const int32_t* ui,
         const C172Inputs in = inputs_from(u, ui, n, i);
         C172Y Y;
         int32_t st = c172_f_ode(*g_model, e, in, d, xi, xd, Y);
-        st |= c172_f_step(*g_model, in, d, xi, Y);
+        try {   // f_step! stops at its first exception (GroundCrash): what precedes it in the reference's order has been applied
+            ThrowScope throwing;
+            c172_f_step(*g_model, in, d, xi, Y);
+        } catch (const Termination& t) { st |= t.bit; }
         for (int k = 0; k < NX; k++) x[k * n + i] = xi[k];
         s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
         if (status) status[i] |= st;
@@ -173,8 +176,12 @@ int32_t fo_c172_f_step(int64_t n, double* x, const double* u, const int32_t* ui,
 // nsteps x step!(sim). threads <= 0: all OpenMP threads. reference_like != 0: 6 RHS evaluations per
 // step as OrdinaryDiffEq does with a u-modifying callback; 0: skip the redundant 6th.
 // traj (optional): [n x NX x n_saved] states saved every save_every steps (incl. step 0 when save_every>0).
-int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
-                     int64_t nsteps, int32_t* status, int32_t threads, int32_t reference_like, double* traj, int64_t save_every) {
+// An aircraft whose status word is non-zero on entry is left alone (its simulation has ended). An aircraft that terminates
+// during the call stops there (sim.jl:561-570): x / s = mdl.x / mdl.s at the throw, status = the exception's bit, and — when given —
+// term_step[i] = step0 + the number of RK updates it had completed, term_where[i] = FB_TERM_* (include/flightbatch.h).
+static int32_t c172_step_many(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
+                              int64_t nsteps, int32_t* status, int32_t threads, int32_t reference_like, double* traj, int64_t save_every,
+                              int64_t step0, int64_t* term_step, int32_t* term_where) {
     const Env e = env_from(env);
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
@@ -187,11 +194,18 @@ int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, i
         d.stall = s[FB_S_STALL * n + i] != 0; d.eng_state = s[FB_S_ENG_STATE * n + i];
         const C172Inputs in = inputs_from(u, ui, n, i);
         C172Y Y;
-        int32_t st = 0;
+        int32_t st = status ? status[i] : 0;
         int64_t slot = 0;
         if (traj && save_every > 0) { for (int k = 0; k < NX; k++) traj[(slot * NX + k) * n + i] = xi[k]; slot++; }
         for (int64_t t = 0; t < nsteps; t++) {
-            st |= c172_step(*g_model, e, in, d, xi, dt, Y, nullptr, reference_like != 0);
+            if (st == 0) {
+                Term tm;
+                st = c172_step(*g_model, e, in, d, xi, dt, Y, nullptr, reference_like != 0, &tm);
+                if (st != 0) {
+                    if (term_step) term_step[i] = step0 + t + (tm.advanced ? 1 : 0);
+                    if (term_where) term_where[i] = tm.where;
+                }
+            }
             if (traj && save_every > 0 && ((t + 1) % save_every == 0)) {
                 for (int k = 0; k < NX; k++) traj[(slot * NX + k) * n + i] = xi[k];
                 slot++;
@@ -199,9 +213,17 @@ int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, i
         }
         for (int k = 0; k < NX; k++) x[k * n + i] = xi[k];
         s[FB_S_STALL * n + i] = d.stall; s[FB_S_ENG_STATE * n + i] = d.eng_state;
-        if (status) status[i] |= st;
+        if (status) status[i] = st;
     }
     return 0;
+}
+int32_t fo_c172_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
+                     int64_t nsteps, int32_t* status, int32_t threads, int32_t reference_like, double* traj, int64_t save_every) {
+    return c172_step_many(n, x, u, ui, s, env, dt, nsteps, status, threads, reference_like, traj, save_every, 0, nullptr, nullptr);
+}
+int32_t fo_c172_step_term(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
+                          int64_t step0, int64_t nsteps, int32_t* status, int64_t* term_step, int32_t* term_where, int32_t threads) {
+    return c172_step_many(n, x, u, ui, s, env, dt, nsteps, status, threads, 1, nullptr, 0, step0, term_step, term_where);
 }
 // diagnostics of the trim solver (tests only): 0 = descent from the initial guess only, 1 = with the continuation fallback
 static int g_trim_continuation = 1;
@@ -326,8 +348,8 @@ int32_t fo_robot2d_f_ode(int64_t n, const double* vp, const double* r, double* x
     }
     return 0;
 }
-int32_t fo_robot2d_step(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
-                        const double* u /*[4 x n]*/, double* r /*[10 x n]*/, int64_t step0, int64_t nsteps, int32_t* status) {
+static int32_t robot2d_step_many(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
+                                 const double* u /*[4 x n]*/, double* r /*[10 x n]*/, int64_t step0, int64_t nsteps, int32_t* status, int64_t* term_step) {
     const R2Vehicle v = r2_vehicle(vp);
     const R2Gains g = r2_gains(gp);
 #ifdef _OPENMP
@@ -337,11 +359,21 @@ int32_t fo_robot2d_step(int64_t n, const double* vp, const double* gp, double dt
         double ri[10], ui[4];
         for (int k = 0; k < 10; k++) ri[k] = r[k * n + i];
         for (int k = 0; k < 4; k++) ui[k] = u[k * n + i];
-        const int32_t st = (status && status[i]) ? status[i] : r2_step(v, g, dt, ratio, with_controller != 0, ui, ri, step0, nsteps);
+        int64_t tk = -1;
+        const int32_t st = (status && status[i]) ? status[i] : r2_step(v, g, dt, ratio, with_controller != 0, ui, ri, step0, nsteps, &tk);
         for (int k = 0; k < 10; k++) r[k * n + i] = ri[k];
         if (status) status[i] |= st;
+        if (term_step && tk >= 0) term_step[i] = tk;
     }
     return 0;
+}
+int32_t fo_robot2d_step(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
+                        const double* u /*[4 x n]*/, double* r /*[10 x n]*/, int64_t step0, int64_t nsteps, int32_t* status) {
+    return robot2d_step_many(n, vp, gp, dt, ratio, with_controller, u, r, step0, nsteps, status, nullptr);
+}
+int32_t fo_robot2d_step_term(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
+                             const double* u, double* r, int64_t step0, int64_t nsteps, int32_t* status, int64_t* term_step) {
+    return robot2d_step_many(n, vp, gp, dt, ratio, with_controller, u, r, step0, nsteps, status, term_step);
 }
 
 // ============================ known-answer test helpers ======================================
@@ -640,10 +672,11 @@ int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double
     }
     return 0;
 }
-// nsteps x step!(sim) with the control laws every `ratio` steps (step0 = steps already taken since init).
-int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
-                      const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
-                      int32_t threads, double* traj, int64_t save_every) {
+// nsteps x step!(sim) with the control laws every `ratio` steps (step0 = steps already taken since init). Termination as in
+// fo_c172_step_term; term_step / term_where may be NULL.
+static int32_t c172x_step_many(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
+                               const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
+                               int32_t threads, double* traj, int64_t save_every, int64_t* term_step, int32_t* term_where) {
     const Env e = env_from(env);
     CtlGains G; G.bind(blob);
 #ifdef _OPENMP
@@ -663,7 +696,14 @@ int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, 
         int64_t slot = 0;
         if (traj && save_every > 0) { for (int k = 0; k < NXX; k++) traj[(slot * NXX + k) * n + i] = xi[k]; slot++; }
         for (int64_t t = 0; t < nsteps; t++) {
-            if (st == 0) st |= c172x_step(*g_model, G, e, in, cui, csi, d, xi, dt, dt * ratio, ((step0 + t + 1) % ratio) == 0, Y);
+            if (st == 0) {
+                Term tm;
+                st = c172x_step(*g_model, G, e, in, cui, csi, d, xi, dt, dt * ratio, ((step0 + t + 1) % ratio) == 0, Y, &tm);
+                if (st != 0) {
+                    if (term_step) term_step[i] = step0 + t + (tm.advanced ? 1 : 0);
+                    if (term_where) term_where[i] = tm.where;
+                }
+            }
             if (traj && save_every > 0 && ((t + 1) % save_every == 0)) {
                 for (int k = 0; k < NXX; k++) traj[(slot * NXX + k) * n + i] = xi[k];
                 slot++;
@@ -676,6 +716,16 @@ int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, 
         if (status) status[i] = st;
     }
     return 0;
+}
+int32_t fo_c172x_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
+                      const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
+                      int32_t threads, double* traj, int64_t save_every) {
+    return c172x_step_many(n, x, u, ui, s, cu, cs, env, blob, dt, ratio, step0, nsteps, status, threads, traj, save_every, nullptr, nullptr);
+}
+int32_t fo_c172x_step_term(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
+                           const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
+                           int64_t* term_step, int32_t* term_where, int32_t threads) {
+    return c172x_step_many(n, x, u, ui, s, cu, cs, env, blob, dt, ratio, step0, nsteps, status, threads, nullptr, 0, term_step, term_where);
 }
 // f_ode!(world) of the X model: xdot [34 x n], y as Cessna172Sv0
 int32_t fo_c172x_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* cs, const double* env,

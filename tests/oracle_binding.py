@@ -92,6 +92,18 @@ class Oracle:
             return x, s, st, traj
         return x, s, st
 
+    def step_term(self, x, u, ui, s, env, dt, nsteps, step0=0, status=None, threads=0):
+        """nsteps x step!(sim) with the reference's termination semantics spelled out: returns x, s, status, term_step, term_where
+        (term_step -1 / term_where 0 for the aircraft still running)."""
+        n = x.shape[1]
+        x = np.array(x, dtype=np.float64, order="C"); s = np.array(s, dtype=np.int32, order="C")
+        u = np.ascontiguousarray(u); ui = np.ascontiguousarray(ui, dtype=np.int32)
+        st = np.zeros(n, np.int32) if status is None else np.array(status, dtype=np.int32)
+        tstep = np.full(n, -1, np.int64); twhere = np.zeros(n, np.int32)
+        self.lib.fo_c172_step_term(C.c_int64(n), _p(x), _p(u), _p(ui), _p(s), _p(env), C.c_double(dt), C.c_int64(step0), C.c_int64(nsteps),
+                                   _p(st), tstep.ctypes.data_as(C.POINTER(C.c_int64)), _p(twhere), C.c_int32(threads))
+        return x, s, st, tstep, twhere
+
     def trim(self, tp, ts, env, threads=0):
         n = tp.shape[1]
         tp = np.ascontiguousarray(tp); ts = np.array(ts, dtype=np.float64, order="C")
@@ -132,6 +144,19 @@ class OracleX:
                                C.c_int32(threads), _p(traj), C.c_int64(save_every))
         st["nstep"] += nsteps
         return traj
+
+    def step_term(self, st, env, dt, ratio, nsteps, threads=0):
+        """like step(), and records where each aircraft's simulation ended in st["term_step"] / st["term_where"]."""
+        n = st["x"].shape[1]
+        for k in ("x", "u", "cu", "cs"):
+            st[k] = np.ascontiguousarray(st[k], dtype=np.float64)
+        st["ui"] = np.ascontiguousarray(st["ui"], dtype=np.int32); st["s"] = np.ascontiguousarray(st["s"], dtype=np.int32)
+        st.setdefault("status", np.zeros(n, np.int32)); st.setdefault("nstep", 0)
+        st.setdefault("term_step", np.full(n, -1, np.int64)); st.setdefault("term_where", np.zeros(n, np.int32))
+        self.lib.fo_c172x_step_term(C.c_int64(n), _p(st["x"]), _p(st["u"]), _p(st["ui"]), _p(st["s"]), _p(st["cu"]), _p(st["cs"]), _p(env),
+                                    _p(self.blob), C.c_double(dt), C.c_int32(ratio), C.c_int64(st["nstep"]), C.c_int64(nsteps), _p(st["status"]),
+                                    st["term_step"].ctypes.data_as(C.POINTER(C.c_int64)), _p(st["term_where"]), C.c_int32(threads))
+        st["nstep"] += nsteps
 
     def f_ode(self, st, env):
         n = st["x"].shape[1]

@@ -51,3 +51,14 @@ def test_blocks_without_an_exec_restore_are_not_join_blocks(tmp_path):
 
 def test_agpr_move_in_the_middle_of_a_block_is_not_spill_placement(tmp_path):    # (only head-of-block AGPR writes count)
     assert _scan(tmp_path, ".LBB0_2:\n\tv_fma_f64 v[0:1], v[2:3], v[4:5], v[0:1]\n\tv_accvgpr_write_b32 a3, v0\n\ts_or_b64 exec, exec, s[2:3]\n") == []
+
+
+def test_the_other_ways_of_re_enabling_lanes_count_as_exec_restores(tmp_path):
+    """`s_or_saveexec_b64` / `s_xor_b64 exec, exec` (the else point of an if-else) and `s_mov_b64 exec, s[..]` (loop exits) bring lanes
+    back just like `s_or_b64 exec, exec`: spill code in front of them is lane-incomplete in the same way."""
+    spill = "\tscratch_store_dword off, v7, off offset:24 ; 4-byte Folded Spill\n"
+    for restore in ("s_or_saveexec_b64 s[8:9], s[8:9]", "s_xor_b64 exec, exec, s[8:9]", "s_mov_b64 exec, s[8:9]"):
+        bad = _scan(tmp_path, ".LBB0_11:\n" + spill + "\t" + restore + "\n\tv_mov_b32_e32 v1, v2\n")
+        assert len(bad) == 1, restore
+    # an instruction that only takes lanes away is not a restore
+    assert _scan(tmp_path, ".LBB0_12:\n" + spill + "\ts_and_saveexec_b64 s[8:9], vcc\n\ts_cbranch_execz .LBB0_13\n") == []

@@ -19,7 +19,9 @@ import sys
 
 SPILL = re.compile(r"^\s*(v_accvgpr_write_b32\s+a\d+,\s*v\d+|scratch_store_dword\w*\s.*Spill)")
 RELOAD = re.compile(r"^\s*scratch_load_dword\w*\s+(v\[?\d+)(?::\d+\])?,.*Reload")
-EXEC_RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
+# every way this compiler re-enables lanes at a join / else point: `s_or_b64 exec, exec, s[..]` (end of an if), `s_or_saveexec_b64 s[..], s[..]`
+# and `s_xor_b64 exec, exec, s[..]` (the else point: the other branch's lanes come on), a plain `s_mov_b64 exec, s[..]` (loop exits)
+EXEC_RESTORE = re.compile(r"^\s*(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64\s|s_xor_b64\s+exec,\s*exec,|s_mov_b64\s+exec,\s*s\[)")
 LABEL = re.compile(r"^(\.LBB\d+_\d+|_Z\w+):")
 BRANCH = re.compile(r"^\s*s_c?branch")
 IGNORE = re.compile(r"^\s*(;|$|\.)")

@@ -1,8 +1,9 @@
 #!/bin/bash
 mkdir -p /tmp/w
 # compile the device code to ISA and summarise the wave-specialised stepper: registers, scratch, spill ops between barriers, spill check
-cd /root/repo/flight.jl_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -freciprocal-math -fapprox-func -fno-hip-fp32-correctly-rounded-divide-sqrt -mllvm -disable-machine-licm -fPIC "$@" -S --cuda-device-only -o /tmp/w/duo.s fb_capi.hip 2>&1 | grep -v "argument unused" | head -30
-cd /root/repo
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+python3 "$ROOT/__graft_entry__.py" --asm /tmp/w/duo.s "$@" 2>&1 | grep -v "argument unused" | head -30
+cd "$ROOT"
 K=_ZN3fbd10k_step_duoILi0EEEvNS_5KArgsEi
 awk "/\.amdhsa_kernel $K/,/\.end_amdhsa_kernel/" /tmp/w/duo.s | grep -E "next_free_vgpr|accum_offset|private_segment_fixed|group_segment"
 awk "/^$K:/,/\.end_amdhsa_kernel/" /tmp/w/duo.s > /tmp/w/duo_k.s

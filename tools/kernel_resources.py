@@ -1,5 +1,11 @@
-"""Registers, scratch and LDS of every kernel in a device-assembly file (hipcc -S --cuda-device-only).   python tools/kernel_resources.py file.s"""
-import re, subprocess, sys
+"""Registers, scratch and LDS of every kernel in a device-assembly file.   python tools/kernel_resources.py [file.s]
+Without an argument the assembly is produced first (python __graft_entry__.py --asm: the shipped build's flags)."""
+import os, re, subprocess, sys
+if len(sys.argv) < 2:
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs("/tmp/w", exist_ok=True)
+    subprocess.run([sys.executable, os.path.join(root, "__graft_entry__.py"), "--asm", "/tmp/w/lib.s"], check=True)
+    sys.argv.append("/tmp/w/lib.s")
 s = open(sys.argv[1]).read()
 for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', s, re.S):
     name, body = m.group(1), m.group(2)

@@ -23,14 +23,18 @@ xg, sg, stg = w.x, w.s, w.status
 idx = np.sort(rng.choice(n, n_or, replace=False))
 orc = Oracle()
 t0 = time.time()
-xo, so, sto = orc.step(x0[:, idx], u0[:, idx], ui0[idx], s0[:, idx], orc.default_env(), 0.01, 10000)
+xo, so, sto, tso, two = orc.step_term(x0[:, idx], u0[:, idx], ui0[idx], s0[:, idx], orc.default_env(), 0.01, 10000)
 print("oracle: %d aircraft x 10000 steps in %.1f s" % (n_or, time.time() - t0), flush=True)
+# the oracle stops an aircraft where the reference stops it (FC/sim.jl:561-570); the GPU must agree on the status WORD, on the step and
+# the place of the termination, and on the frozen state — terminated aircraft are compared like the rest
+tsg, twg = w.termination
 mis = np.nonzero(stg[idx] != sto)[0]
-print("status mismatches: %d; GPU bits %s, oracle bits %s; final h_e (oracle) there: %s" % (len(mis), stg[idx][mis][:10].tolist(), sto[mis][:10].tolist(), np.round(xo[20, mis][:10], 1).tolist()))
+print("status mismatches: %d; GPU bits %s, oracle bits %s" % (len(mis), stg[idx][mis][:10].tolist(), sto[mis][:10].tolist()))
+print("termination step mismatches: %d; place mismatches: %d" % (int((tsg[idx] != tso).sum()), int((twg[idx] != two).sum())))
 print("status histogram GPU (all): %s" % dict(zip(*np.unique(stg, return_counts=True))))
-live = (sto == 0) & (stg[idx] == 0)
+term = sto != 0
 err = np.abs(xg[:, idx] - xo) / np.maximum(np.abs(xo), 1.0)
-# (the GPU freezes an aircraft at its first termination bit; the oracle's loop steps on and collects further bits: compare "terminated or not")
-print("terminated-or-not equal: %s; terminated: GPU %d of %d, oracle %d of %d" % (np.array_equal(stg[idx] != 0, sto != 0), int((stg != 0).sum()), n, int((sto != 0).sum()), n_or))
-print("max scaled |x_gpu - x_oracle| after 10000 steps over %d live aircraft: %.3e (row %d)" % (int(live.sum()), err[:, live].max(), int(err[:, live].max(axis=1).argmax())))
+print("terminated: GPU %d of %d, oracle %d of %d (places %s)" % (int((stg != 0).sum()), n, int(term.sum()), n_or, dict(zip(*np.unique(two[term], return_counts=True)))))
+print("max scaled |x_gpu - x_oracle| after 10000 steps: %.3e over the %d aircraft still flying (row %d), %.3e over the %d terminated ones; discrete states equal: %s"
+      % (err[:, ~term].max(), int((~term).sum()), int(err[:, ~term].max(axis=1).argmax()), err[:, term].max() if term.any() else 0.0, int(term.sum()), np.array_equal(sg[:, idx], so)))
 q = xg[12:16]; print("max | |q_wb| - 1 | = %.2e; non-finite states: %d" % (np.abs(np.sqrt((q ** 2).sum(0)) - 1).max(), int((~np.isfinite(xg)).sum())))

@@ -35,17 +35,19 @@ for same_grid in ("1", "0"):
         o["status"] = np.zeros(n, np.int32); o["nstep"] = 0
         o["cu"] = np.ascontiguousarray(o["cu"]); o["cu"][:] = cu
         o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
-        t0 = time.time(); X.step(o, env, DT, 2, 10000, threads=min(orc.max_threads(), bench.usable_cores()))
+        t0 = time.time(); X.step_term(o, env, DT, 2, 10000, threads=min(orc.max_threads(), bench.usable_cores()))
         print("oracle: %d aircraft x 10000 closed-loop steps in %.1f s" % (n, time.time() - t0), flush=True)
         ref = o
     t0 = time.time(); fb.step(sim, 100.0); w.sync()
     print("GPU (same_grid=%s): %d aircraft x 10000 steps in %.2f s" % (same_grid, n, time.time() - t0), flush=True)
-    ok = (w.status == 0) & (ref["status"] == 0)
+    term = ref["status"] != 0      # terminated aircraft are compared like the rest: frozen where the reference stops (FC/sim.jl:561-570)
+    tsg, twg = w.termination
     sc = np.ones_like(ref["x"]); sc[:27] = bench.state_floor(ref["x"][:27])
-    err = (np.abs(w.x - ref["x"][perm]) / sc[perm])[:, ok]
-    cerr = (np.abs(w.cs - ref["cs"]) / np.maximum(np.abs(ref["cs"]), 1.0))[:, ok]
-    print("  terminated-or-not equal: %s (GPU %d, oracle %d of %d); max scaled |x_gpu - x_oracle| after 10000 steps over %d live aircraft: %.3e (row %d); "
-          "control-law record: %.3e; modes equal: %s" % (np.array_equal(w.status != 0, ref["status"] != 0), int((w.status != 0).sum()), int((ref["status"] != 0).sum()), n,
-                                                         int(ok.sum()), err.max(), int(err.max(axis=1).argmax()), cerr.max(),
-                                                         np.array_equal(w.cs[K["FB_CS_LON_MODE"], ok], ref["cs"][K["FB_CS_LON_MODE"], ok])), flush=True)
+    err = np.abs(w.x - ref["x"][perm]) / sc[perm]
+    cerr = np.abs(w.cs - ref["cs"]) / np.maximum(np.abs(ref["cs"]), 1.0)
+    print("  status mismatches: %d (terminated: GPU %d, oracle %d of %d); termination step / place mismatches: %d / %d; max scaled |x_gpu - x_oracle| after 10000 steps: "
+          "%.3e over %d flying (row %d), %.3e over the terminated; control-law record: %.3e; modes equal: %s"
+          % (int((w.status != ref["status"]).sum()), int((w.status != 0).sum()), int(term.sum()), n, int((tsg != ref["term_step"]).sum()), int((twg != ref["term_where"]).sum()),
+             err[:, ~term].max(), int((~term).sum()), int(err[:, ~term].max(axis=1).argmax()), err[:, term].max() if term.any() else 0.0, cerr.max(),
+             np.array_equal(w.cs[K["FB_CS_LON_MODE"]], ref["cs"][K["FB_CS_LON_MODE"]])), flush=True)
     w.close()

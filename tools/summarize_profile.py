@@ -18,7 +18,9 @@ for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
                 dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 mean = lambda v: sum(v) / len(v) if v else None
 S = {k: {c: mean(v) for c, v in d.items()} for k, d in ctr.items()}
-res = {"n": N, "inner": INNER, "tag": tag, "counters_k_step_mean_per_launch": S["k_step"], "counters_k_f_ode": S["k_f_ode"]}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as _ge   # source_hash(): the code these counters were measured on (bench.py refuses a stale file)
+res = {"n": N, "inner": INNER, "tag": tag, "source_hash": _ge.source_hash(), "counters_k_step_mean_per_launch": S["k_step"], "counters_k_f_ode": S["k_f_ode"]}
 # calibration on k_f_ode (known byte counts): reads x 27*8 + u 16*8 + ui 4 + s 8 + status 4; writes y 174*8 + xdot 27*8 + status 4
 known_rd, known_wr = N * (216 + 128 + 4 + 8 + 4), N * (1392 + 216 + 4)
 fo = S["k_f_ode"]
@@ -40,6 +42,12 @@ if ks.get("SQ_INSTS_VALU_FMA_F64"):
     res["fp64_flops_per_launch"] = flops
     res["fp64_flops_per_aircraft_step"] = flops / (N * INNER)
     res["valu_insts_per_aircraft_step"] = ks["SQ_INSTS_VALU"] * 64 / (N * INNER)   # SQ_INSTS_VALU counts per wave; one lane = one aircraft
+if ks.get("SQ_ACTIVE_INST_VALU") and ks.get("SQ_BUSY_CYCLES"):
+    # SQ_ACTIVE_INST_VALU: cycles (summed over the chip's SIMDs, in units of 4 clocks) with a VALU instruction in flight; SQ_BUSY_CYCLES: per
+    # shader engine. Reported as measured; the busy fraction quoted in DESIGN.md comes from SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time).
+    res["valu_active_over_busy"] = ks["SQ_ACTIVE_INST_VALU"] / ks["SQ_BUSY_CYCLES"]
 res["k_step_mean_ns_under_pmc"] = mean(dur["k_step"])
+if ks.get("SQ_INSTS_VALU") and res["k_step_mean_ns_under_pmc"]:
+    res["valu_busy"] = ks["SQ_INSTS_VALU"] * 4 / 1024 / (2.4e9 * res["k_step_mean_ns_under_pmc"] * 1e-9)   # issue cycles / available SIMD cycles at 2.4 GHz
 json.dump(res, open(os.path.join(summ, f"{tag}_counters.json"), "w"), indent=1)
 print(json.dumps({k: res.get(k) for k in ("hbm_bytes_per_launch", "fp64_flops_per_aircraft_step", "calibration", "k_step_mean_ns_under_pmc")}, indent=1))
