@@ -33,7 +33,8 @@ def load_egm96(path: str | None = None) -> np.ndarray:
     """721 x 1441 float32 geoid heights, returned in Julia (column-major) memory order as a flat-compatible
     Fortran array ``A[lat, lon]`` (geodesy.jl:163-185)."""
     path = path or os.path.join(_DATA_DIR, "ww15mgh_le.bin")
-    raw = open(path, "rb").read()
+    with open(path, "rb") as f:
+        raw = f.read()
     if hashlib.sha256(raw).hexdigest() != EGM96_SHA256:
         raise ValueError("Wrong file hash")  # geodesy.jl:170
     return np.frombuffer(raw, dtype="<f4").reshape((721, 1441), order="F").copy(order="F")

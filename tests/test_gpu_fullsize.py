@@ -75,3 +75,67 @@ def test_config1_identical_trim_stays_identical(fb, oracle):
     err = np.abs(x[:, :1] - xo) / state_scale(xo)
     assert err.max() < 1e-6, err.max()
     w.close()
+
+
+def test_config3_per_gpu_share_xv2_autopilot(fb, oracle):
+    """BASELINE.json configs[3] at its per-GPU size: N = 524 288 Cessna172Xv2, dt = 0.01, autopilot every 2 steps (Δt = 0.02), the
+    README example 2 scenario (wind N 1 / E 0.5 m/s, EAS + climb-rate mode with clm_ref = 2 m/s, bank + sideslip mode with φ_ref = 30°)
+    flown from bench.py's randomised-trim lattice for 10 s: size-independent invariants on ALL aircraft, a 512-aircraft stratified
+    sample against the CPU oracle at 1e-6, and big batch == small batch bit for bit."""
+    import bench
+    from oracle_binding import OracleX
+    from test_gpu_c172x import ref_to_dev_rows, x_scale
+    K = fb.K
+    n = bench.N_TOTAL // 2
+    EAS, h, psi, cell = bench.lattice(3, n)
+    gains = fb.ctl_gains.ctl_gains_blob()
+    wind = (1.0, 0.5, 0.0)
+    w = fb.Cessna172Xv2World(n, gains=gains)
+    w.set_params(wind_ned=wind)
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    tp = fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi)
+    fb.init(sim, tp)
+    assert w.trim_success.all(), f"{(~w.trim_success).sum()} aircraft failed to trim"
+    w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+    w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+    x0, s0, u0, ui0, cu0, cs0 = w.x, w.s, w.u, w.ui, w.cu, w.cs
+    for _ in range(20):
+        fb.step(sim, 0.5)
+    w.sync()
+    x1, s1, st, cs1 = w.x, w.s, w.status, w.cs
+    perm = ref_to_dev_rows(K)                     # C ABI row -> oracle / device row
+    row = {k: int(np.where(perm == k)[0][0]) for k in (8, 12, 16, 20)}
+    # ---- invariants on ALL 524 288 aircraft
+    assert (st == 0).all(), f"{(st != 0).sum()} aircraft terminated"
+    assert np.isfinite(x1).all() and np.isfinite(cs1).all()
+    assert (x1[row[8]] < x0[row[8]]).all(), "fuel must strictly decrease on every aircraft"
+    for r0 in (row[12], row[16]):
+        q = x1[r0:r0 + 4]
+        assert np.abs(np.sqrt((q * q).sum(0)) - 1.0).max() <= 1e-8 * (1 + 1e-6)
+    assert (s1[1] == 2).all()
+    assert (cs1[K["FB_CS_LON_MODE"]] == float(fb.ModeControlLon.EAS_clm)).all() and (cs1[K["FB_CS_LAT_MODE"]] == float(fb.ModeControlLat.φ_β)).all()
+    climbed = x1[row[20]] - x0[row[20]]
+    assert climbed.min() > 8.0 and climbed.max() < 25.0, (climbed.min(), climbed.max())     # 2 m/s demanded for 10 s, minus the capture transient
+    # ---- the stratified sample (one aircraft out of every second (EAS, h) cell, drawn over the whole permuted order) against the oracle
+    sel = bench.stratified_sample(cell, per_cell=1)[::2]
+    assert sel.size == 512 and sel.max() > n - n // 32 and sel.min() < n // 32
+    X = OracleX(oracle, gains)
+    env = oracle.default_env(wind=wind)
+    o = dict(x=np.empty((34, sel.size)), u=np.ascontiguousarray(u0[:, sel]), ui=np.ascontiguousarray(ui0[sel]), s=np.ascontiguousarray(s0[:, sel]),
+             cu=np.ascontiguousarray(cu0[:, sel]), cs=np.ascontiguousarray(cs0[:, sel]), status=np.zeros(sel.size, np.int32), nstep=0)
+    o["x"][perm] = x0[:, sel]
+    X.step(o, env, 0.01, 2, 1000, threads=min(oracle.max_threads(), bench.usable_cores()))
+    assert (o["status"] == 0).all() and np.array_equal(o["s"], s1[:, sel])
+    err = np.abs(x1[:, sel] - o["x"][perm]) / x_scale(o["x"])[perm]
+    cerr = np.abs(cs1[:, sel] - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)
+    print("configs[3] at N = 524 288 per GPU: max scaled error of 512 stratified aircraft after 1000 closed-loop steps: %.3e (control-law record %.3e)" % (err.max(), cerr.max()))
+    assert err.max() < 1e-6 and cerr.max() < 1e-6
+    # ---- results do not depend on batch size / lane position
+    w2 = fb.Cessna172Xv2World(sel.size, gains=gains)
+    w2.set_params(wind_ned=wind)
+    sim2 = fb.Simulation(w2, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    w2.set_state(np.ascontiguousarray(x0[:, sel]), np.ascontiguousarray(s0[:, sel])); w2.u = np.ascontiguousarray(u0[:, sel]); w2.ui = np.ascontiguousarray(ui0[sel])
+    w2.cu = np.ascontiguousarray(cu0[:, sel]); w2.cs = np.ascontiguousarray(cs0[:, sel])
+    fb.step(sim2, 10.0); w2.sync()
+    assert np.array_equal(w2.x, x1[:, sel]) and np.array_equal(w2.cs, cs1[:, sel])
+    w2.close(); w.close()
