@@ -27,6 +27,25 @@
 
 namespace fbd {
 
+// Diagnostic builds (-DFB_STAMP -DFB_DUO_TIMELINE, tools/duo_timeline.py): when, counted from the moment the wave leaves the barrier at the
+// top of an evaluation, wave 0 (role P) and wave 4 (role D) of workgroup 0 pass the marked points of their evaluation — a two-row
+// Gantt chart of one SIMD (g_stamp_acc[k] role P, [16 + k] role D; no drains: a mark is one s_memtime and one lane's global add).
+#if defined(FB_STAMP) && defined(FB_DUO_TIMELINE)
+__device__ unsigned long long g_duo_t0[2];
+__device__ __forceinline__ void duo_mark(int role, int k) {
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler may not move work across a mark: what is attributed to an interval was issued in it)
+    if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (k == 0) g_duo_t0[role - 1] = t;
+        else { g_stamp_acc[(role == 1 ? 0 : 16) + k] += t - g_duo_t0[role - 1]; g_stamp_cnt[(role == 1 ? 0 : 16) + k] += 1; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define DUO_MARK(role, k) duo_mark(role, k)
+#else
+#define DUO_MARK(role, k) do { } while (0)
+#endif
+
 constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
 constexpr int XD_VP = XD_FP;   // role D -> role P before barrier A: the velocity at the propeller, in the rows that carry F_p after it
 
@@ -61,6 +80,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double h_o = h_e - N_geoid;
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         // ----- air data (atmosphere.jl:220-242) -----
+        DUO_MARK(1, 1);   // geoid done
         double T_air, p_air, lnp_air;
         const double h_gp = h_o * wgs::a / (wgs::a + h_o);   // geopotential altitude
         isa_data<true>(h_gp, env.T_sl, env.p_sl, T_air, p_air, lnp_air, st);
@@ -68,9 +88,15 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double rho = (p_air * (1 / isa::R)) * i_T;
         constexpr double sqrt_gR = 20.046795704052055;   // sqrt(1.4 * 287.05287)
         const double i_a_snd = (1 / sqrt_gR) * rs_T;
+        DUO_MARK(1, 2);   // ISA done
         emit.xput(XD_RHO, rho); emit.xput(XD_HO, h_o);
         if (st != 0) emit.xstatus(st);
+        DUO_MARK(1, 11);  // at A
         emit.xsync(1);   // ----- barrier A -----
+        DUO_MARK(1, 3);   // left A
+#ifdef FB_DUO_P_BOOST
+        __builtin_amdgcn_s_setprio(3);   // experiment: role D waits for the propeller wrench at barrier B
+#endif
 
         // ----- propeller (propellers.jl:405-452) -----
         const double w_prop = w_eng;  // gear ratio 1
@@ -93,6 +119,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             a_p = atan2m(v_p.z, v_p.x);
             b_p = atan2p(v_p.y, sqrt(v_p.x * v_p.x + v_p.z * v_p.z));
         }
+        DUO_MARK(1, 4);   // propeller coefficients and angles
         const double fr = w_prop / (2 * PI), fr2 = fr * fr;
         constexpr double d4 = prop_d * prop_d * prop_d * prop_d, d5 = d4 * prop_d;
         const double kF = rho * fr2 * d4, kM = rho * fr2 * d5;
@@ -101,7 +128,14 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const v3 tau_pb = tau_p + cross(r_p, F_p);
         emit.xput(XD_FP, F_p.x); emit.xput(XD_FP + 1, F_p.y); emit.xput(XD_FP + 2, F_p.z);
         emit.xput(XD_TAUP, tau_pb.x); emit.xput(XD_TAUP + 1, tau_pb.y); emit.xput(XD_TAUP + 2, tau_pb.z);
+        DUO_MARK(1, 5);   // wrench put
         emit.xput(XD_HROT, prop_Jxx * w_prop);
+#ifdef FB_DUO_B_EARLY
+        emit.xsync(2);   // ----- barrier B -----
+#endif
+#ifdef FB_DUO_P_BOOST
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
         // ----- engine (piston.jl:314-426) -----
         double out_frc, out_idle;
@@ -120,7 +154,11 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
         const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
         const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
+DUO_MARK(1, 6);   // at B
+        #ifndef FB_DUO_B_EARLY
         emit.xsync(2);   // ----- barrier B (role D has finished its aerodynamics by about now) -----
+#endif
+        DUO_MARK(1, 7);   // left B
         const double k_f = rsqrt(rho * (1 / isa::rho_std));
         const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
         const double f_run = mix_auto ? f_lean + mixture * (f_rich - f_lean) : k_f * (f_rich * (0.5 * (mixture + 1)));
@@ -134,6 +172,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double pi_wot = lerp2(PT + PT_PIWOT_V, 5, l_n5w, grid_locate<3, true>(PT + PT_PIWOT_D_K, RPT + PT_PIWOT_D_K, d_wot, true, false, gkp(LDS_PISTON + PT_PIWOT_D_K)));
         double pi_isa = (fabs(d_wot - 1) < 5e-3) ? pi_std : pi_std + (pi_wot - pi_std) / (d_wot - 1) * (delta - 1);
         pi_isa = fmax(pi_isa, 0.0);
+        DUO_MARK(1, 8);   // engine lookups
         const double pi_pow = pi_isa * (rt_theta * (isa_sqrt_T_std * rs_T));   // pi_isa (T_ISA / T)^1/2
         const double pi_act = pi_pow * pi_ratio;
         const double P_run = P_rated * pi_act;
@@ -143,10 +182,12 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double tau_shaft = eng_off ? out_frc * (0.01 * P_rated / w_rated) : (eng_starting ? tau_start : tau_run);
         const double mdot = eng_running ? SFC_run * P_run : 0.0;
         const double tau_load = tau_p.x;  // gear_ratio * τ_prop
+        DUO_MARK(1, 9);   // engine done
         emit(FB_X_ENG_OMEGA, (tau_shaft + tau_load) / (J_eng + prop_Jxx));
         // ----- fuel (c172.jl:607-616) -----
         (void)x_fuel;
         emit(FB_X_FUEL, -mdot / (m_full - m_res));
+        DUO_MARK(1, 10);   // end of role P's evaluation
         return st;
     } else {
         // ================================= role D =================================
@@ -167,6 +208,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
             emit.xput(XD_VP, v_p.x); emit.xput(XD_VP + 1, v_p.y); emit.xput(XD_VP + 2, v_p.z);
         }
+        DUO_MARK(2, 1);   // head, velocity at the propeller put
         const quat q_eb = qmul(q_ew, q_wb);
         const double x_fuel = x[FB_X_FUEL];   // (before barrier A: role P rewrites this row at the very end of its evaluation)
         const double TAS = norm(v_wb_b);
@@ -182,6 +224,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             beta = atan2p(v_wb_b.y, r);   // (TAS > 0.1: r and v_y are not both zero)
             if (r_ok) { cos_al = v_wb_b.x * ir; sin_al = v_wb_b.z * ir; }   // cos, sin of atan2(z, x) (atan2(0, 0) = 0)
         }
+        DUO_MARK(2, 2);   // airflow angles
         const double V = fmax(TAS, V_min);
         const double afd = 1 / tau_filt * (alpha - x[FB_X_ALPHA_FILT]);
         const double bfd = 1 / tau_filt * (beta - x[FB_X_BETA_FILT]);
@@ -195,6 +238,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const loc l_al2 = grid_locate<2, true>(A + AT_ALPHA2_K, RA + AT_ALPHA2_K, al, true, true, gkp(LDS_AERO + AT_ALPHA2_K));
         const loc l_be3 = grid_locate<3, true>(A + AT_CY_BETA_K, RA + AT_CY_BETA_K, be, true, true, gkp(LDS_AERO + AT_CY_BETA_K));
         const loc l_bu = grid_locate<3, true>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true, gkp(LDS_AERO + AT_UNIT3_K));
+        DUO_MARK(2, 3);   // knot locations
         const loc l_stall = {0, stall ? 1.0 : 0.0};
         const loc l_df4 = ac.l_df4, l_df2 = ac.l_df2;
         // the lookups on those axes alone
@@ -203,10 +247,12 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double cy_p = lerp2(A + AT_CY_P_V, 2, l_al2, l_df2), cy_r = lerp2(A + AT_CY_R_V, 2, l_al2, l_df2);
         const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
         const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
+        DUO_MARK(2, 4);   // at A
         emit.xsync(1);   // ----- barrier A -----
         const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         const double q_dyn = 0.5 * rho * (TAS * TAS);
+        DUO_MARK(2, 5);   // left A
 
         // ----- kinematics derivatives (kinematics.jl:181-242; geodesy.jl:125-129) -----
         // ----- radii of curvature (geodesy.jl:125-129), fuel mass, mass properties, gravity at the CoM: while role P works on the atmosphere -----
@@ -233,6 +279,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             emit_rows<4>(emit, KX, kq1);
             emit_rows<5>(emit, KX + 4, kq2);
         }
+        DUO_MARK(2, 6);   // kinematics rows emitted
         // ----- fuel mass, mass properties, gravity at the CoM -----
         const double m_fuel_total = m_res + x_fuel * (m_full - m_res);
         aux.m_avail = m_fuel_total - m_res;
@@ -244,6 +291,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const v3 g_c_c = gravity_com(q_eb, r_bc, n_e, h_e, R_N, R_E, i_RN, i_RE, st, d_e);
         const v3 w_ie_b = earth_rate_b(q_eb);
 
+        DUO_MARK(2, 7);   // mass properties, gravity
         // ----- aerodynamics, the rest (c172.jl:341-373, 226-245) -----
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
         const double dh_nd = (h_o - env.h_trn) / b;
@@ -265,10 +313,12 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         aux.wow = 0;
         aux.crash = 0;
         if (!(fmin(h_o - env.h_trn, h_e - H_MIN) > 10.0)) st |= FB_ST_INTERNAL_REDO;   // (within reach of the ground, or of the altitude floor: rhs(), "high-clearance shortcut")
+        DUO_MARK(2, 8);   // aerodynamics done, at B
         emit.xsync(2);   // ----- barrier B -----
         const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
         const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
         const v3 h_rot = {emit.xget(XD_HROT), 0.0, 0.0};
+        DUO_MARK(2, 9);   // left B
         // ----- rigid-body dynamics at the CoM (dynamics.jl:443-525), as in rhs() -----
         const v3 F_b = F_a + F_p;
         const v3 tau_b = tau_a + tau_pb;
@@ -287,8 +337,10 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
                        (c13 * rhs_w.x + c23 * rhs_w.y + c33 * rhs_w.z) * idet};
         const v3 vd_c = iM * F_c + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
         const v3 vd_b = vd_c - cross(wd, r_bc);
+        DUO_MARK(2, 10);   // dynamics
         const double kd6[6] = {wd.x, wd.y, wd.z, vd_b.x, vd_b.y, vd_b.z};
         emit_rows<6>(emit, FB_X_OMEGA_EB_B, kd6);
+        DUO_MARK(2, 11);   // end of role D's evaluation
         return st;
     }
 }

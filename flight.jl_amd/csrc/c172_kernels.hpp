@@ -952,6 +952,18 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
     int* ctrl_l = (int*)&rk[LDS_ATAN + ATAN_N];   // one control word per wave pair (the LDS is full to the last 16 bytes)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) + 1;   // 1: P (waves 0-3), 2: D (waves 4-7)
+    // Issue priority. The SIMD's arbiter serves the OLDER wave first, i.e. role P (waves 0-3), while role D is the critical path of
+    // every barrier-to-barrier segment (profiles/r02_duo_barrier_wait.txt: P waits 6.0 k cycles per evaluation inside the barriers, D 0.3 k):
+    // P raced ahead on the shared fp64 pipe, then sat in the barrier while D ran alone with nobody to fill its stalls. With D ahead in
+    // priority P fills D's gaps instead: 16.64 -> 15.95 ms per launch (profiles/r03_ab_prio.txt; s_setprio 1, 2, 3 and D in waves 0-3
+    // measure alike).
+#ifndef FB_DUO_PRIO_D
+#define FB_DUO_PRIO_D 2
+#endif
+    if (role == 2) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
+#ifdef FB_DUO_PRIO_P
+    if (role == 1) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_P);
+#endif
     const int t = threadIdx.x & (B - 1);
     const int pair = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t i = (int64_t)blockIdx.x * B + t;
@@ -990,7 +1002,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
 #pragma unroll 1
         while (true) {
+            DUO_MARK(1, 15);  // (arrival at the top barrier, counted from the previous evaluation's start)
             duo_barrier(0);   // the previous evaluation's emits, and D's flag / control words, are visible
+            DUO_MARK(1, 0);
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
             if (c & DUO_C_EXIT) break;
@@ -1064,7 +1078,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
 #pragma unroll 1
     while (true) {
+        DUO_MARK(2, 15);
         duo_barrier(0);
+        DUO_MARK(2, 0);
         if (exit_) break;
         const bool cb = stage == 0 && pending_cb && !redoing;
         const StageK sk = stage_k(stage);

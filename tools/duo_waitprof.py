@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long each role of the wave-specialised stepper waits for the other (diagnostic build):
-    tools/build_variant.sh waitprof -DFB_STAMP -DFB_DUO_WAITPROF
+    python __graft_entry__.py --diagnostic-variant waitprof -DFB_STAMP -DFB_DUO_WAITPROF
     FLIGHTBATCH_LIB=flight.jl_amd/libflightbatch_waitprof.so python tools/duo_waitprof.py
 Wave 0 (role P) and wave 4 (role D) of workgroup 0: cycles inside each of the four barriers of an evaluation, per evaluation."""
 import ctypes as C, os, sys
