@@ -37,7 +37,7 @@ __device__ __forceinline__ void duo_mark(int role, int k) {
     if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (k == 0) g_duo_t0[role - 1] = t;
-        else { g_stamp_acc[(role == 1 ? 0 : 16) + k] += t - g_duo_t0[role - 1]; g_stamp_cnt[(role == 1 ? 0 : 16) + k] += 1; }
+        else if (g_duo_t0[role - 1] != 0) { g_stamp_acc[(role == 1 ? 0 : 16) + k] += t - g_duo_t0[role - 1]; g_stamp_cnt[(role == 1 ? 0 : 16) + k] += 1; }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -94,7 +94,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         DUO_MARK(1, 11);  // at A
         emit.xsync(1);   // ----- barrier A -----
         DUO_MARK(1, 3);   // left A
-#ifdef FB_DUO_P_BOOST
+#if defined(FB_DUO_P_BOOST) || defined(FB_DUO_P_ALL)
         __builtin_amdgcn_s_setprio(3);   // experiment: role D waits for the propeller wrench at barrier B
 #endif
 
@@ -159,6 +159,9 @@ DUO_MARK(1, 6);   // at B
         emit.xsync(2);   // ----- barrier B (role D has finished its aerodynamics by about now) -----
 #endif
         DUO_MARK(1, 7);   // left B
+#ifdef FB_DUO_P_TAIL
+        __builtin_amdgcn_s_setprio(3);   // experiment: behind B role P has the longer way to go
+#endif
         const double k_f = rsqrt(rho * (1 / isa::rho_std));
         const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
         const double f_run = mix_auto ? f_lean + mixture * (f_rich - f_lean) : k_f * (f_rich * (0.5 * (mixture + 1)));
@@ -187,6 +190,9 @@ DUO_MARK(1, 6);   // at B
         // ----- fuel (c172.jl:607-616) -----
         (void)x_fuel;
         emit(FB_X_FUEL, -mdot / (m_full - m_res));
+#if defined(FB_DUO_P_TAIL) || defined(FB_DUO_P_ALL)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         DUO_MARK(1, 10);   // end of role P's evaluation
         return st;
     } else {
@@ -313,30 +319,35 @@ DUO_MARK(1, 6);   // at B
         aux.wow = 0;
         aux.crash = 0;
         if (!(fmin(h_o - env.h_trn, h_e - H_MIN) > 10.0)) st |= FB_ST_INTERNAL_REDO;   // (within reach of the ground, or of the altitude floor: rhs(), "high-clearance shortcut")
-        DUO_MARK(2, 8);   // aerodynamics done, at B
-        emit.xsync(2);   // ----- barrier B -----
-        const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
-        const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
-        const v3 h_rot = {emit.xget(XD_HROT), 0.0, 0.0};
-        DUO_MARK(2, 9);   // left B
-        // ----- rigid-body dynamics at the CoM (dynamics.jl:443-525), as in rhs() -----
-        const v3 F_b = F_a + F_p;
-        const v3 tau_b = tau_a + tau_pb;
+        // ----- rigid-body dynamics at the CoM (dynamics.jl:443-525), the part that does not need the propeller: role D reaches barrier B ahead
+        // of role P (tools/duo_waitprof.py), and everything behind B is on the critical path of the evaluation — so the wrench and the
+        // angular momentum enter a form prepared in front of it:
+        //   ω̇ = J⁻¹ (τ_a + τ_p − r_bc × (F_a + F_p) − J (ω_ie × ω) − ω_ic × (J ω_ic + h_rot))  =  J⁻¹ (T0 + τ_p − r_bc × F_p − ω_ic × h_rot)
+        //   v̇_c = (F_a + F_p) / M + g − (ω + 2 ω_ie) × v_ec                                   =  A0 + F_p / M
+        // (the same terms as rhs(), summed in another order: agreement with k_step_air to rounding, tests/test_gpu_duo.py)
         auto Jmul = [&](v3 v) { return v3{Jxx * v.x + Jxy * v.y + Jxz * v.z, Jxy * v.x + Jyy * v.y + Jyz * v.z, Jxz * v.x + Jyz * v.y + Jzz * v.z}; };
-        const v3 F_c = F_b;
-        const v3 tau_c = tau_b - cross(r_bc, F_b);
         const v3 v_ec_c = v_eb_b + cross(w_eb_b, r_bc);
         const v3 w_ic_c = w_ie_b + w_eb_b;
-        const v3 hc = Jmul(w_ic_c) + h_rot;
-        const v3 rhs_w = tau_c - Jmul(cross(w_ie_b, w_eb_b)) - cross(w_ic_c, hc);
-        // symmetric 3x3 solve by cofactors
+        v3 T0 = tau_a - cross(r_bc, F_a) - Jmul(cross(w_ie_b, w_eb_b)) - cross(w_ic_c, Jmul(w_ic_c));
+        v3 A0 = iM * F_a + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
+        // symmetric 3x3 inverse by cofactors, scaled once
         const double c11 = Jyy * Jzz - Jyz * Jyz, c12 = Jyz * Jxz - Jxy * Jzz, c13 = Jxy * Jyz - Jyy * Jxz;
         const double c22 = Jxx * Jzz - Jxz * Jxz, c23 = Jxy * Jxz - Jxx * Jyz, c33 = Jxx * Jyy - Jxy * Jxy;
         const double idet = 1 / (Jxx * c11 + Jxy * c12 + Jxz * c13);
-        const v3 wd = {(c11 * rhs_w.x + c12 * rhs_w.y + c13 * rhs_w.z) * idet, (c12 * rhs_w.x + c22 * rhs_w.y + c23 * rhs_w.z) * idet,
-                       (c13 * rhs_w.x + c23 * rhs_w.y + c33 * rhs_w.z) * idet};
-        const v3 vd_c = iM * F_c + g_c_c - cross(w_eb_b + 2.0 * w_ie_b, v_ec_c);
-        const v3 vd_b = vd_c - cross(wd, r_bc);
+        double i11 = c11 * idet, i12 = c12 * idet, i13 = c13 * idet, i22 = c22 * idet, i23 = c23 * idet, i33 = c33 * idet;
+        double wy = w_ic_c.y, wz = w_ic_c.z;
+        // (pinned: without it the compiler is free to sink this arithmetic behind the barrier, next to its first use)
+        asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(A0.x), "+v"(A0.y), "+v"(A0.z));
+        asm volatile("" : "+v"(i11), "+v"(i12), "+v"(i13), "+v"(i22), "+v"(i23), "+v"(i33), "+v"(wy), "+v"(wz));
+        DUO_MARK(2, 8);   // aerodynamics and the propeller-free part of the dynamics done, at B
+        emit.xsync(2);   // ----- barrier B -----
+        DUO_MARK(2, 9);   // left B
+        const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
+        const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
+        const double h_rot = emit.xget(XD_HROT);   // (h_rot, 0, 0)
+        const v3 rw = (T0 + tau_pb) - cross(r_bc, F_p) - v3{0.0, wz * h_rot, -(wy * h_rot)};
+        const v3 wd = {i11 * rw.x + i12 * rw.y + i13 * rw.z, i12 * rw.x + i22 * rw.y + i23 * rw.z, i13 * rw.x + i23 * rw.y + i33 * rw.z};
+        const v3 vd_b = (A0 + iM * F_p) - cross(wd, r_bc);
         DUO_MARK(2, 10);   // dynamics
         const double kd6[6] = {wd.x, wd.y, wd.z, vd_b.x, vd_b.y, vd_b.z};
         emit_rows<6>(emit, FB_X_OMEGA_EB_B, kd6);

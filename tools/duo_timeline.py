@@ -16,7 +16,7 @@ w = fb.BatchedWorld(n)
 fb.f_init(w, fb.TrimParameters(EAS=EAS[:n], h_e=h[:n], ψ_nb=psi[:n]))
 sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
 fb.step(sim, 0.5); w.sync()
-fb.lib.fb_debug_stamps(None, None, 1)
+fb.lib.fb_debug_stamps(None, None, 1)   # (the marks of the first evaluation after this reset are measured from a stale t0: 1 in 800)
 fb.lib.fb_timing_begin(w._h)
 fb.step(sim, 2.0); w.sync()
 ms = C.c_float(); nl = C.c_int64(); fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
