@@ -159,8 +159,11 @@ DUO_MARK(1, 6);   // at B
         emit.xsync(2);   // ----- barrier B (role D has finished its aerodynamics by about now) -----
 #endif
         DUO_MARK(1, 7);   // left B
-#ifdef FB_DUO_P_TAIL
-        __builtin_amdgcn_s_setprio(3);   // experiment: behind B role P has the longer way to go
+#ifndef FB_DUO_NO_P_TAIL
+        // behind B role P has the longer way to go (the rest of the engine: 396 instructions against role D's ~110 since the propeller-free
+        // part of the dynamics moved ahead of the barrier): it goes ahead of D in issue priority until its evaluation ends
+        // (16.0 -> 15.8 ms per launch, profiles/r03_ab_prio.txt)
+        __builtin_amdgcn_s_setprio(3);
 #endif
         const double k_f = rsqrt(rho * (1 / isa::rho_std));
         const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
@@ -190,7 +193,7 @@ DUO_MARK(1, 6);   // at B
         // ----- fuel (c172.jl:607-616) -----
         (void)x_fuel;
         emit(FB_X_FUEL, -mdot / (m_full - m_res));
-#if defined(FB_DUO_P_TAIL) || defined(FB_DUO_P_ALL)
+#if !defined(FB_DUO_NO_P_TAIL) || defined(FB_DUO_P_ALL)
         __builtin_amdgcn_s_setprio(0);
 #endif
         DUO_MARK(1, 10);   // end of role P's evaluation
