@@ -41,7 +41,8 @@ BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flag
 BYTES_PER_X2_STEP = 756.0         # Cessna172Xv2
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r03_counters.json"   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r03_counters.json"
+PROFILE_COUNTERS_X2 = "r03_x2_counters.json"   # the same for the Cessna172Xv2 airborne stepper (tools/collect_profile_x2.sh)   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
 
 
 def lattice(seed_offset: int = 0, n: int = N_TOTAL):
@@ -305,6 +306,26 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
                         "note": "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d)"}}
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
+    # fp64 VALU fraction and real HBM traffic of the Xv2 stepper, from the committed PMC summary — quoted only next to the code it was
+    # measured on (source hash, like the headline's roofline_valu)
+    prof = os.path.join(ROOT, "profiles", PROFILE_COUNTERS_X2)
+    out["roofline_valu"] = None
+    if os.path.exists(prof) and args.x2_inner == 50:
+        import __graft_entry__ as _ge
+        pj = json.load(open(prof))
+        here = _ge.source_hash()
+        if pj.get("source_hash") != here:
+            out["roofline"]["traffic_note"] = f"profiles/{PROFILE_COUNTERS_X2} was collected on source hash {pj.get('source_hash')}, this tree is {here}: PMC figures withheld"
+        else:
+            kms = out["kernel_ms"]
+            tf = pj["fp64_flops_per_launch"] * (n / pj["n"]) / (kms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                                    "flops_per_aircraft_step": pj["fp64_flops_per_aircraft_step"], "valu_insts_per_aircraft_step": pj["valu_insts_per_aircraft_step"],
+                                    "valu_busy": pj.get("valu_busy"), "per_gpu": True,
+                                    "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS_X2 + " (source hash " + here + ")"}
+            if pj.get("hbm_bytes_per_launch"):
+                out["roofline"]["traffic"] = pj["hbm_bytes_per_launch"] * (n / pj["n"])
+                out["roofline"]["traffic_note"] = "per launch of one GPU's share (50 steps, 25 control updates): the control-law record (94 rows read, ~53 written per update) dominates"
     return out
 
 

@@ -810,6 +810,14 @@ restart:
 // stage sums 34 KB and three of P's four 6 KB, the payload's mass-property sums 20 KB, exchange 6 KB, flags 2 KB.
 // The step's bookkeeping (stage machine, f_step!, status, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
 // P follows through a per-lane flag word and a per-pair control word in LDS.
+// BARRIERS. No data crosses wave pairs: every barrier orders the two waves of ONE pair, and it is a workgroup barrier only because
+// gfx950 has no narrower one. Two things follow, and both lean on how s_barrier works on this hardware rather than on HIP's
+// __syncthreads() contract: (1) a pair whose 64 aircraft are all done (terminated before the launch, or handed over) LEAVES the kernel
+// while the other pairs go on — s_barrier counts the waves of the workgroup that have not ended, so the remaining barriers complete
+// without it; (2) pairs drift apart in their stage machines (a pair re-evaluates k1 after an f_step! that modified a lane; the barrier
+// ahead of f_step! exists only in iterations that have one), so barrier instance n may be "A" for one pair and "top" for another — harmless,
+// because the two waves of a pair always execute the same barrier sequence. tests/test_gpu_duo.py runs both situations (pairs running
+// dry at different steps of one launch, lanes terminated before it) against the one-wave stepper and the oracle.
 constexpr int DUO_B = 256;
 constexpr int DUO_D_PST_SHIFT = 8;   // bits 8-9 of role D's bookkeeping word: status bits found by role P (altitude / ISA range)
 constexpr int DUO_NP = 4, DUO_ND = 17;   // state rows per role

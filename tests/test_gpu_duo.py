@@ -78,3 +78,44 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
     assert err[:, live & ~low].max() < 1e-10
     if (live & low).any():
         assert err[:, live & low].max() < 1e-6                      # (contact amplifies rounding, see test_approach_crosses_the_air_ground_handover)
+
+
+def test_wave_pairs_leaving_at_different_steps(fb, oracle):
+    """One workgroup of k_step_duo serves 256 aircraft with four wave pairs, and a pair whose lanes have all left (handed over to the
+    ground-capable pass) leaves the kernel on its own while the others go on through the workgroup's barriers — which relies on gfx950's
+    s_barrier counting only the waves that have not ended. Here every pair of two workgroups runs dry at a DIFFERENT step of one launch
+    (its 64 aircraft zoom through the ISA ceiling, pair by pair; the last pair of each workgroup flies on), with a few lanes terminated
+    before the launch mixed in: the survivors must agree with the one-wave stepper, the terminated ones with the oracle."""
+    from test_gpu_termination import flying_batch, geoid
+    n = 512
+    rng = np.random.default_rng(77)
+    lat = rng.uniform(-1.0, 1.0, n); lon = rng.uniform(-3.0, 3.0, n)
+    a = 6378137.0
+    ceiling = 84852.0 * a / (a - 84852.0) + geoid(oracle, lat, lon)
+    pair = (np.arange(n) // 64) % 4
+    below = np.where(pair < 3, 1.0 + 1.7 * pair + rng.uniform(0.0, 0.4, n), 500.0)      # pair p crosses around step 5 + 8 p; pair 3 never
+    x, s, u, ui = flying_batch(fb, oracle, n, 77, lat, lon, ceiling - below, np.full(n, 20.0), {})
+    st0 = np.zeros(n, np.int32); st0[rng.random(n) < 0.04] = fb.K["FB_ST_NAN"]
+    out = {}
+    for duo in (False, True):
+        w = _world(fb, n, duo)
+        w.set_state(x, s); w.u = u; w.ui = ui
+        fb._lib.check(fb.lib.fb_set_status(w._h, st0.ctypes.data_as(fb._lib.C.POINTER(fb._lib.C.c_int32))))
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+        fb.step(sim, 1.0); w.sync()
+        out[duo] = (w.x, w.s, w.status, w.termination)
+        w.close()
+    (xa, sa, sta, (tsa, twa)), (xd, sd, std, (tsd, twd)) = out[False], out[True]
+    assert np.array_equal(sta, std) and np.array_equal(sa, sd) and np.array_equal(tsa, tsd) and np.array_equal(twa, twd)
+    fresh = st0 == 0
+    gone = fresh & (pair < 3)
+    assert (std[gone] == fb.K["FB_ST_ISA_RANGE"]).all() and (std[fresh & (pair == 3)] == 0).all()
+    steps = [np.median(tsd[gone & (pair == p)]) for p in range(3)]
+    assert steps[0] < steps[1] < steps[2] < 40, steps                      # the pairs ran dry one after the other, inside the first launch
+    assert np.array_equal(xd[:, ~fresh], x[:, ~fresh])                     # terminated before the launch: untouched
+    assert np.array_equal(xd[:, gone], xa[:, gone])                        # ended by the same ground-capable pass in both worlds
+    err = np.abs(xd - xa)[:, fresh & (pair == 3)] / _scale(xa[:, fresh & (pair == 3)])
+    assert err.max() < 1e-10, err.max()
+    xo, so, sto, tso, two = oracle.step_term(x, u, ui, s, oracle.default_env(), 0.01, 100, status=st0)
+    assert np.array_equal(sto, std) and np.array_equal(tso[gone], tsd[gone]) and np.array_equal(two[gone], twd[gone])
+    assert (np.abs(xd - xo) / np.maximum(np.abs(xo), 1e-3)).max() < 1e-9

@@ -17,6 +17,7 @@ bash tools/collect_profile_f32.sh > $OUT/collect_f32.log 2>&1; cp gpurun_out/pro
 python3 tools/bench_x2.py > $OUT/${TAG}_x2_bench.json 2> $OUT/bench_x2.err
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x2 -- python3 $ROOT/tools/bench_x2.py > $OUT/x2_under_rocprof.json 2> $OUT/stats_x2.log)
 cp $OUT/stats_x2/*/*_kernel_stats.csv $OUT/${TAG}_x2_kernel_stats.csv; echo "x2 done"
+bash tools/collect_profile_x2.sh $TAG > $OUT/collect_x2.log 2>&1; cp gpurun_out/prof_x2_$TAG/${TAG}_x2_counters.json $OUT/; echo "x2 pmc done"
 python3 tools/bench_fleet.py > $OUT/${TAG}_fleet_bench.json 2> $OUT/bench_fleet.err; echo "fleet done"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_gnd -- python3 $ROOT/tools/bench_ground.py > $OUT/${TAG}_ground_bench.txt 2> $OUT/stats_gnd.log)
 cp $OUT/stats_gnd/*/*_kernel_stats.csv $OUT/${TAG}_ground_kernel_stats.csv; echo "ground done"
