@@ -848,21 +848,69 @@ struct InputsDuoD {
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
 };
-// A workgroup barrier of the wave-specialised stepper. Diagnostic builds (-DFB_STAMP -DFB_DUO_WAITPROF, tools/duo_waitprof.py): wave 0
-// (role P) and wave 4 (role D) of workgroup 0 add the cycles they spend INSIDE barrier `slot` (0 top, 1 A, 2 B, 3 ahead of f_step!) to
-// g_stamp_acc[slot] / [8 + slot]: how long each role waits for the other.
-FBD void duo_barrier(int slot) {
+// The synchronisation point of a wave PAIR of the wave-specialised stepper. Nothing crosses pairs, so the two waves that share 64 aircraft
+// meet through two counters in LDS (each wave publishes how many synchronisation points it has reached and waits until its partner's
+// count catches up) instead of through a workgroup barrier: behind s_barrier a pair also waited for the three pairs on the other
+// SIMDs at every one of the four points of an evaluation — ~0.5 k cycles each even with the partner already there
+// (profiles/r03_duo_timeline_d_alone.txt). The LDS serves one wave's instructions in order, so what a wave wrote ahead of its counter is
+// there when the partner sees the count; the waits are bounded (a partner that never arrives would otherwise hang the GPU: the pair then
+// goes on, and its aircraft are flagged FB_ST_NAN when the kernel ends).
+// FB_DUO_PAIRSYNC=0 brings the workgroup barriers back (A/B measurements).
+// Diagnostic builds (-DFB_STAMP -DFB_DUO_WAITPROF, tools/duo_waitprof.py): wave 0 (role P) and wave 4 (role D) of workgroup 0 add the
+// cycles they spend INSIDE synchronisation point `slot` (0 top, 1 A, 2 B, 3 ahead of f_step!) to g_stamp_acc[slot] / [8 + slot].
+#ifndef FB_DUO_PAIRSYNC
+#define FB_DUO_PAIRSYNC 1
+#endif
+#ifdef FB_DUO_SYNC_DEBUG
+__device__ unsigned g_duo_sync_dbg[40];
+#endif
+struct DuoSync {
+    volatile __attribute__((address_space(3))) int* mine;
+    volatile __attribute__((address_space(3))) int* other;
+    int base;     // synchronisation points passed before this iteration of the evaluation loop. WAVE-UNIFORM: it is advanced by the loops,
+                  // in uniform code (two of an iteration's points sit inside the divergent `if (run)` of the evaluation, where a counter
+                  // incremented in place would advance for the running lanes only)
+    int failed;
+};
+FBD void duo_sync_wait(DuoSync& sy, int slot) {
+#if FB_DUO_PAIRSYNC
+    const int c = sy.base + slot + 1;   // the points of an iteration in order: 0 top, 1 A, 2 B, 3 ahead of f_step!
+    asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above)
+    *sy.mine = c;
+    int spins = 0;
+#pragma unroll 1
+    while (__builtin_amdgcn_readfirstlane(*sy.other) < c) {
+        __builtin_amdgcn_s_sleep(1);
+#ifdef FB_DUO_SYNC_DEBUG
+        if (++spins > (1 << 10)) {
+            sy.failed = 1;
+            if ((threadIdx.x & 63) == 0 && atomicAdd(&g_duo_sync_dbg[0], 1u) < 7) {
+                const unsigned k = atomicAdd(&g_duo_sync_dbg[1], 4u);
+                g_duo_sync_dbg[2 + k] = blockIdx.x; g_duo_sync_dbg[3 + k] = threadIdx.x; g_duo_sync_dbg[4 + k] = c; g_duo_sync_dbg[5 + k] = *sy.other;
+            }
+            break;
+        }
+#else
+        if (++spins > (1 << 20)) { sy.failed = 1; break; }
+#endif
+    }
+    asm volatile("" ::: "memory");   // (and every one below stays below)
+#else
+    (void)sy; (void)slot;
+    __syncthreads();
+#endif
+}
+FBD void duo_barrier(DuoSync& sy, int slot) {
 #if defined(FB_STAMP) && defined(FB_DUO_WAITPROF)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    __syncthreads();
+    duo_sync_wait(sy, slot);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == DUO_B)) {
         const int k = slot + (threadIdx.x ? 8 : 0);
         g_stamp_acc[k] += t1 - t0; g_stamp_cnt[k] += 1;
     }
 #else
-    (void)slot;
-    __syncthreads();
+    duo_sync_wait(sy, slot);
 #endif
 }
 
@@ -881,6 +929,7 @@ struct DuoEmit {
     double eb, ee, em;
     bool last;
     int t;
+    DuoSync* sync;     // this wave's side of the pair's synchronisation counters
     // panel rows: 0-1 filters (D), 2 fuel, 3-5 engine (P), 6-14 q_wb q_ew h_e (D), 15-20 angular and linear velocity (D)
     __device__ __forceinline__ static constexpr bool owned(int j) {
         if (SV::skip(j)) return false;
@@ -920,7 +969,7 @@ struct DuoEmit {
     }
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
-    __device__ __forceinline__ void xsync(int slot) const { duo_barrier(slot); }
+    __device__ __forceinline__ void xsync(int slot) const { duo_barrier(*sync, slot); }
     __device__ __forceinline__ void xstatus(int32_t st) const { *dst_p |= (st & 3) << DUO_D_PST_SHIFT; }   // (FB_ST_ALT_RANGE | FB_ST_ISA_RANGE)
 };
 // every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
@@ -959,6 +1008,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
     static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
     int* ctrl_l = (int*)&rk[LDS_ATAN + ATAN_N];   // one control word per wave pair (the LDS is full to the last 16 bytes)
+    int* sync_l = ctrl_l + 4;                      // two synchronisation counters per wave pair: [pair] role P's, [4 + pair] role D's
+    static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 6, "room for the control words and the synchronisation counters behind the atan table");
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) + 1;   // 1: P (waves 0-3), 2: D (waves 4-7)
     // Issue priority. The SIMD's arbiter serves the OLDER wave first, i.e. role P (waves 0-3), while role D is the critical path of
     // every barrier-to-barrier segment (profiles/r02_duo_barrier_wait.txt: P waits 6.0 k cycles per evaluation inside the barriers, D 0.3 k):
@@ -979,7 +1030,10 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __syncthreads();
     for (int k = threadIdx.x; k < LDS_RK_KNOTS; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
     for (int k = threadIdx.x; k < ATAN_N; k += blockDim.x) rk[LDS_ATAN + k] = atan(k * (1.0 / 32));
+    if (threadIdx.x < 8) sync_l[threadIdx.x] = 0;
     __syncthreads();
+    DuoSync sy = {(volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? pair : 4 + pair)),
+                  (volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? 4 + pair : pair)), 0, 0};
     const bool valid = i < a.n && a.status[i] == 0;
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     // what an evaluation at stage `stg` needs (wave-uniform)
@@ -1011,7 +1065,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll 1
         while (true) {
             DUO_MARK(1, 15);  // (arrival at the top barrier, counted from the previous evaluation's start)
-            duo_barrier(0);   // the previous evaluation's emits, and D's flag / control words, are visible
+            duo_barrier(sy, 0);   // the previous evaluation's emits, and D's flag / control words, are visible
             DUO_MARK(1, 0);
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
@@ -1033,12 +1087,23 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     StepAux aux;
                     InputsDuoP inl = in;
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
-                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, &dst_l[t], (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, &dst_l[t], (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
                     const SV xv = {sk.xrd_l + t + lds_off};
+#if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 2
+                    // timing diagnostic (tools/duo_alone.sh): role D alone on its SIMD — role P puts plausible constants and waits
+                    emit.xput(XD_RHO, 1.1); emit.xput(XD_HO, 1000.0);
+                    emit.xsync(1);
+                    emit.xput(XD_FP, 900.0); emit.xput(XD_FP + 1, 0.0); emit.xput(XD_FP + 2, 0.0);
+                    emit.xput(XD_TAUP, -150.0); emit.xput(XD_TAUP + 1, 0.0); emit.xput(XD_TAUP + 2, 700.0); emit.xput(XD_HROT, 80.0);
+                    emit.xsync(2);
+                    (void)xv; (void)aux; (void)inl;
+#else
                     rhs_duo<1>(xv, 0, eng, inl, a.env, T, emit, aux);
+#endif
                 }
-            } else { duo_barrier(1); duo_barrier(2); }   // (barriers A and B of an evaluation nobody runs)
-            if (c & DUO_C_CB) duo_barrier(3);
+            } else { duo_barrier(sy, 1); duo_barrier(sy, 2); }   // (synchronisation points A and B of an evaluation nobody runs)
+            if (c & DUO_C_CB) duo_barrier(sy, 3);
+            sy.base += (c & DUO_C_CB) ? 4 : 3;
         }
         return;
     }
@@ -1087,7 +1152,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
-        duo_barrier(0);
+        duo_barrier(sy, 0);
         DUO_MARK(2, 0);
         if (exit_) break;
         const bool cb = stage == 0 && pending_cb && !redoing;
@@ -1104,12 +1169,20 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 const int d0 = dst_l[t];
                 InputsDuoD inl = in;
                 inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
-                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, nullptr, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t};
+                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, nullptr, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
                 const SV xv = {sk.xrd_l + t + lds_off};
+#if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 1
+                // timing diagnostic: role P alone on its SIMD — role D hands the velocity at the propeller over and waits
+                emit.xput(XD_VP, 50.0); emit.xput(XD_VP + 1, 0.0); emit.xput(XD_VP + 2, 2.0);
+                emit.xsync(1); emit.xsync(2);
+                (void)xv; (void)inl; (void)d0;
+#else
                 bits = rhs_duo<2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
+#endif
             }
-        } else { duo_barrier(1); duo_barrier(2); }
-        if (cb) duo_barrier(3);   // role P has read x_{n+1} for the last time: f_step! may modify it
+        } else { duo_barrier(sy, 1); duo_barrier(sy, 2); }
+        if (cb) duo_barrier(sy, 3);   // role P has read x_{n+1} for the last time: f_step! may modify it
+        sy.base += cb ? 4 : 3;
         int d = dst_l[t];
         if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
         // within reach of the ground, or an exception (altitude / ISA range): nothing is committed for this lane, the ground-capable pass
@@ -1177,7 +1250,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         bad = bad || !isfinite(v);
         a.x[(int64_t)k * a.n + i] = v;
     }
-    if (bad) a.status[i] |= FB_ST_NAN;
+    if (bad || __builtin_amdgcn_ballot_w64(sy.failed != 0) != 0) a.status[i] |= FB_ST_NAN;   // (sy.failed: a synchronisation wait ran into its bound — the partner wave never arrived)
     a.s[i] = (d & D_STALL) ? 1 : 0;
     a.s[a.n + i] = (d >> D_ENG_SHIFT) & 3;
 }

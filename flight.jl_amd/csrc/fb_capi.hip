@@ -791,6 +791,9 @@ int32_t fb_debug_stamps(unsigned long long* acc, unsigned long long* cnt, int32_
     return 0;
 }
 #endif
+#ifdef FB_DUO_SYNC_DEBUG
+int32_t fb_debug_duo_sync(unsigned* out40) { HIPCHK(hipMemcpyFromSymbol(out40, HIP_SYMBOL(fbd::g_duo_sync_dbg), sizeof(unsigned) * 40)); return 0; }
+#endif
 int32_t fb_sync(fb_handle h) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
