@@ -219,7 +219,6 @@ DUO_MARK(1, 6);   // at B
         }
         DUO_MARK(2, 1);   // head, velocity at the propeller put
         const quat q_eb = qmul(q_ew, q_wb);
-        const double x_fuel = x[FB_X_FUEL];   // (before barrier A: role P rewrites this row at the very end of its evaluation)
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
@@ -259,6 +258,9 @@ DUO_MARK(1, 6);   // at B
         DUO_MARK(2, 4);   // at A
         emit.xsync(1);   // ----- barrier A -----
         const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
+        // the fuel row is role P's: it emits it last of all, so it is read HERE — role P has passed A, i.e. finished its previous
+        // evaluation, and it will not emit again before it has passed B, where it waits for this wave
+        const double x_fuel = x[FB_X_FUEL];
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         const double q_dyn = 0.5 * rho * (TAS * TAS);
         DUO_MARK(2, 5);   // left A

@@ -872,11 +872,13 @@ struct DuoSync {
                   // incremented in place would advance for the running lanes only)
     int failed;
 };
+template <bool WAIT = true>
 FBD void duo_sync_wait(DuoSync& sy, int slot) {
 #if FB_DUO_PAIRSYNC
     const int c = sy.base + slot + 1;   // the points of an iteration in order: 0 top, 1 A, 2 B, 3 ahead of f_step!
     asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above)
     *sy.mine = c;
+    if constexpr (!WAIT) { asm volatile("" ::: "memory"); return; }   // (publish only: this wave needs nothing of its partner here)
     int spins = 0;
 #pragma unroll 1
     while (__builtin_amdgcn_readfirstlane(*sy.other) < c) {
@@ -900,19 +902,31 @@ FBD void duo_sync_wait(DuoSync& sy, int slot) {
     __syncthreads();
 #endif
 }
+template <bool WAIT = true>
 FBD void duo_barrier(DuoSync& sy, int slot) {
 #if defined(FB_STAMP) && defined(FB_DUO_WAITPROF)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    duo_sync_wait(sy, slot);
+    duo_sync_wait<WAIT>(sy, slot);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == DUO_B)) {
         const int k = slot + (threadIdx.x ? 8 : 0);
         g_stamp_acc[k] += t1 - t0; g_stamp_cnt[k] += 1;
     }
 #else
-    duo_sync_wait(sy, slot);
+    duo_sync_wait<WAIT>(sy, slot);
 #endif
 }
+// Which of the four points a role has to WAIT at (FB_DUO_PAIRSYNC; with workgroup barriers everybody waits everywhere):
+//   role P waits at all of them — top: role D's control and flag words and the kinematics rows of the state it is about to read; A: the
+//   velocity at the propeller; B and the point ahead of f_step!: nothing it needs, but they keep it from running so far ahead that it
+//   rewrites (in place) rows role D has yet to read: the fuel row, and x_{n+1} under f_step!;
+//   role D waits at A (density, orthometric altitude — and, because role P has then finished its previous evaluation, the fuel row) and
+//   at B (the propeller's wrench). At the top and ahead of f_step! it only publishes: what it reads there is its own, and role P has
+//   read the state rows it needs before A (all its state reads sit at the head of rhs_duo<1>()).
+#ifndef FB_DUO_D_WAITS_EVERYWHERE
+#define FB_DUO_D_WAITS_EVERYWHERE 0
+#endif
+constexpr bool DUO_D_WAIT_TOP = !FB_DUO_PAIRSYNC || FB_DUO_D_WAITS_EVERYWHERE;
 
 template <int ROLE>
 struct DuoEmit {
@@ -1152,7 +1166,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
-        duo_barrier(sy, 0);
+        duo_barrier<DUO_D_WAIT_TOP>(sy, 0);
         DUO_MARK(2, 0);
         if (exit_) break;
         const bool cb = stage == 0 && pending_cb && !redoing;
@@ -1181,7 +1195,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #endif
             }
         } else { duo_barrier(sy, 1); duo_barrier(sy, 2); }
-        if (cb) duo_barrier(sy, 3);   // role P has read x_{n+1} for the last time: f_step! may modify it
+        if (cb) duo_barrier<DUO_D_WAIT_TOP>(sy, 3);   // role P has read x_{n+1} for the last time (ahead of A): f_step! may modify it
         sy.base += cb ? 4 : 3;
         int d = dst_l[t];
         if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
