@@ -4,24 +4,31 @@
 // and tools/duo_check.py + the parity tests compare the two); only the order of the blocks and who evaluates them differ:
 //
 //   role P  "atmosphere + power plant"                     role D  "airframe"
-//   n_e                                                    attitude, n_e, wind-relative velocity -> put the velocity at the propeller
+//   reads its state rows (q_ew, h_e, engine, fuel)         attitude, n_e, wind-relative velocity -> put the velocity at the propeller
+//   ---- publishes R                                        ---- publishes V
 //   geoid height (lat / lon, EGM96) -> h_o                 airflow angles, filter rows,
 //   ISA atmosphere -> T, p, log p                          table locations and lookups on the alpha / beta axes
-//   put rho, h_o  ----------------------- barrier A ---->  get rho, h_o
-//   get the velocity at the propeller; propeller            radii of curvature, kinematics derivatives (9 rows), mass properties,
-//   put F_p, tau_p, h_rot                                  gravity at the CoM, ground-effect location, aerodynamic coefficients and
-//   engine (3 rows)                                        wrench, landing gear (airborne shortcut)
-//        ...  ------------------------- barrier B ---->    get F_p, tau_p, h_rot
-//   engine tail, fuel row                                  rigid-body dynamics (6 rows)
+//   put rho, h_o                                            ---- waits for R:  fuel row, kinematics derivatives (9 rows), radii of curvature,
+//   ---- publishes A, waits for V                                mass properties, gravity at the CoM
+//   get the velocity at the propeller; propeller            ---- waits for A:  get rho, h_o (and examines the altitude / ISA ranges),
+//   put F_p, tau_p, h_rot                                        ground-effect location, aerodynamic coefficients and wrench, landing gear
+//   ---- publishes W                                             (airborne shortcut), the propeller-free part of the rigid-body dynamics
+//   engine (3 rows), fuel flow                              ---- waits for W:  get F_p, tau_p, h_rot
+//   ---- waits for X                                        ---- publishes X
+//   engine-speed row, fuel row                              the rest of the dynamics (6 rows); the step's bookkeeping; ---- publishes T
 //
-// Only n_e (ten instructions) is evaluated twice. Who may touch which LDS row when:
-//   * both roles read the state rows they need from the other role's rows BEFORE barrier A (D: nothing of P's but the fuel row,
-//     which P rewrites last of all, after B; P: q_ew and h_e);
-//   * D rewrites the kinematics rows after A, its angular / linear velocity rows after B; P rewrites the engine rows after A and
-//     the fuel row after B;
+// Only n_e (ten instructions) is evaluated twice. The two waves of a pair keep in step through two counters in LDS — no barrier
+// (k_step_duo, c172_kernels.hpp) — and every wait sits where a value is needed. Who may touch which LDS row when:
+//   * role P reads the state rows it needs — of role D's: q_ew and h_e — at the head of its evaluation, ahead of its point R; role D
+//     rewrites the kinematics rows behind R. Role D reads nothing of role P's rows but the fuel row, behind R too (role P emits it last
+//     of all, behind role D's point X, so "R reached" means the previous evaluation's fuel row is there and this one's is not);
+//   * role D rewrites the filter rows at its head, the kinematics rows behind R, the angular / linear velocity rows behind X; role P its
+//     engine-compensator rows behind W and the engine-speed and fuel rows behind X;
 //   * exchange rows 0-5 are the angular / linear velocity rows of the evaluation panel: only role D reads them as state (at its head),
-//     so it may overwrite rows 0-2 with the velocity at the propeller before A; role P reads that after A and then writes F_p, tau_p
-//     over rows 0-5, which D reads after B and overwrites with its own emit at the end.
+//     so it may overwrite rows 0-2 with the velocity at the propeller (point V); role P reads that behind V and then writes F_p, tau_p
+//     over rows 0-5 (point W), which role D reads behind W and, behind X, overwrites with its own emit;
+//   * the control and flag words of an evaluation are role D's, written before its point T, which role P waits for at the top of its loop
+//     (role D has waited for W of the evaluation before, so role P has long read the previous ones).
 #pragma once
 #include "c172_device.hpp"
 
@@ -46,6 +53,10 @@ __device__ __forceinline__ void duo_mark(int role, int k) {
 #define DUO_MARK(role, k) do { } while (0)
 #endif
 
+// the points of an evaluation the two roles publish / wait for (k_step_duo, c172_kernels.hpp: "How the two waves of a PAIR ... keep in step")
+enum { DUO_PT_T = 0, DUO_PT_V = 1, DUO_PT_X = 2,    // role D: top of the loop; velocity at the propeller put; wrench and fuel row read
+       DUO_PT_R = 0, DUO_PT_A = 1, DUO_PT_W = 2,    // role P: state rows read; density and altitude put; wrench put
+       DUO_NPT = 3 };
 constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
 constexpr int XD_VP = XD_FP;   // role D -> role P before barrier A: the velocity at the propeller, in the rows that carry F_p after it
 
@@ -75,6 +86,11 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         lds_cptr RPT = T.rk + LDS_PISTON;
         const double w_eng = x[FB_X_ENG_OMEGA];
         const double x_frc = x[FB_X_ENG_FRC], x_idle = x[FB_X_ENG_IDLE], x_fuel = x[FB_X_FUEL];
+        {   // every state row this role reads is read HERE (pinned: the compiler may not sink a read towards its use, past the point)
+            double pin_w = w_eng, pin_f = x_frc, pin_i = x_idle, pin_u = x_fuel, pin_h = h_e, pin_q0 = q_ew.w, pin_q1 = q_ew.x, pin_q2 = q_ew.y, pin_q3 = q_ew.z;
+            asm volatile("" : "+v"(pin_w), "+v"(pin_f), "+v"(pin_i), "+v"(pin_u), "+v"(pin_h), "+v"(pin_q0), "+v"(pin_q1), "+v"(pin_q2), "+v"(pin_q3));
+        }
+        emit.xpub(DUO_PT_R);   // ----- point R: state rows read (role D may rewrite the kinematics rows; this wave's previous evaluation is complete) -----
         double lat, lon;
         const double N_geoid = geoid_height<true>(T, n_e, lat, lon);
         const double h_o = h_e - N_geoid;
@@ -90,13 +106,10 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double i_a_snd = (1 / sqrt_gR) * rs_T;
         DUO_MARK(1, 2);   // ISA done
         emit.xput(XD_RHO, rho); emit.xput(XD_HO, h_o);
-        if (st != 0) emit.xstatus(st);
         DUO_MARK(1, 11);  // at A
-        emit.xsync(1);   // ----- barrier A -----
-        DUO_MARK(1, 3);   // left A
-#if defined(FB_DUO_P_BOOST) || defined(FB_DUO_P_ALL)
-        __builtin_amdgcn_s_setprio(3);   // experiment: role D waits for the propeller wrench at barrier B
-#endif
+        emit.xpub(DUO_PT_A);    // ----- point A: density and orthometric altitude put (role D examines the altitude and ISA ranges itself) -----
+        emit.xwait(DUO_PT_V);   // ----- role D's point V: the velocity at the propeller -----
+        DUO_MARK(1, 3);   // past V
 
         // ----- propeller (propellers.jl:405-452) -----
         const double w_prop = w_eng;  // gear ratio 1
@@ -130,12 +143,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         emit.xput(XD_TAUP, tau_pb.x); emit.xput(XD_TAUP + 1, tau_pb.y); emit.xput(XD_TAUP + 2, tau_pb.z);
         DUO_MARK(1, 5);   // wrench put
         emit.xput(XD_HROT, prop_Jxx * w_prop);
-#ifdef FB_DUO_B_EARLY
-        emit.xsync(2);   // ----- barrier B -----
-#endif
-#ifdef FB_DUO_P_BOOST
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        emit.xpub(DUO_PT_W);    // ----- point W: propeller wrench put -----
 
         // ----- engine (piston.jl:314-426) -----
         double out_frc, out_idle;
@@ -154,17 +162,13 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const loc l_n2 = range_locate(0.667, 1.0, 2, n_eng, false);
         const double mu_wot = lerp2(PT + PT_MU_WOT_V, 2, l_n2, range_locate(0.441, 1.0, 9, delta, false));
         const double mu = mu_wot * (mu_ratio_idle + throttle * (1 - mu_ratio_idle));
-DUO_MARK(1, 6);   // at B
-        #ifndef FB_DUO_B_EARLY
-        emit.xsync(2);   // ----- barrier B (role D has finished its aerodynamics by about now) -----
+DUO_MARK(1, 6);   // engine head done
+        // behind W role P has the longer way to go (the rest of the engine: ~400 instructions against role D's ~110 once it has the wrench): it
+        // goes ahead of D in issue priority until its evaluation ends (profiles/r03_ab_prio.txt)
+#ifndef FB_DUO_P_TAIL_PRIO
+#define FB_DUO_P_TAIL_PRIO 3
 #endif
-        DUO_MARK(1, 7);   // left B
-#ifndef FB_DUO_NO_P_TAIL
-        // behind B role P has the longer way to go (the rest of the engine: 396 instructions against role D's ~110 since the propeller-free
-        // part of the dynamics moved ahead of the barrier): it goes ahead of D in issue priority until its evaluation ends
-        // (16.0 -> 15.8 ms per launch, profiles/r03_ab_prio.txt)
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        __builtin_amdgcn_s_setprio(FB_DUO_P_TAIL_PRIO);
         const double k_f = rsqrt(rho * (1 / isa::rho_std));
         const bool mix_auto = in.ui & FB_UI_MIXTURE_AUTO;
         const double f_run = mix_auto ? f_lean + mixture * (f_rich - f_lean) : k_f * (f_rich * (0.5 * (mixture + 1)));
@@ -189,13 +193,12 @@ DUO_MARK(1, 6);   // at B
         const double mdot = eng_running ? SFC_run * P_run : 0.0;
         const double tau_load = tau_p.x;  // gear_ratio * τ_prop
         DUO_MARK(1, 9);   // engine done
+        emit.xwait(DUO_PT_X);   // ----- role D's point X: it has read the fuel row (and the wrench): the rows below may be rewritten in place -----
         emit(FB_X_ENG_OMEGA, (tau_shaft + tau_load) / (J_eng + prop_Jxx));
         // ----- fuel (c172.jl:607-616) -----
         (void)x_fuel;
         emit(FB_X_FUEL, -mdot / (m_full - m_res));
-#if !defined(FB_DUO_NO_P_TAIL) || defined(FB_DUO_P_ALL)
         __builtin_amdgcn_s_setprio(0);
-#endif
         DUO_MARK(1, 10);   // end of role P's evaluation
         return st;
     } else {
@@ -217,6 +220,7 @@ DUO_MARK(1, 6);   // at B
             const v3 v_p = v_wb_b + cross(w_eb_b, r_p);
             emit.xput(XD_VP, v_p.x); emit.xput(XD_VP + 1, v_p.y); emit.xput(XD_VP + 2, v_p.z);
         }
+        emit.xpub(DUO_PT_V);   // ----- point V: velocity at the propeller put -----
         DUO_MARK(2, 1);   // head, velocity at the propeller put
         const quat q_eb = qmul(q_ew, q_wb);
         const double TAS = norm(v_wb_b);
@@ -255,15 +259,11 @@ DUO_MARK(1, 6);   // at B
         const double cy_p = lerp2(A + AT_CY_P_V, 2, l_al2, l_df2), cy_r = lerp2(A + AT_CY_R_V, 2, l_al2, l_df2);
         const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
         const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
-        DUO_MARK(2, 4);   // at A
-        emit.xsync(1);   // ----- barrier A -----
-        const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
-        // the fuel row is role P's: it emits it last of all, so it is read HERE — role P has passed A, i.e. finished its previous
-        // evaluation, and it will not emit again before it has passed B, where it waits for this wave
+        DUO_MARK(2, 4);   // lookups done
+        emit.xwait(DUO_PT_R);   // ----- role P's point R: it has read q_ew, h_e (the kinematics rows may be rewritten) and finished its previous
+                                // evaluation (the fuel row, which it emits last of all, is there; it will not emit it again before this wave's X) -----
         const double x_fuel = x[FB_X_FUEL];
-        if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
-        const double q_dyn = 0.5 * rho * (TAS * TAS);
-        DUO_MARK(2, 5);   // left A
+        DUO_MARK(2, 5);   // past R
 
         // ----- kinematics derivatives (kinematics.jl:181-242; geodesy.jl:125-129) -----
         // ----- radii of curvature (geodesy.jl:125-129), fuel mass, mass properties, gravity at the CoM: while role P works on the atmosphere -----
@@ -304,6 +304,13 @@ DUO_MARK(1, 6);   // at B
 
         DUO_MARK(2, 7);   // mass properties, gravity
         // ----- aerodynamics, the rest (c172.jl:341-373, 226-245) -----
+        emit.xwait(DUO_PT_A);   // ----- role P's point A: density, orthometric altitude -----
+        const double rho = emit.xget(XD_RHO), h_o = emit.xget(XD_HO);
+        // (the range checks role P's own evaluation makes on these — Altitude{Orthometric}, kinematics.jl:199; ISAData, atmosphere.jl:116-135 —
+        // are made here: a status bit in this kernel is a hand-over flag, and this role keeps the book)
+        if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        if (!(h_o * wgs::a < 84852.0 * (wgs::a + h_o))) st |= FB_ST_ISA_RANGE;   // geopotential altitude h a / (a + h) beyond the last ISA layer
+        const double q_dyn = 0.5 * rho * (TAS * TAS);
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
         const double dh_nd = (h_o - env.h_trn) / b;
         const loc l_ge = grid_locate<13, true, AUX_GE>(A + AT_GE_K, RA + AT_GE_K, dh_nd, true, true, gkp(LDS_AERO + AT_GE_K), T.gk);
@@ -344,12 +351,17 @@ DUO_MARK(1, 6);   // at B
         // (pinned: without it the compiler is free to sink this arithmetic behind the barrier, next to its first use)
         asm volatile("" : "+v"(T0.x), "+v"(T0.y), "+v"(T0.z), "+v"(A0.x), "+v"(A0.y), "+v"(A0.z));
         asm volatile("" : "+v"(i11), "+v"(i12), "+v"(i13), "+v"(i22), "+v"(i23), "+v"(i33), "+v"(wy), "+v"(wz));
-        DUO_MARK(2, 8);   // aerodynamics and the propeller-free part of the dynamics done, at B
-        emit.xsync(2);   // ----- barrier B -----
-        DUO_MARK(2, 9);   // left B
+        DUO_MARK(2, 8);   // aerodynamics and the propeller-free part of the dynamics done
+        emit.xwait(DUO_PT_W);   // ----- role P's point W: the propeller's wrench -----
+        DUO_MARK(2, 9);   // past W
         const v3 F_p = {emit.xget(XD_FP), emit.xget(XD_FP + 1), emit.xget(XD_FP + 2)};
         const v3 tau_pb = {emit.xget(XD_TAUP), emit.xget(XD_TAUP + 1), emit.xget(XD_TAUP + 2)};
         const double h_rot = emit.xget(XD_HROT);   // (h_rot, 0, 0)
+        {   // (pinned: the reads above are complete at the point below)
+            double p0 = F_p.x, p1 = F_p.y, p2 = F_p.z, p3 = tau_pb.x, p4 = tau_pb.y, p5 = tau_pb.z, p6 = h_rot;
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6));
+        }
+        emit.xpub(DUO_PT_X);   // ----- point X: wrench and fuel row read (role P may emit its last rows; the exchange rows are this wave's again) -----
         const v3 rw = (T0 + tau_pb) - cross(r_bc, F_p) - v3{0.0, wz * h_rot, -(wy * h_rot)};
         const v3 wd = {i11 * rw.x + i12 * rw.y + i13 * rw.z, i12 * rw.x + i22 * rw.y + i23 * rw.z, i13 * rw.x + i23 * rw.y + i33 * rw.z};
         const v3 vd_b = (A0 + iM * F_p) - cross(wd, r_bc);

@@ -804,22 +804,19 @@ restart:
 // same 256 aircraft per workgroup with EIGHT waves: waves 0-3 ("P") evaluate geoid, atmosphere, propeller and engine, waves 4-7
 // ("D") the airframe: aerodynamics, kinematics, mass, gravity, dynamics — rhs_duo() in c172_duo_device.hpp. Wave w and wave w + 4
 // work on the same 64 aircraft, so a SIMD always has a second instruction stream to issue from; each role fits 256 registers.
-// Per evaluation the pair meets at three workgroup barriers: at the top (the previous evaluation's emits are visible), A (P hands
-// density and orthometric altitude over) and B (P hands the propeller wrench over); a fourth precedes f_step!, which modifies
-// x_{n+1} in place. LDS (full to the last byte): aero and piston tables 8 KB, x_n and the evaluation state 2 x 42 KB, D's seventeen
-// stage sums 34 KB and three of P's four 6 KB, the payload's mass-property sums 20 KB, exchange 6 KB, flags 2 KB.
-// The step's bookkeeping (stage machine, f_step!, status, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
+// The two waves of a pair hand four things over per evaluation (velocity at the propeller D -> P; density and orthometric altitude,
+// then the propeller's wrench P -> D; the control words of the next evaluation D -> P) and keep in step through two counters in LDS,
+// without a barrier (DuoSync, below). LDS (full to the last byte): aero and piston tables 8 KB, x_n and the evaluation state 2 x 42 KB,
+// D's seventeen stage sums 34 KB and three of P's four 6 KB, the payload's mass-property sums 20 KB, exchange 6 KB, flags 2 KB.
+// The step's bookkeeping (stage machine, f_step!, hand-over to the ground-capable pass) is D's, exactly as in k_step_air;
 // P follows through a per-lane flag word and a per-pair control word in LDS.
-// BARRIERS. No data crosses wave pairs: every barrier orders the two waves of ONE pair, and it is a workgroup barrier only because
-// gfx950 has no narrower one. Two things follow, and both lean on how s_barrier works on this hardware rather than on HIP's
-// __syncthreads() contract: (1) a pair whose 64 aircraft are all done (terminated before the launch, or handed over) LEAVES the kernel
-// while the other pairs go on — s_barrier counts the waves of the workgroup that have not ended, so the remaining barriers complete
-// without it; (2) pairs drift apart in their stage machines (a pair re-evaluates k1 after an f_step! that modified a lane; the barrier
-// ahead of f_step! exists only in iterations that have one), so barrier instance n may be "A" for one pair and "top" for another — harmless,
-// because the two waves of a pair always execute the same barrier sequence. tests/test_gpu_duo.py runs both situations (pairs running
-// dry at different steps of one launch, lanes terminated before it) against the one-wave stepper and the oracle.
+// NO WORKGROUP BARRIER inside the stepping loop: nothing crosses wave pairs. A pair whose 64 aircraft are all done (terminated before
+// the launch, or handed over) leaves the kernel while the others go on, and pairs drift apart in their stage machines (a pair
+// re-evaluates k1 after an f_step! that modified one of its lanes); neither needs anything of anybody. (Up to round 3 the pair met at
+// __syncthreads(), which made both a matter of how s_barrier treats ended waves and mismatched call sites on this hardware.)
+// tests/test_gpu_duo.py runs both situations (pairs running dry at different steps of one launch, lanes terminated before it) against
+// the one-wave stepper and the oracle.
 constexpr int DUO_B = 256;
-constexpr int DUO_D_PST_SHIFT = 8;   // bits 8-9 of role D's bookkeeping word: status bits found by role P (altitude / ISA range)
 constexpr int DUO_NP = 4, DUO_ND = 17;   // state rows per role
 constexpr int DUO_NPL = 3;   // how many of role P's four stage sums live in LDS (what is left of the 160 KB)
 // Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation. Role D reads the payload's
@@ -848,37 +845,50 @@ struct InputsDuoD {
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
 };
-// The synchronisation point of a wave PAIR of the wave-specialised stepper. Nothing crosses pairs, so the two waves that share 64 aircraft
-// meet through two counters in LDS (each wave publishes how many synchronisation points it has reached and waits until its partner's
-// count catches up) instead of through a workgroup barrier: behind s_barrier a pair also waited for the three pairs on the other
-// SIMDs at every one of the four points of an evaluation — ~0.5 k cycles each even with the partner already there
-// (profiles/r03_duo_timeline_d_alone.txt). The LDS serves one wave's instructions in order, so what a wave wrote ahead of its counter is
-// there when the partner sees the count; the waits are bounded (a partner that never arrives would otherwise hang the GPU: the pair then
-// goes on, and its aircraft are flagged FB_ST_NAN when the kernel ends).
-// FB_DUO_PAIRSYNC=0 brings the workgroup barriers back (A/B measurements).
+// How the two waves of a PAIR of the wave-specialised stepper (role P: wave w, role D: wave w + 4, the same 64 aircraft) keep in step.
+// Nothing crosses pairs, so they do not meet at workgroup barriers — behind s_barrier a pair also waited for the three pairs on the other
+// SIMDs, ~0.5 k cycles at each of four barriers per evaluation even with its partner already there (profiles/r03_duo_alone.txt) —
+// but through two counters in LDS, one per wave: a wave PUBLISHES the points of its evaluation it has passed (one ds_write), and WAITS,
+// where it needs something of its partner, until the partner's counter has reached the point that produces it. Three points per
+// evaluation and role, numbered 3 i + k + 1 in iteration i of the evaluation loop:
+//     role D publishes  T (k = 0)  top of the loop: control and flag words of this evaluation written, every row of the previous one emitted
+//                       V (k = 1)  velocity at the propeller put (its own state rows read)
+//                       X (k = 2)  propeller wrench and fuel row read
+//     role P publishes  R (k = 0)  state rows read (so: its previous evaluation is complete, fuel row included)
+//                       A (k = 1)  density and orthometric altitude put
+//                       W (k = 2)  propeller wrench put
+//     role D waits for  R before it emits the kinematics rows (role P reads q_ew, h_e) and reads the fuel row;  A before the part of the
+//                       aerodynamics that needs the atmosphere;  W before the last part of the dynamics
+//     role P waits for  T before it reads the control words and the state;  V before the propeller;  X before it emits the engine-speed and
+//                       fuel rows (in place, at the end of its evaluation)
+// Each wait sits where the value is needed and no earlier, so the waves slide against each other: role D — the critical path
+// (tools/duo_alone.sh: 12.7 ms per launch alone on its SIMD, role P 10.7) — almost never finds itself waiting (tools/duo_waitprof.py).
+// The LDS serves one wave's instructions in order: what a wave wrote ahead of its counter is there when the partner sees the count, and
+// what it read ahead of it has been read. The waits are bounded (a partner that never arrives would hang the GPU): the pair then goes on
+// and its aircraft are flagged FB_ST_NAN when the kernel ends.
 // Diagnostic builds (-DFB_STAMP -DFB_DUO_WAITPROF, tools/duo_waitprof.py): wave 0 (role P) and wave 4 (role D) of workgroup 0 add the
-// cycles they spend INSIDE synchronisation point `slot` (0 top, 1 A, 2 B, 3 ahead of f_step!) to g_stamp_acc[slot] / [8 + slot].
-#ifndef FB_DUO_PAIRSYNC
-#define FB_DUO_PAIRSYNC 1
-#endif
+// cycles they spend in wait k to g_stamp_acc[k] / [8 + k].
 #ifdef FB_DUO_SYNC_DEBUG
 __device__ unsigned g_duo_sync_dbg[40];
 #endif
 struct DuoSync {
     volatile __attribute__((address_space(3))) int* mine;
     volatile __attribute__((address_space(3))) int* other;
-    int base;     // synchronisation points passed before this iteration of the evaluation loop. WAVE-UNIFORM: it is advanced by the loops,
-                  // in uniform code (two of an iteration's points sit inside the divergent `if (run)` of the evaluation, where a counter
-                  // incremented in place would advance for the running lanes only)
+    int base;     // DUO_NPT x the iteration of the evaluation loop. WAVE-UNIFORM: advanced by the loops, in uniform code (most points sit inside
+                  // the divergent `if (run)` of the evaluation, where a counter incremented in place would advance for the running lanes only)
     int failed;
 };
-template <bool WAIT = true>
-FBD void duo_sync_wait(DuoSync& sy, int slot) {
-#if FB_DUO_PAIRSYNC
-    const int c = sy.base + slot + 1;   // the points of an iteration in order: 0 top, 1 A, 2 B, 3 ahead of f_step!
-    asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above)
-    *sy.mine = c;
-    if constexpr (!WAIT) { asm volatile("" ::: "memory"); return; }   // (publish only: this wave needs nothing of its partner here)
+FBD void duo_publish(DuoSync& sy, int k) {
+    asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above ...)
+    *sy.mine = sy.base + k + 1;
+    asm volatile("" ::: "memory");   // (... and every one below stays below)
+}
+FBD void duo_wait(DuoSync& sy, int k) {
+#if defined(FB_STAMP) && defined(FB_DUO_WAITPROF)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int c = sy.base + k + 1;
+    asm volatile("" ::: "memory");
     int spins = 0;
 #pragma unroll 1
     while (__builtin_amdgcn_readfirstlane(*sy.other) < c) {
@@ -887,8 +897,8 @@ FBD void duo_sync_wait(DuoSync& sy, int slot) {
         if (++spins > (1 << 10)) {
             sy.failed = 1;
             if ((threadIdx.x & 63) == 0 && atomicAdd(&g_duo_sync_dbg[0], 1u) < 7) {
-                const unsigned k = atomicAdd(&g_duo_sync_dbg[1], 4u);
-                g_duo_sync_dbg[2 + k] = blockIdx.x; g_duo_sync_dbg[3 + k] = threadIdx.x; g_duo_sync_dbg[4 + k] = c; g_duo_sync_dbg[5 + k] = *sy.other;
+                const unsigned q = atomicAdd(&g_duo_sync_dbg[1], 4u);
+                g_duo_sync_dbg[2 + q] = blockIdx.x; g_duo_sync_dbg[3 + q] = threadIdx.x; g_duo_sync_dbg[4 + q] = c; g_duo_sync_dbg[5 + q] = *sy.other;
             }
             break;
         }
@@ -896,37 +906,15 @@ FBD void duo_sync_wait(DuoSync& sy, int slot) {
         if (++spins > (1 << 20)) { sy.failed = 1; break; }
 #endif
     }
-    asm volatile("" ::: "memory");   // (and every one below stays below)
-#else
-    (void)sy; (void)slot;
-    __syncthreads();
-#endif
-}
-template <bool WAIT = true>
-FBD void duo_barrier(DuoSync& sy, int slot) {
+    asm volatile("" ::: "memory");
 #if defined(FB_STAMP) && defined(FB_DUO_WAITPROF)
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    duo_sync_wait<WAIT>(sy, slot);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == DUO_B)) {
-        const int k = slot + (threadIdx.x ? 8 : 0);
-        g_stamp_acc[k] += t1 - t0; g_stamp_cnt[k] += 1;
+        const int q = k + (threadIdx.x ? 8 : 0);
+        g_stamp_acc[q] += t1 - t0; g_stamp_cnt[q] += 1;
     }
-#else
-    duo_sync_wait<WAIT>(sy, slot);
 #endif
 }
-// Which of the four points a role has to WAIT at (FB_DUO_PAIRSYNC; with workgroup barriers everybody waits everywhere):
-//   role P waits at all of them — top: role D's control and flag words and the kinematics rows of the state it is about to read; A: the
-//   velocity at the propeller; B and the point ahead of f_step!: nothing it needs, but they keep it from running so far ahead that it
-//   rewrites (in place) rows role D has yet to read: the fuel row, and x_{n+1} under f_step!;
-//   role D waits at A (density, orthometric altitude — and, because role P has then finished its previous evaluation, the fuel row) and
-//   at B (the propeller's wrench). At the top and ahead of f_step! it only publishes: what it reads there is its own, and role P has
-//   read the state rows it needs before A (all its state reads sit at the head of rhs_duo<1>()).
-#ifndef FB_DUO_D_WAITS_EVERYWHERE
-#define FB_DUO_D_WAITS_EVERYWHERE 0
-#endif
-constexpr bool DUO_D_WAIT_TOP = !FB_DUO_PAIRSYNC || FB_DUO_D_WAITS_EVERYWHERE;
 
 template <int ROLE>
 struct DuoEmit {
@@ -938,7 +926,6 @@ struct DuoEmit {
     lds_ptr acc_l;     // this role's stage sums in LDS: D's seventeen [17][DUO_B], the first DUO_NPL of P's four
     double* acc_r;     // role P: the rest of its stage sums (registers)
     lds_ptr xch_l;     // exchange rows 6.. [XD_ROWS - 6][DUO_B]
-    int* dst_p;        // role D's bookkeeping word of this lane (role P leaves the status bits it finds there)
     lds_ptr xov_l;     // exchange rows 0-5: the angular / linear velocity rows of the evaluation panel (see c172_duo_device.hpp)
     double eb, ee, em;
     bool last;
@@ -983,8 +970,8 @@ struct DuoEmit {
     }
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
-    __device__ __forceinline__ void xsync(int slot) const { duo_barrier(*sync, slot); }
-    __device__ __forceinline__ void xstatus(int32_t st) const { *dst_p |= (st & 3) << DUO_D_PST_SHIFT; }   // (FB_ST_ALT_RANGE | FB_ST_ISA_RANGE)
+    __device__ __forceinline__ void xpub(int k) const { duo_publish(*sync, k); }
+    __device__ __forceinline__ void xwait(int k) const { duo_wait(*sync, k); }
 };
 // every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
 constexpr bool duo_rows_ok() {
@@ -1003,13 +990,12 @@ static_assert(duo_rows_ok(), "k_step_duo: row ownership / stage-sum slots");
 static_assert(DuoEmit<1>::owned(FB_X_FUEL) && DuoEmit<1>::owned(FB_X_ENG_OMEGA) && DuoEmit<2>::owned(FB_X_Q_WB) && DuoEmit<2>::owned(FB_X_V_EB_B + 2),
               "rhs_duo emits the engine and fuel rows in role P, everything else in role D");
 enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
-enum { DUO_C_EXIT = 4, DUO_C_CB = 8 };                              // per-pair control word: stage | EXIT | CB
+enum { DUO_C_EXIT = 4 };                                            // per-pair control word: stage | EXIT
 template <int KIN>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
     using SV = StateLds<B, false>;
     static_assert(KIN == FB_KIN_WA, "the wave-specialised stepper is built for the WA mechanisation");
-    static_assert(FB_ST_ALT_RANGE == 1 && FB_ST_ISA_RANGE == 2, "DuoEmit::xstatus");
     __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs_duo())
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
@@ -1078,8 +1064,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
 #pragma unroll 1
         while (true) {
-            DUO_MARK(1, 15);  // (arrival at the top barrier, counted from the previous evaluation's start)
-            duo_barrier(sy, 0);   // the previous evaluation's emits, and D's flag / control words, are visible
+            DUO_MARK(1, 15);  // (arrival at the top of the loop, counted from the previous evaluation's start)
+            duo_wait(sy, DUO_PT_T);   // role D's control and flag words of this evaluation are written, every row of the previous one emitted
             DUO_MARK(1, 0);
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
@@ -1101,23 +1087,25 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     StepAux aux;
                     InputsDuoP inl = in;
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
-                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, &dst_l[t], (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
+                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
                     const SV xv = {sk.xrd_l + t + lds_off};
 #if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 2
-                    // timing diagnostic (tools/duo_alone.sh): role D alone on its SIMD — role P puts plausible constants and waits
+                    // timing diagnostic (tools/duo_alone.sh): role D alone on its SIMD — role P puts plausible constants and publishes its points
+                    emit.xpub(DUO_PT_R);
                     emit.xput(XD_RHO, 1.1); emit.xput(XD_HO, 1000.0);
-                    emit.xsync(1);
+                    emit.xpub(DUO_PT_A);
+                    emit.xwait(DUO_PT_V);
                     emit.xput(XD_FP, 900.0); emit.xput(XD_FP + 1, 0.0); emit.xput(XD_FP + 2, 0.0);
                     emit.xput(XD_TAUP, -150.0); emit.xput(XD_TAUP + 1, 0.0); emit.xput(XD_TAUP + 2, 700.0); emit.xput(XD_HROT, 80.0);
-                    emit.xsync(2);
+                    emit.xpub(DUO_PT_W);
+                    emit.xwait(DUO_PT_X);
                     (void)xv; (void)aux; (void)inl;
 #else
                     rhs_duo<1>(xv, 0, eng, inl, a.env, T, emit, aux);
 #endif
                 }
-            } else { duo_barrier(sy, 1); duo_barrier(sy, 2); }   // (synchronisation points A and B of an evaluation nobody runs)
-            if (c & DUO_C_CB) duo_barrier(sy, 3);
-            sy.base += (c & DUO_C_CB) ? 4 : 3;
+            } else duo_publish(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
+            sy.base += DUO_NPT;
         }
         return;
     }
@@ -1166,10 +1154,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
-        duo_barrier<DUO_D_WAIT_TOP>(sy, 0);
+        duo_publish(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
         DUO_MARK(2, 0);
         if (exit_) break;
-        const bool cb = stage == 0 && pending_cb && !redoing;
         const StageK sk = stage_k(stage);
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
@@ -1183,22 +1170,22 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 const int d0 = dst_l[t];
                 InputsDuoD inl = in;
                 inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
-                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, nullptr, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
+                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
                 const SV xv = {sk.xrd_l + t + lds_off};
 #if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 1
                 // timing diagnostic: role P alone on its SIMD — role D hands the velocity at the propeller over and waits
                 emit.xput(XD_VP, 50.0); emit.xput(XD_VP + 1, 0.0); emit.xput(XD_VP + 2, 2.0);
-                emit.xsync(1); emit.xsync(2);
+                emit.xpub(DUO_PT_V); emit.xwait(DUO_PT_R); emit.xwait(DUO_PT_A); emit.xwait(DUO_PT_W); emit.xpub(DUO_PT_X);
                 (void)xv; (void)inl; (void)d0;
 #else
                 bits = rhs_duo<2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
 #endif
             }
-        } else { duo_barrier(sy, 1); duo_barrier(sy, 2); }
-        if (cb) duo_barrier<DUO_D_WAIT_TOP>(sy, 3);   // role P has read x_{n+1} for the last time (ahead of A): f_step! may modify it
-        sy.base += cb ? 4 : 3;
+        } else duo_publish(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
+        // (f_step!, below, modifies x_{n+1} in place at the end of a step's last evaluation: role P has read what it reads of it — its
+        // point R, which this wave has waited for in the evaluation)
+        sy.base += DUO_NPT;
         int d = dst_l[t];
-        if (d & (3 << DUO_D_PST_SHIFT)) { if (run) bits |= (d >> DUO_D_PST_SHIFT) & 3; d &= ~(3 << DUO_D_PST_SHIFT); }   // status bits found by role P
         // within reach of the ground, or an exception (altitude / ISA range): nothing is committed for this lane, the ground-capable pass
         // steps it again from the launch-start state and ends its simulation where the reference would (see k_step_air, `tkey`)
         if (run && bits != 0) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }
@@ -1251,7 +1238,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         dst_l[t] = d;
         flags_l[t] = (run ? DUO_F_RUN : 0) | (zero_acc ? DUO_F_ZERO_ACC : 0) | (((d >> D_ENG_SHIFT) & 3) << DUO_F_ENG_SHIFT);
         if ((threadIdx.x & 63) == 0)
-            ctrl_l[pair] = stage | (exit_ ? DUO_C_EXIT : 0) | ((stage == 0 && pending_cb && !redoing) ? DUO_C_CB : 0);
+            ctrl_l[pair] = stage | (exit_ ? DUO_C_EXIT : 0);
     }
     const int d = dst_l[t];
     if (!(d & D_ACTIVE)) return;
@@ -1620,7 +1607,7 @@ __global__ __launch_bounds__(256) void k_kin_convert(KArgs a, const double* tp) 
     const quat q_nb = {k[0], k[1], k[2], k[3]}, q_en = {k[4], k[5], k[6], k[7]};
     const double h_e = k[8];
     const v3 n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
-    double o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double o[9] = {0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (KIN == FB_KIN_ECEF) {
         const quat q_eb = qmul(q_en, q_nb);
         o[0] = q_eb.w; o[1] = q_eb.x; o[2] = q_eb.y; o[3] = q_eb.z; o[4] = n_e.x; o[5] = n_e.y; o[6] = n_e.z; o[7] = h_e;
