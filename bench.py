@@ -164,6 +164,20 @@ def parity_sample(fb, x0, u0, ui0, s0, cell, dtype, nsteps=1000):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Rehearsal of the N > 1 code path on a ONE-GPU box (FLIGHTBATCH_BENCH_REHEARSAL=1): every rank uses GPU 0, the process group is gloo
+# and the collectives run on host copies. The numbers mean nothing; what it exercises is every line a multi-GPU run executes
+# (tools/rehearse_multi_gpu.sh). Never set by the driver.
+REHEARSAL = os.environ.get("FLIGHTBATCH_BENCH_REHEARSAL", "0") == "1"
+
+
+def _cdev():
+    return "cpu" if REHEARSAL else "cuda"
+
+
+def _gather_state(fb, x_dev, n_total):
+    return fb.sharding.all_gather_state(x_dev.cpu() if REHEARSAL else x_dev, n_total)
+
+
 def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     """trim + warm-up + the timed region for one shard of the Cessna172Sv0 batch. Returns a dict of measurements (and the
     initial condition on the host, for the CPU legs)."""
@@ -209,18 +223,18 @@ def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     out["quat_off_unit"] = int(((np.abs(np.sqrt((xf[12:16] ** 2).sum(0)) - 1) > qtol) | (np.abs(np.sqrt((xf[16:20] ** 2).sum(0)) - 1) > qtol)).sum())
     out["non_finite"] = int((~np.isfinite(xf)).any(axis=0).sum())
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_cdev())
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         every = [float(e.item()) for e in every]
         out["elapsed"] = max(every); out["elapsed_per_rank"] = every
         cnt = torch.tensor([out["trim_ok"], out["status_bad"], out["fuel_not_decreasing"], out["quat_off_unit"], out["non_finite"], n],
-                           dtype=torch.int64, device="cuda")
+                           dtype=torch.int64, device=_cdev())
         dist.all_reduce(cnt)
         out["trim_ok"], out["status_bad"], out["fuel_not_decreasing"], out["quat_off_unit"], out["non_finite"], out["n_total"] = [int(v) for v in cnt.tolist()]
         # trajectory collection: ONE RCCL all-gather of the final states over xGMI (north star)
         torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
-        gathered = fb.sharding.all_gather_state(x_dev, out["n_total"])
+        gathered = _gather_state(fb, x_dev, out["n_total"])
         torch.cuda.synchronize(); out["gather_ms"] = (time.perf_counter() - g0) * 1e3
         assert gathered.shape == (fb.K["FB_NX"], out["n_total"])
         del gathered
@@ -282,13 +296,13 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
     bad = int((w.status != 0).sum())
     n_total, gather_ms = n, None
     if world > 1:
-        t = torch.tensor([el, float(bad)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el, float(bad)], dtype=torch.float64, device=_cdev())
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         el = max(float(e[0].item()) for e in every); bad = int(sum(float(e[1].item()) for e in every))
         n_total = n * world
         torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
-        gathered = fb.sharding.all_gather_state(x_dev, n_total)
+        gathered = _gather_state(fb, x_dev, n_total)
         torch.cuda.synchronize(); gather_ms = (time.perf_counter() - g0) * 1e3
         assert gathered.shape == (fb.K["FB_X2_NX"], n_total)
         del gathered
@@ -450,7 +464,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if REHEARSAL else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nnodes=1 "
@@ -462,7 +476,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: libflightbatch has no CPU path")
     if world > 1:   # the process group first: nothing of this process has touched a device before RCCL binds this rank to its GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSAL:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
     import ctypes as C
