@@ -16,7 +16,11 @@ from flightbatch.guidance import Segment  # noqa: E402
 LOC = (np.deg2rad(47.80433), np.deg2rad(12.997)); H_ORTH = 427.2; PSI = np.deg2rad(157.0)   # c172_demos.jl:17-19
 
 
-def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False):
+def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False):
+    """hold_decrab = False: the demo's callback to the letter — it leaves `seg.u.hor_gdc_req` set in the flare, so the guidance law puts the
+    lateral channel back on track hold (χ_β) at its next update and the de-crab (φ_β with β_ref = ψ − χ_12) lasts one control period.
+    hold_decrab = True: the request is dropped at the flare, so the bank + sideslip mode stays in force until touchdown (a variant, not
+    the demo)."""
     K = fb.K
     rng = np.random.default_rng(seed)
     w = fb.Cessna172Xv2World(n)
@@ -63,9 +67,8 @@ def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False):
             d = psi - chi_12
             cu[K["FB_CU_BETA_REF"], flare] = (d + 2 * np.pi * np.floor((np.pi - d) / (2 * np.pi)))[flare]     # wrap_to_π
             cu[K["FB_CU_PHI_REF"], flare] = 0.0
-            # the demo leaves hor_gdc_req set, so its guidance re-requests χ_β on the following update; the request is dropped
-            # here so that the bank + sideslip mode of the flare (the de-crab) stays in force until touchdown
-            cu[K["FB_CU_SEG_HOR_REQ"], flare] = 0
+            if hold_decrab:   # (the demo leaves hor_gdc_req set: c172_demos.jl:447-461)
+                cu[K["FB_CU_SEG_HOR_REQ"], flare] = 0
             phase[flare] = 2
         touch = (phase == 2) & on_gnd
         if touch.any():
@@ -97,4 +100,4 @@ def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 64, verbose=True)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 64, verbose=True, hold_decrab=len(sys.argv) > 2 and sys.argv[2] == "hold")

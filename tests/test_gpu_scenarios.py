@@ -10,10 +10,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_crosswind_landing_batch(fb):
+@pytest.mark.parametrize("hold_decrab", [False, True])
+def test_crosswind_landing_batch(fb, hold_decrab):
+    """hold_decrab = False is the demo's callback to the letter (it leaves the horizontal guidance request set in the flare, so the
+    de-crab lasts one control period); True keeps the bank + sideslip mode to touchdown — both must land every aircraft."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import crosswind_landing as demo
-    out = demo.run(n=32, t_end=150.0, seed=3)
+    out = demo.run(n=32, t_end=150.0, seed=3, hold_decrab=hold_decrab)
     td = out["touchdown"]
     print("touchdown: %.1f-%.1f s, %.0f..%.0f m past the threshold, |cross-track| <= %.2f m; final ground speed <= %.3f m/s"
           % (td[0].min(), td[0].max(), td[1].min(), td[1].max(), np.abs(td[2]).max(), out["v_gnd"].max()))
