@@ -94,7 +94,8 @@ def check(rc: int):
 
 def header_constants() -> dict:
     """Parse the enum constants of include/flightbatch.h (single source of truth for layouts)."""
-    text = open(HEADER_PATH).read()
+    with open(HEADER_PATH) as f:
+        text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out: dict = {}
     for body in re.findall(r"enum\s*\{(.*?)\}", text, flags=re.S):

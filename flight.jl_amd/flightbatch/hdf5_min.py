@@ -23,7 +23,8 @@ class HDF5Error(ValueError):
 
 class File:
     def __init__(self, path: str):
-        self.b = open(path, "rb").read()
+        with open(path, "rb") as f:
+            self.b = f.read()
         b = self.b
         if b[:8] != b"\x89HDF\r\n\x1a\n":
             raise HDF5Error("not an HDF5 file")
