@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Build-time guard against a register-allocator bug seen with this ROCm's LLVM on gfx950 at full register pressure:
+"""DIAGNOSTIC since round 3 (the build's gate is tools/check_mir_spills.py, which sees the blocks as the register allocator saw them
+and has no false positives; this scan of the final assembly cannot tell a reload folded into a phi copy at the end of an else branch
+from one placed too early in the join block, and refused correct kernels). Kept because it points at the place in the assembly.
+
+The first guard against a register-allocator bug seen with this ROCm's LLVM on gfx950 at full register pressure:
 VGPR spill code (a scratch_store "Folded Spill" / v_accvgpr_write, or a scratch_load "Folded Reload") gets placed in a control-flow
 JOIN block BEFORE the `s_or_b64 exec, exec, s[..]` that re-enables the lanes of the other branch, so only the lanes of one branch
 save (or get back) their value and the others later work with garbage — results then depend on what the scratch memory held,
