@@ -190,15 +190,17 @@ template <bool X> struct Dims { static constexpr int NXT = X ? (int)FB_X2_NX : (
 
 // vehicle.y as the control laws see it, from the state x (device row order): one RHS evaluation with a partial sink — everything
 // that does not feed the twelve tapped outputs is dead code. GROUND = false: the caller knows the aircraft is clear of the terrain.
-template <bool GROUND, class CmdFn>
+// the row of the ellipsoidal altitude in each mechanisation's own state block (c172_device_impl.inc, rhs())
+template <int KIN> constexpr int h_e_row() { return KIN == FB_KIN_WA ? (int)FB_X_H_E : (KIN == FB_KIN_ECEF ? FB_X_Q_WB + 7 : FB_X_Q_WB + 5); }
+template <bool GROUND, int KIN, class CmdFn>
 FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double (&x)[FB_X2_NX], int stall, int eng, int ui, CmdFn&& cmd_of) {
     const InputsX in = {&x[X2_ACT], a.u + i, a.n, ui};
     StepAux aux;
     CtlSink tap;
-    rhs<FB_KIN_WA, GROUND>(x, stall, eng, in, a.env, T, [](int, double) {}, aux, tap);
+    rhs<KIN, GROUND>(x, stall, eng, in, a.env, T, [](int, double) {}, aux, tap);
     CtlIn v;
     v.lat = tap.lat; v.lon = tap.lon;
-    v.EAS = tap.EAS; v.h_e = x[FB_X_H_E]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
+    v.EAS = tap.EAS; v.h_e = x[h_e_row<KIN>()]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
     v.w_wb_b = {tap.wx, tap.wy, tap.wz};
     v.w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
     v.alpha = tap.alpha; v.beta = tap.beta; v.alpha_filt = x[FB_X_ALPHA_FILT]; v.beta_filt = x[FB_X_BETA_FILT];
@@ -658,7 +660,7 @@ restart:
                         v.w_wb_b = {tap.wx, tap.wy, tap.wz};
                         v.alpha = tap.alpha; v.beta = tap.beta;
                         auto XS = [&](int k) { return xs_l[SV::row(k) * B + t]; };   // x_{n+1}, before f_step! touches it
-                        v.h_e = XS(FB_X_H_E);
+                        v.h_e = XS(h_e_row<KIN>());
                         v.w_eb_b = {XS(FB_X_OMEGA_EB_B), XS(FB_X_OMEGA_EB_B + 1), XS(FB_X_OMEGA_EB_B + 2)};
                         v.alpha_filt = XS(FB_X_ALPHA_FILT); v.beta_filt = XS(FB_X_BETA_FILT);
                         v.n_eng = XS(FB_X_ENG_OMEGA) / c172::w_rated;

@@ -1,4 +1,4 @@
-// c172x_kernels.hpp — Cessna172Xv2 kernels besides the stepping kernels (k_step_air<WA, true, GROUND> in c172_kernels.hpp, which also run the control laws every Δt):
+// c172x_kernels.hpp — Cessna172Xv2 kernels besides the stepping kernels (k_step_air<KIN, true, GROUND> in c172_kernels.hpp, which also run the control laws every Δt):
 //   k_x2_ctl   f_periodic!(avionics, vehicle): the control laws on the outputs of the last f_ode! (aircraftbase.jl:232-242)
 //   k_x2_init  f_init!(aircraft, trim) after the trim solve: actuator states and the control-law initialisation
 //              (c172x.jl:285-326; aircraftbase.jl:255-265; c172x_ctl.jl:463-519, 1000-1032)
@@ -16,12 +16,13 @@ struct CtlArgs {
 };
 
 // vehicle.y as the control laws see it (the ground-capable form of c172_kernels.hpp's x2_ctl_inputs, discrete states from memory)
-template <class CmdFn>
+template <int KIN, class CmdFn>
 FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double (&x)[FB_X2_NX], CmdFn&& cmd_of) {
-    return x2_ctl_inputs<true>(a, i, T, x, a.s[i], a.s[a.n + i], a.ui[i], cmd_of);
+    return x2_ctl_inputs<true, KIN>(a, i, T, x, a.s[i], a.s[a.n + i], a.ui[i], cmd_of);
 }
 
 constexpr int CTL_GAINS_MAX = 6144;   // doubles of LDS reserved for the gains blob (the shipped lookups need 5744)
+template <int KIN>
 __global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
     // The partial sink needs none of the aero / engine / propeller tables (everything that reads them is dead code here), so
     // they are not staged; the pointers below are never dereferenced.
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
 #pragma unroll
         for (int k = 0; k < 8; k++) x[FB_X_Q_WB + k] = a.q_pre[(int64_t)k * a.n + i];
     }
-    const CtlIn v = x2_ctl_inputs(a, i, T, x, [&](int k) { return x2_command(a, i, k); });
+    const CtlIn v = x2_ctl_inputs<KIN>(a, i, T, x, [&](int k) { return x2_command(a, i, k); });
     const CtlMem M = {const_cast<double*>(a.cu) + i, a.cs + i, a.n};
     gdc_update(M, v);   // Avionics f_periodic!: guidance first, then the control laws (c172x2.jl:27-37)
     const CtlTabT<ldsd_cptr> tab = ctl_tab((ldsd_cptr)gains_l, c.off, v.EAS, v.h_e);
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void k_x2_ctl(KArgs a, CtlArgs c) {
 
 // After k_trim has left the trimmed Sv0 state, u and s: actuator states = actuator commands = trim values (c172x.jl:253-271),
 // brakes released, then f_init!(avionics, vehicle) for a freshly built model.
+template <int KIN>
 __global__ __launch_bounds__(256) void k_x2_init(KArgs a, CtlArgs c) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_x2_init(KArgs a, CtlArgs c) {
                                   u[(int64_t)FB_U_RUDDER * n + i], u[(int64_t)FB_U_FLAPS * n + i], 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < FB_NACT; k++) { x[X2_ACT + k] = cmd7[k]; a.x[(int64_t)(X2_ACT + k) * n + i] = cmd7[k]; }
-    const CtlIn v = x2_ctl_inputs(a, i, T, x, [&](int k) { return clampd(cmd7[k], k == 0 ? 0.0 : -1.0, 1.0); });
+    const CtlIn v = x2_ctl_inputs<KIN>(a, i, T, x, [&](int k) { return clampd(cmd7[k], k == 0 ? 0.0 : -1.0, 1.0); });
     const CtlMem M = {cu + i, a.cs + i, n};
     for (int k = 0; k < FB_NCS; k++) M.S(k) = 0;
     M.S(FB_CS_H_STATE) = FB_ALT_HOLD;

@@ -117,13 +117,15 @@ static void fsal_invalidate(fb_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipMemsetAsync(h->k1_valid, 0, sizeof(int32_t) * h->n, h->stream);
 }
-// states of the C ABI: 27 (WA), 26 (ECEF: q_eb[4] n_e[3] h_e), 24 (NED: ψ θ φ ϕ λ h_e), 34 (Cessna172Xv2); the device keeps
+// states of the C ABI: 27 (WA), 26 (ECEF: q_eb[4] n_e[3] h_e), 24 (NED: ψ θ φ ϕ λ h_e), Cessna172Xv2 seven more (34 / 33 / 31); the device keeps
 // 27 (34) rows for every mechanisation, the unused kinematic rows stay zero
-static int nx_of(fb_handle h) { return is_x2(h) ? (int)FB_X2_NX : (h->kin == FB_KIN_ECEF ? FB_NX - 1 : (h->kin == FB_KIN_NED ? FB_NX - 3 : (int)FB_NX)); }
+static int nx_of(fb_handle h) { return (is_x2(h) ? (int)FB_X2_NX : (int)FB_NX) - (h->kin == FB_KIN_ECEF ? 1 : (h->kin == FB_KIN_NED ? 3 : 0)); }
 static int ecef_dev_row(int k) { return k < FB_X_Q_WB + 8 ? k : k + 1; }
 static int ned_dev_row(int k) { return k < FB_X_Q_WB + 6 ? k : k + 3; }
 // Cessna172X: row of the C ABI state layout (reference order: act after pwp) -> device row (actuators last)
 static int x2_dev_row(int k) { return k < FB_X2_ACT ? k : (k < FB_X2_KIN ? FB_NX + (k - FB_X2_ACT) : k - FB_NACT); }
+static int x2_ecef_dev_row(int k) { return k < FB_X2_KIN ? x2_dev_row(k) : ecef_dev_row(k - FB_NACT); }
+static int x2_ned_dev_row(int k) { return k < FB_X2_KIN ? x2_dev_row(k) : ned_dev_row(k - FB_NACT); }
 typedef int (*row_map_t)(int);
 static row_map_t row_map_of(fb_handle h);
 static int32_t check_ready_x2(fb_handle h) {
@@ -132,7 +134,7 @@ static int32_t check_ready_x2(fb_handle h) {
     return 0;
 }
 static row_map_t row_map_of(fb_handle h) {
-    if (is_x2(h)) return x2_dev_row;
+    if (is_x2(h)) return h->kin == FB_KIN_ECEF ? x2_ecef_dev_row : (h->kin == FB_KIN_NED ? x2_ned_dev_row : x2_dev_row);
     if (h->kin == FB_KIN_ECEF) return ecef_dev_row;
     if (h->kin == FB_KIN_NED) return ned_dev_row;
     return nullptr;
@@ -140,7 +142,9 @@ static row_map_t row_map_of(fb_handle h) {
 // one launch statement per (model, kinematics) instance of a kernel template
 #define FB_LAUNCH_MK(KERNEL, GRID, BLOCK, ...)                                                                                       \
     do {                                                                                                                              \
-        if (is_x2(h)) hipLaunchKernelGGL((KERNEL<true, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                          \
+        if (is_x2(h) && h->kin == FB_KIN_ECEF) hipLaunchKernelGGL((KERNEL<true, FB_KIN_ECEF>), GRID, BLOCK, 0, h->stream, __VA_ARGS__); \
+        else if (is_x2(h) && h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<true, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__); \
+        else if (is_x2(h)) hipLaunchKernelGGL((KERNEL<true, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                     \
         else if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL((KERNEL<false, FB_KIN_ECEF>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);     \
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
@@ -149,9 +153,23 @@ static row_map_t row_map_of(fb_handle h) {
 // wave-specialised k_step_duo (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air
 static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
+#define FB_STEP_X2(KIN, GRID, A, K)                                                                                                   \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL((k_step_air<KIN, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                     \
+        hipLaunchKernelGGL((k_step_air<KIN, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
+    } while (0)
+// the Cessna172Xv2 kernels that are not stepping kernels take the mechanisation alone
+#define FB_LAUNCH_X2K(KERNEL, N, ...)                                                                                                 \
+    do {                                                                                                                              \
+        if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL(KERNEL<FB_KIN_ECEF>, grid_for(N, 256), dim3(256), 0, h->stream, __VA_ARGS__);  \
+        else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL(KERNEL<FB_KIN_NED>, grid_for(N, 256), dim3(256), 0, h->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<FB_KIN_WA>, grid_for(N, 256), dim3(256), 0, h->stream, __VA_ARGS__);                          \
+    } while (0)
 #define FB_LAUNCH_STEP(GRID, A, K)                                                                                                    \
     do {                                                                                                                              \
-        if (is_x2(h)) {                                                                                                               \
+        if (is_x2(h) && h->kin == FB_KIN_ECEF) FB_STEP_X2(FB_KIN_ECEF, GRID, A, K);                                                   \
+        else if (is_x2(h) && h->kin == FB_KIN_NED) FB_STEP_X2(FB_KIN_NED, GRID, A, K);                                                \
+        else if (is_x2(h)) {                                                                                                          \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
@@ -252,8 +270,7 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (!out) return fail("out is null");
     *out = nullptr;
     if (model_id != FB_MODEL_C172S0 && model_id != FB_MODEL_C172X2 && model_id != FB_MODEL_ROBOT2D) return fail("unknown model id");
-    if (model_id == FB_MODEL_C172S0 && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
-    if (model_id == FB_MODEL_C172X2 && kin_id != FB_KIN_WA) return fail("Cessna172Xv2: only FB_KIN_WA is implemented");
+    if ((model_id == FB_MODEL_C172S0 || model_id == FB_MODEL_C172X2) && kin_id != FB_KIN_WA && kin_id != FB_KIN_ECEF && kin_id != FB_KIN_NED) return fail("unknown kinematics id");
     if (model_id == FB_MODEL_C172X2 && dtype != FB_F64) return fail("Cessna172Xv2: only FB_F64 is implemented");
     if (model_id == FB_MODEL_C172S0 && dtype == FB_F32 && kin_id != FB_KIN_WA) return fail("Cessna172Sv0 in fp32: only FB_KIN_WA is implemented");
     if (dtype != FB_F64 && dtype != FB_F32) return fail("unknown dtype");
@@ -479,7 +496,7 @@ int32_t fb_f_init(fb_handle h, const double* init, int32_t ninit) {
     if (is_x2(h) && ninit == 0) {   // f_init!(avionics, vehicle) on the state the host has set
         if (int32_t rc = check_ready_x2(h)) return rc;
         fsal_invalidate(h);
-        hipLaunchKernelGGL(k_x2_init, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        FB_LAUNCH_X2K(k_x2_init, h->n, make_args(h), ctl_args(h, 0));
         HIPCHK(hipGetLastError());
         h->steps_done = 0;
         h->t = 0.0;
@@ -508,7 +525,7 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL(k_kin_convert<FB_KIN_ECEF>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
     if (h->kin == FB_KIN_NED) hipLaunchKernelGGL(k_kin_convert<FB_KIN_NED>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
     if (is_x2(h)) {  // f_init!(aircraft, trim): actuator states, then f_init!(avionics, vehicle) (aircraftbase.jl:255-265)
-        hipLaunchKernelGGL(k_x2_init, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        FB_LAUNCH_X2K(k_x2_init, n, make_args(h), ctl_args(h, 0));
         HIPCHK(hipGetLastError());
     }
     h->steps_done = 0;
@@ -563,7 +580,7 @@ int32_t fb_f_periodic(fb_handle h) {
     if (is_x2(h)) {  // f_periodic!(Unconditional(), world): the control laws on the outputs of an f_ode! at the current x
         if (int32_t rc = check_ready_x2(h)) return rc;
         HIPCHK(hipSetDevice(h->device));
-        hipLaunchKernelGGL(k_x2_ctl, grid_for(h->n, 256), dim3(256), 0, h->stream, make_args(h), ctl_args(h, 0));
+        FB_LAUNCH_X2K(k_x2_ctl, h->n, make_args(h), ctl_args(h, 0));
         HIPCHK(hipGetLastError());
         return 0;
     }

@@ -85,8 +85,9 @@ class Cessna172Xv2World(BatchedWorld):
     MODEL = "FB_MODEL_C172X2"
     _CKPT_ARRAYS = ("x", "s", "u", "ui", "cu", "cs")
 
-    def __init__(self, n: int, device: int = 0, tables: dict | None = None, gains: np.ndarray | None = None):
-        super().__init__(n, device, tables)
+    def __init__(self, n: int, device: int = 0, tables: dict | None = None, gains: np.ndarray | None = None, kinematics: str = "WA"):
+        """kinematics: Cessna172Xv2(kinematics) (FA/c172/c172x/c172x2.jl:57-59) — "WA" (34 states), "ECEF" (33) or "NED" (31)."""
+        super().__init__(n, device, tables, kinematics=kinematics)
         blob = np.ascontiguousarray(gains if gains is not None else ctl_gains.ctl_gains_blob(), dtype=np.float64)
         dims = (C.c_int64 * 1)(blob.size)
         check(lib.fb_set_table(self._h, K["FB_TABLE_CTL_GAINS"], blob.ctypes.data_as(C.c_void_p), dims, 1))

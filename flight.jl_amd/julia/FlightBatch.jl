@@ -49,7 +49,7 @@ const TABLE_CTL_GAINS = Cint(5)
 const NCU, NCS = 28, 66                                                 # FB_NCU, FB_NCS (Cessna172Xv2 control laws)
 
 "N instances of SimpleWorld(aircraft) resident on one GPU (the batched counterpart of a root Model).
-`aircraft` is `Cessna172Sv0(kin)` (kin = WA(), ECEF() or NED()) or `Cessna172Xv2()`; its type picks the model id."
+`aircraft` is `Cessna172Sv0(kin)` or `Cessna172Xv2(kin)` (kin = WA(), ECEF() or NED()); its type picks the model id."
 mutable struct BatchedWorld <: ModelDefinition
     handle::Ptr{Cvoid}
     n::Int
@@ -61,7 +61,7 @@ mutable struct BatchedWorld <: ModelDefinition
         check(ccall((:fb_create, lib), Cint, (Cint, Cint, Cint, Int64, Cint, Ptr{Ptr{Cvoid}}), model, kin, 0, n, device, h))
         nx = Ref{Cint}(0)
         check(ccall((:fb_dims, lib), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}, Ptr{Cint}), h[], nx, C_NULL, C_NULL, C_NULL))
-        w = new(h[], n, nx[])      # 27 (WA) / 26 (ECEF) / 24 (NED) / 34 (Xv2): length(Model(aircraft).x)
+        w = new(h[], n, nx[])      # 27 (WA) / 26 (ECEF) / 24 (NED), Xv2 seven more: length(Model(aircraft).x)
         finalizer(w -> ccall((:fb_destroy, lib), Cint, (Ptr{Cvoid},), w.handle), w)
         upload_tables!(w)
         # Xv2: the ten gain lookups of c172x/control/data packed as include/flightbatch.h documents (flightbatch/ctl_gains.py)

@@ -127,6 +127,9 @@ enum {
  * Continuous state x [N x FB_X2_NX], in the order of the reference's ComponentVector (`act` is the last Systems
  * field, c172.jl:678-686): rows 0-11 as Cessna172Sv0 (aero, ldg, fuel, pwp), rows FB_X2_ACT + {THROTTLE..BRAKE_RIGHT}
  * the seven actuator positions, rows 19-27 kinematics (q_wb, q_ew, h_e), rows 28-33 dynamics (w_eb_b, v_eb_b).
+ * Cessna172Xv2(kinematics) (c172x2.jl:57-59) with FB_KIN_ECEF / FB_KIN_NED: the kinematic block is that mechanisation's
+ * (8 rows q_eb, n_e, h_e / 6 rows psi, theta, phi, lat, lon, h_e — FP/kinematics.jl:250-425), the dynamics rows follow it
+ * directly, and x has 33 / 31 rows (fb_dims reports the number).
  * Discrete state s and inputs u/ui as Cessna172Sv0, except that u's throttle/aileron/elevator/rudder (+offset) rows
  * are ignored: those four actuators are commanded by the control laws; FB_U_FLAPS / FB_U_BRAKE_* are the commands of
  * the remaining three actuators (act.flaps.u etc.). Output record y as Cessna172Sv0. */
@@ -239,8 +242,9 @@ int32_t fb_set_stream(fb_handle h, void* hip_stream);
 /* Use caller-owned DEVICE memory for x and s [N x FB_NS int32] (e.g. a torch tensor's data_ptr), so collectives can run
  * on the state without a host round trip. NULL restores the handle's own buffers. The buffer holds the DEVICE layout:
  * [N x FB_NX] doubles for every Cessna172Sv0 mechanisation (ECEF / NED: their 8 / 6 kinematic states in rows 12.., the
- * remaining kinematic rows zero, then w_eb_b, v_eb_b in rows 21-26) and [N x FB_X2_NX] for Cessna172Xv2 with the Sv0 rows
- * first and the seven actuator positions in rows 27-33; fb_get_state / fb_set_state present the reference's order. */
+ * remaining kinematic rows zero, then w_eb_b, v_eb_b in rows 21-26) and [N x FB_X2_NX] for every Cessna172Xv2 mechanisation
+ * with the Sv0 rows first (laid out as just described) and the seven actuator positions in rows 27-33; fb_get_state /
+ * fb_set_state present the reference's order and row count. */
 int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev);
 
 /* Lookup tables: what the reference builds at construction time (Appendix B of SURVEY.md). */

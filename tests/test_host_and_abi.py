@@ -40,6 +40,7 @@ def test_no_cpu_fallback(fb):
     # unknown models / mechanisations / dtypes and unsupported combinations are refused before anything touches a device (so this
     # holds with and without a GPU, and no handle is ever created here), not silently substituted
     for args, msg in (((99, 0, fb.K["FB_F64"], 8, 0), b"unknown model id"), ((fb.K["FB_MODEL_C172S0"], 7, fb.K["FB_F64"], 8, 0), b"unknown kinematics id"),
+                      ((fb.K["FB_MODEL_C172X2"], 3, fb.K["FB_F64"], 8, 0), b"unknown kinematics id"),
                       ((fb.K["FB_MODEL_C172S0"], 0, 5, 8, 0), b"unknown dtype"), ((fb.K["FB_MODEL_C172S0"], 0, fb.K["FB_F64"], 0, 0), b"n must be positive"),
                       ((fb.K["FB_MODEL_C172X2"], 0, fb.K["FB_F32"], 8, 0), b"only FB_F64"),
                       ((fb.K["FB_MODEL_C172S0"], fb.K["FB_KIN_NED"], fb.K["FB_F32"], 8, 0), b"only FB_KIN_WA")):
