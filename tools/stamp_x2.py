@@ -24,3 +24,13 @@ names = {21: "end of evaluation -> entry of x2_periodic (bookkeeping, arguments,
          28: "lon: outer loops (3 PID lookups + runs, integrator, cos / tan)", 29: "lon: LQR gain lookup", 24: "lon: LQR run, stores", 25: "lat", 26: "return, reload commands"}
 for k in (21, 22, 23, 27, 28, 29, 24, 25, 26):
     if cnt[k]: print("%2d %-78s %9.1f cycles (x %d)" % (k, names[k], acc[k] / cnt[k], cnt[k]))
+# the evaluations of the stepping loop between the updates, phase by phase (same fences as tools/stamp_profile.py)
+rhs_names = {0: "loop tail + emit setup (20 -> 0)", 11: "kinematics head", 1: "kinematics rest + emits", 2: "air data", 12: "aero: angles, filters, knots",
+             3: "aero: lookups, coefficients, wrench", 4: "gear unit (x3)", 5: "gear tail", 9: "propeller", 10: "engine head", 6: "engine chain",
+             7: "fuel", 8: "mass properties", 20: "dynamics + emits"}
+order = [0, 11, 1, 2, 12, 3, 4, 5, 9, 10, 6, 7, 8, 20]
+evals = max(cnt[11], 1)
+tot = sum(acc[k] for k in order)
+for k in order:
+    print("%3d %-50s %9.1f cycles/eval %5.1f %%" % (k, rhs_names[k], acc[k] / evals, 100.0 * acc[k] / max(tot, 1)))
+print("total %.1f cycles per evaluation over %d evaluations (the interval 20 -> 0 contains the bookkeeping between evaluations: actuators, f_step!, the update's call)" % (tot / evals, evals))
