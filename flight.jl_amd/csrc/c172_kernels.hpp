@@ -20,53 +20,133 @@
 
 namespace fbd {
 
-// ---- ground contact, out of line (landinggear.jl:260-328, 426-476) ---------------------------
+// ---- ground contact (landinggear.jl:260-328, 426-476) -----------------------------------------
+// Two forms of each function. !FAST follows the reference operation by operation with the library's acos / atan2 / sincos (f_ode!, the
+// output record). FAST is what the stepping kernels run — a batch on the ground spends half of every evaluation here (three units x
+// ~1 080 instructions before, profiles/r03_ground_*): the same quantities with
+//   * what the three units share (q_en, strut axis and terrain normal in ECEF axes, the tilt criterion) formed once (ground_common);
+//   * rotations of a coordinate axis and products with a z-rotation written out for their structural zeros (the generic forms multiply
+//     by literal 0 and 1, which the compiler may not fold without fast-math flags); same operations on the non-zero terms, so the values
+//     are the reference's (a state quaternion off unit norm keeps its (1 - s^2) v + s^2 R v behaviour, DESIGN.md "Faithfulness rule");
+//   * the wheel frame's quaternion from its z-rotation matrix in closed form (RQuat(RMatrix) has two live cases for such a matrix);
+//   * a castoring nose wheel's cos / sin of HALF the velocity azimuth by half_angle_cs (no atan2 + sincos), a steered one's by a short
+//     series (|psi| <= pi / 12);
+//   * the skid azimuth by the stepping kernels' table atan2; reciprocal square roots where the reference divides by a square root;
+//   * F_b = N (q_sc f_c) from the rotation already made for N, instead of rotating N f_c again.
+template <bool FAST>
+__device__ FB_GROUND_ATTR void ground_common(quat q_eb, quat q_nb, GroundCommon& c) {
+    c.q_en = qmul(q_eb, qconj(q_nb));
+    if constexpr (FAST) {
+        // qrot(q, (0,0,1)) = (2 (q_y q_w + q_z q_x), 2 (q_z q_y - q_x q_w), 1 - 2 (q_x^2 + q_y^2)), term by term as the generic form makes them
+        auto rot_z = [](quat q) { return v3{(2 * q.y) * q.w - (2 * q.z) * (-q.x), (2 * q.z) * q.y - (2 * q.x) * q.w, 1 + ((2 * q.x) * (-q.x) - (2 * q.y) * q.y)}; };
+        c.ks_e = rot_z(q_eb);
+        c.ut_e = rot_z(c.q_en);
+    } else {
+        c.ks_e = qrot(q_eb, v3{0, 0, 1});
+        c.ut_e = qrot(c.q_en, v3{0, 0, 1});
+    }
+    c.ut_ks = dot(c.ut_e, c.ks_e);
+    if constexpr (FAST) {
+        const bool lo = c.ut_ks < 0.5 - 1e-7, hi = c.ut_ks > 0.5 + 1e-7;
+        c.tilt_crash = lo;
+        if (__builtin_amdgcn_ballot_w64(!lo && !hi) != 0) {
+            const double a = acos(fmax(fmin(c.ut_ks, 1.0), -1.0));
+            if (!lo && !hi) c.tilt_crash = a * (180 / PI) > 60;
+        }
+        c.alpha_ts = 0;
+    } else {
+        c.alpha_ts = acos(fmax(fmin(c.ut_ks, 1.0), -1.0));
+        c.tilt_crash = c.alpha_ts * (180 / PI) > 60;
+    }
+}
+template <bool FAST>
 __device__ FB_GROUND_ATTR void gear_ground_kinematics(const GroundIn& in, GroundOut& o) {
     using namespace c172;
     const int g = in.g;
     const v3 r_bs_b = {ldg_r[g][0], ldg_r[g][1], ldg_r[g][2]};
     // terrain point under the wheel, ECEF (geodesy.jl:418-428)
-    const double f_den = sqrt(1 - wgs::e2 * in.loc_Ot.z * in.loc_Ot.z);
-    const double RE = wgs::a / f_den;
+    // (kept as the reference's a / sqrt(...) in both forms: the strut's compression is the difference of two ECEF positions 6.4e6 m from
+    // the origin, and a second ulp on this radius is a nanometre of compression in front of 4e4 N/m)
+    const double RE = wgs::a / sqrt(1 - wgs::e2 * in.loc_Ot.z * in.loc_Ot.z);
     const v3 r_et_e = {(RE + in.he_Ot) * in.loc_Ot.x, (RE + in.he_Ot) * in.loc_Ot.y, (RE * (1 - wgs::e2) + in.he_Ot) * in.loc_Ot.z};
     const v3 r_es_e = in.r_eb_e + in.r_bs_e;
     const v3 r_st_e = r_et_e - r_es_e;
-    const v3 ut_e = qrot(in.q_en, v3{0, 0, 1});
-    const double ut_ks = dot(ut_e, in.ks_e);
-    const double l = dot(ut_e, r_st_e) / ut_ks;
-    o.alpha_ts = acos(fmax(fmin(ut_ks, 1.0), -1.0));
+    const double l = dot(in.ut_e, r_st_e) / in.ut_ks;
     o.xi = fmin(0.0, l);
     const v3 r_bc_b = v3{0, 0, o.xi} + r_bs_b;
     const v3 v_body = in.v_eb_b + cross(in.w_eb_b, r_bc_b);
-    const double psi_v = atan2(v_body.y, v_body.x);
-    double psi_sw = 0.0;
-    if (g == 2) psi_sw = in.steer_engaged ? in.steer_in * psi_max : psi_v;
-    double s, c;
-    sincos(0.5 * psi_sw, &s, &c);
-    const quat q_nw = qmul(in.q_nb, quat{c, 0, 0, s});
-    const v3 iw_n = qrot(q_nw, v3{1, 0, 0});
-    const v3 kc = {0, 0, 1};
-    const v3 iw_t = iw_n - dot(iw_n, kc) * kc;
-    const v3 ic = (1 / norm(iw_t)) * iw_t;
-    const v3 jc = cross(kc, ic);
-    // RQuat(RMatrix([ic jc kc])) (attitude.jl:192-233)
-    const double R[3][3] = {{ic.x, jc.x, kc.x}, {ic.y, jc.y, kc.y}, {ic.z, jc.z, kc.z}};
-    const double tr = R[0][0] + R[1][1] + R[2][2];
-    int imax = 0;
-    double best = tr;
-    if (R[0][0] > best) { best = R[0][0]; imax = 1; }
-    if (R[1][1] > best) { best = R[1][1]; imax = 2; }
-    if (R[2][2] > best) { best = R[2][2]; imax = 3; }
-    quat v;
-    if (imax == 0) v = {1 + tr, R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};
-    else if (imax == 1) v = {R[2][1] - R[1][2], 1 + 2 * R[0][0] - tr, R[0][1] + R[1][0], R[2][0] + R[0][2]};
-    else if (imax == 2) v = {R[0][2] - R[2][0], R[0][1] + R[1][0], 1 + 2 * R[1][1] - tr, R[1][2] + R[2][1]};
-    else v = {R[1][0] - R[0][1], R[2][0] + R[0][2], R[1][2] + R[2][1], 1 + 2 * R[2][2] - tr};
-    const double inv = 1 / sqrt(v.w * v.w + v.x * v.x + v.y * v.y + v.z * v.z);
-    const quat q_nc = {v.w * inv, v.x * inv, v.y * inv, v.z * inv};
-    const quat q_sc = qmul(qconj(in.q_nb), q_nc);  // q_ns = q_nb (q_bs = 1)
+    quat q_sc;
+    if constexpr (FAST) {
+        // q_nw = q_nb o Rz(psi_sw): main wheels psi_sw = 0; nose wheel steered (psi = steer psi_max) or castoring (psi = azimuth of v)
+        quat q_nw = in.q_nb;
+        if (g == 2) {
+            double c, s;
+            if (in.steer_engaged) {
+                const double h = 0.5 * (in.steer_in * psi_max), z = h * h;   // |h| <= pi / 12: sin to h^13, cos to h^14 (< 1e-18)
+                double ps = -1.0 / 6227020800.0, pc = -1.0 / 87178291200.0;
+                ps = __builtin_fma(z, ps, 1.0 / 39916800.0); ps = __builtin_fma(z, ps, -1.0 / 362880.0); ps = __builtin_fma(z, ps, 1.0 / 5040.0);
+                ps = __builtin_fma(z, ps, -1.0 / 120.0); ps = __builtin_fma(z, ps, 1.0 / 6.0);
+                pc = __builtin_fma(z, pc, 1.0 / 479001600.0); pc = __builtin_fma(z, pc, -1.0 / 3628800.0); pc = __builtin_fma(z, pc, 1.0 / 40320.0);
+                pc = __builtin_fma(z, pc, -1.0 / 720.0); pc = __builtin_fma(z, pc, 1.0 / 24.0); pc = __builtin_fma(z, pc, -0.5);
+                s = __builtin_fma(-(h * z), ps, h);
+                c = __builtin_fma(z, pc, 1.0);
+            } else {
+                half_angle_cs(v_body.y, v_body.x, c, s);
+            }
+            const quat a = in.q_nb;   // qmul(a, {c, 0, 0, s}) without its zero terms
+            q_nw = {a.w * c - a.z * s, c * a.x + a.y * s, c * a.y - a.x * s, a.w * s + c * a.z};
+        }
+        // iw_n = qrot(q_nw, (1,0,0)), of which the horizontal part is kept: ic = (x, y, 0) / |(x, y)|, jc = kc x ic, kc = (0,0,1)
+        const double iwx = 1 + ((2 * q_nw.y) * (-q_nw.y) - (2 * q_nw.z) * q_nw.z);
+        const double iwy = (2 * q_nw.z) * q_nw.w - (2 * q_nw.x) * (-q_nw.y);
+        const double in_ = rsqrt(iwx * iwx + iwy * iwy);
+        const double icx = in_ * iwx, icy = in_ * iwy;
+        // RQuat(RMatrix([ic jc kc])) (attitude.jl:192-233) for R = Rz: trace 1 + 2 ic.x; the largest-diagonal search ends on the trace
+        // unless 1 > trace (then on R33 = 1)
+        const double tr = (icx + icx) + 1;
+        const bool on_trace = !(1 > tr);
+        const double vw = on_trace ? 1 + tr : icy + icy, vz = on_trace ? icy + icy : 1 + 2 * 1.0 - tr;
+        const double inv = rsqrt(vw * vw + vz * vz);
+        const double cw = vw * inv, sz = vz * inv;   // q_nc = (cw, 0, 0, sz)
+        const quat a = qconj(in.q_nb);               // q_sc = q_bn o q_nc (q_ns = q_nb: q_bs = 1)
+        q_sc = {a.w * cw - a.z * sz, cw * a.x + a.y * sz, cw * a.y - a.x * sz, a.w * sz + cw * a.z};
+    } else {
+        const double psi_v = atan2(v_body.y, v_body.x);
+        double psi_sw = 0.0;
+        if (g == 2) psi_sw = in.steer_engaged ? in.steer_in * psi_max : psi_v;
+        double s, c;
+        sincos(0.5 * psi_sw, &s, &c);
+        const quat q_nw = qmul(in.q_nb, quat{c, 0, 0, s});
+        const v3 iw_n = qrot(q_nw, v3{1, 0, 0});
+        const v3 kc = {0, 0, 1};
+        const v3 iw_t = iw_n - dot(iw_n, kc) * kc;
+        const v3 ic = (1 / norm(iw_t)) * iw_t;
+        const v3 jc = cross(kc, ic);
+        // RQuat(RMatrix([ic jc kc])) (attitude.jl:192-233)
+        const double R[3][3] = {{ic.x, jc.x, kc.x}, {ic.y, jc.y, kc.y}, {ic.z, jc.z, kc.z}};
+        const double tr = R[0][0] + R[1][1] + R[2][2];
+        int imax = 0;
+        double best = tr;
+        if (R[0][0] > best) { best = R[0][0]; imax = 1; }
+        if (R[1][1] > best) { best = R[1][1]; imax = 2; }
+        if (R[2][2] > best) { best = R[2][2]; imax = 3; }
+        quat v;
+        if (imax == 0) v = {1 + tr, R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};
+        else if (imax == 1) v = {R[2][1] - R[1][2], 1 + 2 * R[0][0] - tr, R[0][1] + R[1][0], R[2][0] + R[0][2]};
+        else if (imax == 2) v = {R[0][2] - R[2][0], R[0][1] + R[1][0], 1 + 2 * R[1][1] - tr, R[1][2] + R[2][1]};
+        else v = {R[1][0] - R[0][1], R[2][0] + R[0][2], R[1][2] + R[2][1], 1 + 2 * R[2][2] - tr};
+        const double inv = 1 / sqrt(v.w * v.w + v.x * v.x + v.y * v.y + v.z * v.z);
+        const quat q_nc = {v.w * inv, v.x * inv, v.y * inv, v.z * inv};
+        q_sc = qmul(qconj(in.q_nb), q_nc);  // q_ns = q_nb (q_bs = 1)
+    }
     const v3 v_c_body = qrot_inv(q_sc, v_body);
-    const v3 ks_c = qrot_inv(q_sc, v3{0, 0, 1});
+    v3 ks_c;
+    if constexpr (FAST) {
+        const quat p = qconj(q_sc);   // qrot(p, (0,0,1)), as in ground_common
+        ks_c = {(2 * p.y) * p.w - (2 * p.z) * (-p.x), (2 * p.z) * p.y - (2 * p.x) * p.w, 1 + ((2 * p.x) * (-p.x) - (2 * p.y) * p.y)};
+    } else {
+        ks_c = qrot_inv(q_sc, v3{0, 0, 1});
+    }
     o.xi_dot = -v_c_body.z / ks_c.z;
     const double kd = ldg_kd[g];  // k_d_ext == k_d_cmp for both C172 dampers (c172.jl:444-451)
     o.F_dmp = -(ldg_ks[g] * o.xi + kd * o.xi_dot);
@@ -78,6 +158,7 @@ __device__ FB_GROUND_ATTR void gear_ground_kinematics(const GroundIn& in, Ground
     o.r_bc_b = r_bc_b;
 }
 
+template <bool FAST>
 __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& o) {
     const double nv = sqrt(o.v_xy0 * o.v_xy0 + o.v_xy1 * o.v_xy1);
     auto mu = [&](double mu_s, double mu_d) {
@@ -88,23 +169,29 @@ __device__ FB_GROUND_ATTR void gear_ground_force(const GroundIn& in, GroundOut& 
     const double mu_skid = in.surface == 0 ? mu(0.75, 0.25) : (in.surface == 1 ? mu(0.25, 0.15) : mu(0.075, 0.025));
     const double k_br = in.brake_in;  // η_br = 1 (landinggear.jl:106-108); nose gear has NoBraking -> 0
     const double mu_x = mu_roll + (mu_skid - mu_roll) * k_br;
-    const double psi_cv = (nv < 1e-3) ? PI / 2 : atan2(o.v_xy1, o.v_xy0);
-    const double psi_skid = 10 * (PI / 180), psi_abs = fabs(psi_cv);
+    double psi_abs;   // |atan2(v_y, v_x)|
+    if constexpr (FAST) psi_abs = (nv < 1e-3) ? PI / 2 : atan2_tab(fabs(o.v_xy1), o.v_xy0, in.atan_tab);
+    else psi_abs = fabs((nv < 1e-3) ? PI / 2 : atan2(o.v_xy1, o.v_xy0));
+    const double psi_skid = 10 * (PI / 180);
     double mu_y;
     if (psi_abs < psi_skid) mu_y = mu_skid * psi_abs / psi_skid;
     else if (psi_abs > PI - psi_skid) mu_y = mu_skid * (1 - (psi_skid + psi_abs - PI) / psi_skid);
     else mu_y = mu_skid;
-    const double sc = fmin(1.0, mu_skid / sqrt(mu_x * mu_x + mu_y * mu_y));
+    double sc;
+    if constexpr (FAST) sc = fmin(1.0, mu_skid * rsqrt(mu_x * mu_x + mu_y * mu_y));
+    else sc = fmin(1.0, mu_skid / sqrt(mu_x * mu_x + mu_y * mu_y));
     const v3 f_c = {in.frc_out0 * (mu_x * sc), in.frc_out1 * (mu_y * sc), -1.0};
     const v3 f_s = qrot(o.q_sc, f_c);
     const double N = fmax(0.0, -o.F_dmp / f_s.z);
-    const v3 F_b = qrot(o.q_sc, N * f_c);  // q_bc = q_sc
+    v3 F_b;
+    if constexpr (FAST) F_b = N * f_s;      // = q_sc(N f_c): the rotation is linear (q_bc = q_sc)
+    else F_b = qrot(o.q_sc, N * f_c);
     o.F_b = F_b;
     o.tau_b = cross(o.r_bc_b, F_b);
 }
 
-__device__ __noinline__ void gear_ground_kinematics_call(const GroundIn& in, GroundOut& o) { gear_ground_kinematics(in, o); }
-__device__ __noinline__ void gear_ground_force_call(const GroundIn& in, GroundOut& o) { gear_ground_force(in, o); }
+template <bool FAST> __device__ __noinline__ void gear_ground_kinematics_call(const GroundIn& in, GroundOut& o) { gear_ground_kinematics<FAST>(in, o); }
+template <bool FAST> __device__ __noinline__ void gear_ground_force_call(const GroundIn& in, GroundOut& o) { gear_ground_force<FAST>(in, o); }
 
 // ---- kernel arguments -----------------------------------------------------------------------
 struct KArgs {
