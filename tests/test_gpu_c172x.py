@@ -174,6 +174,7 @@ def test_checkpoint_restore_resumes_bitwise(fb, gains):
         w.ctl.lat.mode_req = float(fb.ModeControlLat.χ_β); w.ctl.lat.χ_ref = 0.3
 
     exercise(lambda: fb.Cessna172Xv2World(n, gains=gains), prep_x2, 0.37, 1.0, dt=0.01, Δt=0.02, steps_per_launch=50)
+    exercise(lambda: fb.Cessna172Xv2World(n, gains=gains, kinematics="NED"), prep_x2, 0.37, 1.0, dt=0.01, Δt=0.02, steps_per_launch=50)   # 31 rows
     exercise(lambda: fb.BatchedWorld(n), lambda w, sim: fb.init(sim, tp), 0.37, 1.0, dt=0.01, steps_per_launch=50)
 
     def prep_r2(w, sim):
@@ -432,3 +433,35 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
     cerr = np.abs(a["cs"] - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)
     assert cerr[:, term | flying].max() < 1e-6 and np.quantile(cerr[:, rolling].max(0), 0.99) < 1e-5 and cerr.max() < 5e-2
     assert np.array_equal(a["s"], o["s"])
+
+
+@pytest.mark.parametrize("kin", ["ECEF", "NED"])
+def test_x2_mechanisations_device_log(fb, gains, kin):
+    """The on-device TimeSeries log of Cessna172Xv2(ECEF()) / (NED()): 33 / 31 state rows in the reference's order, equal to what the
+    same run gives when it is stopped by hand at the same instants (cb_save, FC/sim.jl:210-217)."""
+    n = 512
+    nx = {"ECEF": 33, "NED": 31}[kin]
+    tp = lattice_trim_params(fb, n, seed=6)
+    rows = [fb.K["FB_Y_KIN"] + 1, fb.K["FB_Y_AIR"] + 20]
+    runs = []
+    for by_hand in (False, True):
+        w = fb.Cessna172Xv2World(n, gains=gains, kinematics=kin)
+        sim = fb.Simulation(w, dt=0.01, Δt=0.02, t_end=2.0, saveat=0.5, save_rows=rows, save_on=not by_hand, steps_per_launch=40)
+        fb.init(sim, tp)
+        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 1.5
+        w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = 0.2
+        if not by_hand:
+            fb.run(sim)
+            ts = fb.TimeSeries(sim)
+            assert len(ts) == 5 and ts.x.shape == (5, nx, n) and ts.y.shape == (5, 2, n) and np.array_equal(ts.x[-1], w.x)
+            runs.append(ts)
+        else:
+            ts = runs[0]
+            for k in range(5):
+                if k:
+                    fb.step(sim, 0.5)
+                fb.f_ode(w)
+                assert np.array_equal(ts.x[k], w.x), k
+                assert np.array_equal(ts.y[k], w.y[rows]), k
+        assert (w.status == 0).all()
+        w.close()
