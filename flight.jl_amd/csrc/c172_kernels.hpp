@@ -1,9 +1,10 @@
 // c172_kernels.hpp — HIP kernels for gfx950: f_ode, fused RK4 stepper, f_step, trim.
 //
-// Mapping: one lane = one aircraft; 256-lane workgroups; state is structure-of-arrays in HBM
-// (x[k*N + i]) so every load/store is one coalesced 512-B request per wave. The three small tables are
-// copied into LDS once per workgroup. The stepper keeps the state in registers for `nsteps` RK4 steps
-// per launch, so HBM traffic per aircraft-step is (27 x 8 B read + 27 x 8 B write + flags)/nsteps.
+// Mapping: one lane = one aircraft; state is structure-of-arrays in HBM (x[k*N + i]) so every load / store is one coalesced
+// 512-B request per wave. The three small tables are copied into LDS once per workgroup. The stepping kernels keep an aircraft's
+// state on chip (LDS panels, see "the stepping kernel" below) for the `nsteps` RK4 steps of a launch, so HBM traffic per
+// aircraft-step is (27 x 8 B read + 27 x 8 B write + flags) / nsteps. Cessna172Sv0 / WA / fp64 is stepped by the wave-specialised
+// k_step_duo (512-thread workgroups: two waves per aircraft group, c172_duo_device.hpp), everything else by k_step_air.
 //
 // Stepper semantics (lib/FlightCore/src/sim.jl:204-218,301-328 + OrdinaryDiffEq RK4):
 //   k1 = f(x_n) ; k2 = f(x_n + dt/2 k1) ; k3 = f(x_n + dt/2 k2) ; k4 = f(x_n + dt k3)
