@@ -715,3 +715,70 @@ def test_gravity_at_com_with_off_norm_states(fb, oracle, eps, tol):
     print("eps %.0e: |g_c - oracle| <= %.2e m/s^2, |vdot - oracle| <= %.2e" % (eps, eg, ev))
     assert eg < tol and ev < 5 * tol
     w.close()
+
+
+def test_ground_roll_with_steering_and_brakes_matches_oracle(fb, oracle):
+    """One second of ground roll through the STEPPING kernels' contact branch (the FAST forms of gear_ground_kinematics / gear_ground_force,
+    c172_kernels.hpp) in every variant it has: nose wheel steered (rudder + offset, a series for cos / sin of half the steering angle) on
+    two thirds of the aircraft and castoring (half-angle of the velocity azimuth) on the rest, differential braking, taxi speeds from 1
+    to 15 m/s with sideslip, engine at idle and running — against the oracle, which follows the reference operation by operation."""
+    n = 1536
+    rng = np.random.default_rng(19)
+    x = np.zeros((27, n))
+    x[8] = 0.5
+    th = rng.uniform(-0.01, 0.03, n); ph = rng.uniform(-0.01, 0.01, n); ps = rng.uniform(-np.pi, np.pi, n)
+
+    def qmul(a, b):
+        return np.stack([a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
+                         a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0]])
+    z = np.zeros(n)
+    x[12:16] = qmul(qmul(np.stack([np.cos(ps/2), z, z, np.sin(ps/2)]), np.stack([np.cos(th/2), z, np.sin(th/2), z])), np.stack([np.cos(ph/2), np.sin(ph/2), z, z]))
+    lat, lon = -0.4, 2.1
+    a = -(lat + np.pi / 2)
+    x[16:20] = qmul(np.array([np.cos(lon/2), 0, 0, np.sin(lon/2)])[:, None] * np.ones(n), np.array([np.cos(a/2), 0, np.sin(a/2), 0])[:, None] * np.ones(n))
+    n_e = np.array([np.cos(lat)*np.cos(lon), np.cos(lat)*np.sin(lon), np.sin(lat)])
+    import ctypes
+    geoid = oracle.lib.fo_geoid_height(np.ascontiguousarray(n_e).ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    x[20] = geoid + rng.uniform(1.80, 1.88, n)           # on its wheels, struts a little compressed
+    x[24] = rng.uniform(1.0, 15, n)      # rolling (at a crawl the friction regulators' stick-slip amplifies rounding by 1e15 in 40 steps — in
+                                         # the oracle against itself as well: a property of RK4 at dt k_i = 4, nothing a parity test can hold)
+    x[25] = rng.normal(0, 0.2, n)
+    x[9] = np.where(np.arange(n) % 2 == 0, 70.0, 230.0)
+    s = np.zeros((2, n), np.int32); s[1] = 2
+    u = np.zeros((16, n)); u[11:16] = np.array([75, 75, 0, 0, 50.0])[:, None]
+    u[0] = np.where(np.arange(n) % 2 == 0, 0.0, 0.4); u[1] = 0.5
+    K = fb.K
+    u[K["FB_U_RUDDER"]] = rng.uniform(-1, 1, n); u[K["FB_U_RUDDER_OFFSET"]] = rng.uniform(-0.3, 0.3, n)     # the steering input
+    u[K["FB_U_BRAKE_LEFT"]] = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(0, 1, n))
+    u[K["FB_U_BRAKE_RIGHT"]] = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(0, 1, n))
+    ui = np.full(n, K["FB_UI_MIXTURE_AUTO"] | K["FB_UI_STEERING_ENGAGED"], np.int32)
+    ui[::3] = K["FB_UI_MIXTURE_AUTO"]                     # castoring
+    w = fb.BatchedWorld(n)
+    w.set_state(x, s); w.u = u; w.ui = ui
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=25)
+    # one step: no time for the contact dynamics to amplify anything — what differs here is the arithmetic of one evaluation chain
+    # (strut compression is a difference of ECEF positions: 1e-9 m of rounding in front of 4e4 N/m, 2e-7 m/s^2 on a 1000 kg aircraft)
+    fb.step(sim, 0.01); w.sync()
+    x1, s1, st1 = oracle.step(x, u, ui, s, oracle.default_env(), 0.01, 1)
+    e1 = np.abs(w.x - x1) / np.maximum(np.abs(x1), 1.0)
+    print("ground roll, 1 step: max error %.2e (per unit of state, or relative above 1)" % e1.max())
+    assert e1.max() < 2e-8 and np.array_equal(w.status, st1) and np.array_equal(w.s, s1)
+    fb.step(sim, 0.99); w.sync()
+    xo, so, sto = oracle.step(x, u, ui, s, oracle.default_env(), 0.01, 100)
+    assert np.array_equal(w.status, sto) and np.array_equal(w.s, so)
+    live = sto == 0
+    assert live.mean() > 0.95
+    _, yo, _ = oracle.f_ode(xo, u, ui, so, oracle.default_env())
+    wow = (yo[K["FB_Y_LDG"] + 1] + yo[K["FB_Y_LDG"] + 12] + yo[K["FB_Y_LDG"] + 23])
+    assert (wow[live] == 3).mean() > 0.9, "the batch must stay on its wheels"
+    err = (np.abs(w.x - xo) / state_scale(xo))[:, live]
+    per = err.max(0)
+    steered = (ui[live] & K["FB_UI_STEERING_ENGAGED"]) != 0
+    q = np.quantile(per, [0.5, 0.99, 1.0])
+    print("ground roll, 100 steps: per-aircraft max scaled error, quantiles 50 / 99 / 100 %%: %.2e %.2e %.2e (steered %.2e, castoring %.2e)" % (
+        q[0], q[1], q[2], per[steered].max(), per[~steered].max()))
+    # 100 steps of braking, skidding and bouncing (the batch is dropped onto struts compressed by up to 8 cm) amplify that: the median stays
+    # at the one-step level, a steered and braked aircraft in a skid reaches 1e-4. The stepping kernels' own forms of the contact branch and
+    # the reference's operations in their place (-DFB_GROUND_REFERENCE_FORMS) give these same three numbers to three digits.
+    assert q[0] < 1e-6 and q[1] < 1e-5 and q[2] < 1e-3
+    w.close()

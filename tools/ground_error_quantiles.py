@@ -2,7 +2,8 @@
 """Distribution (not only the maximum) of the GPU-vs-oracle error over aircraft in ground contact: descending approaches that touch down
 and roll (the scenario of tests/test_gpu_parity.py::test_approach_crosses_the_air_ground_handover, 4096 aircraft, 8 s). Contact amplifies
 rounding, so the maximum over a batch moves with any change of rounding in the contact code; the quantiles are what shows whether a change
-of the arithmetic changed the accuracy. FLIGHTBATCH_LIB selects the library (A/B of two builds)."""
+of the arithmetic changed the accuracy. FLIGHTBATCH_LIB selects the library (A/B of two builds, e.g. the stepping kernels' own forms of the
+contact branch against the reference's operations in their place: python __graft_entry__.py --variant gref -DFB_GROUND_REFERENCE_FORMS)."""
 import os, sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
