@@ -320,7 +320,7 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
 struct GeoPt { double lat, lon, h; };
 FBD v3 nvec_of(const GeoPt& p) {
     double sla, cla, slo, clo;
-    sincos(p.lat, &sla, &cla); sincos(p.lon, &slo, &clo);
+    sincos_step(p.lat, sla, cla); sincos_step(p.lon, slo, clo);
     return {cla * clo, cla * slo, sla};
 }
 FBD v3 ecef_of(const GeoPt& p) {   // Cartesian(Geographic{LatLon, Ellipsoidal}), geodesy.jl:418-428
