@@ -1,10 +1,11 @@
-// c172_duo_device.hpp — the right-hand side of the airborne Cessna172Sv0 / WA evaluation, cut in two for k_step_duo
+// c172_duo_device.hpp — the right-hand side of the airborne Cessna172Sv0 evaluation (rhs_duo<KIN, ROLE>: WA, ECEF or NED kinematics),
+// cut in two for k_step_duo<KIN>
 // (c172_kernels.hpp): two waves serve the same 64 aircraft, each evaluating its share, so that two waves fit a SIMD's registers.
 // Same arithmetic, block by block, as rhs() in c172_device_impl.inc (which stays the reference form: every other kernel uses it,
 // and tools/duo_check.py + the parity tests compare the two); only the order of the blocks and who evaluates them differ:
 //
 //   role P  "atmosphere + power plant"                     role D  "airframe"
-//   reads its state rows (q_ew, h_e, engine, fuel)         attitude, n_e, wind-relative velocity -> put the velocity at the propeller
+//   reads its state rows (position, engine, fuel)          attitude, n_e, wind-relative velocity -> put the velocity at the propeller
 //   ---- publishes R                                        ---- publishes V
 //   geoid height (lat / lon, EGM96) -> h_o                 airflow angles, filter rows,
 //   ISA atmosphere -> T, p, log p                          table locations and lookups on the alpha / beta axes
@@ -17,9 +18,10 @@
 //   ---- waits for X                                        ---- publishes X
 //   engine-speed row, fuel row                              the rest of the dynamics (6 rows); the step's bookkeeping; ---- publishes T
 //
-// Only n_e (ten instructions) is evaluated twice. The two waves of a pair keep in step through two counters in LDS — no barrier
+// Only n_e is evaluated twice (WA: ten instructions from q_ew; ECEF: it is a state; NED: the sines and cosines of latitude and
+// longitude). The position rows role P reads are q_ew, h_e (WA), n_e, h_e (ECEF), latitude, longitude, h_e (NED). The two waves of a pair keep in step through two counters in LDS — no barrier
 // (k_step_duo, c172_kernels.hpp) — and every wait sits where a value is needed. Who may touch which LDS row when:
-//   * role P reads the state rows it needs — of role D's: q_ew and h_e — at the head of its evaluation, ahead of its point R; role D
+//   * role P reads the state rows it needs — of role D's: the position rows — at the head of its evaluation, ahead of its point R; role D
 //     rewrites the kinematics rows behind R. Role D reads nothing of role P's rows but the fuel row, behind R too (role P emits it last
 //     of all, behind role D's point X, so "R reached" means the previous evaluation's fuel row is there and this one's is not);
 //   * role D rewrites the filter rows at its head, the kinematics rows behind R, the angular / linear velocity rows behind X; role P its
@@ -60,10 +62,11 @@ enum { DUO_PT_T = 0, DUO_PT_V = 1, DUO_PT_X = 2,    // role D: top of the loop; 
 constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
 constexpr int XD_VP = XD_FP;   // role D -> role P before barrier A: the velocity at the propeller, in the rows that carry F_p after it
 
-template <int ROLE, class In, class Emit, class XV>
+template <int KIN, int ROLE, class In, class Emit, class XV>
 __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state, const In& in, const Env& env, const Tables& T, const Emit& emit, StepAux& aux) {
     using namespace c172;
     static_assert(ROLE == 1 || ROLE == 2, "role P or role D");
+    static_assert(KIN == FB_KIN_WA || KIN == FB_KIN_ECEF || KIN == FB_KIN_NED, "kinematic mechanisation");
     int32_t st = 0;
     constexpr int KX = FB_X_Q_WB;
     auto gkp = [&](int off) -> gk_cptr { return T.gk + off; };
@@ -72,12 +75,29 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
 
     // ===== kinematics head (kinematics.jl:181-223; geodesy.jl:62-69, 140-147). Role P needs the position only (n_e from q_ew, h_e); the
     // attitude products, the wind-relative velocity and from it the velocity at the propeller are role D's, which hands the latter over =====
-    const double h_e = x[KX + 8];
+    // (ECEF, kinematics.jl:282-320: n_e and h_e are states; NED, :366-407: latitude, longitude and h_e are, and n_e comes from their sines
+    // and cosines — both roles form it, role P for the geoid, role D for the radii of curvature and gravity. The rows role P reads of the
+    // kinematic block — WA q_ew, h_e; ECEF n_e, h_e; NED lat, lon, h_e — it reads ahead of its point R, like the WA ones.)
+    const double h_e = x[KIN == FB_KIN_WA ? KX + 8 : (KIN == FB_KIN_ECEF ? KX + 7 : KX + 5)];
     if (!(h_e >= H_MIN)) st |= FB_ST_ALT_RANGE;
-    const quat q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
-    const double dq12 = 2 * q_ew.w * q_ew.x, dq13 = 2 * q_ew.w * q_ew.y;
-    const double dq24 = 2 * q_ew.x * q_ew.z, dq34 = 2 * q_ew.y * q_ew.z;
-    const v3 n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+    [[maybe_unused]] quat q_ew = {1, 0, 0, 0};
+    [[maybe_unused]] double dq12 = 0, dq13 = 0, dq24 = 0, dq34 = 0;
+    [[maybe_unused]] double ned_cla = 1, pos0 = 0, pos1 = 0, pos2 = 0;   // (pos: the position rows as read, for role P's pin)
+    v3 n_e;
+    if constexpr (KIN == FB_KIN_WA) {
+        q_ew = {x[KX + 4], x[KX + 5], x[KX + 6], x[KX + 7]};
+        dq12 = 2 * q_ew.w * q_ew.x; dq13 = 2 * q_ew.w * q_ew.y;
+        dq24 = 2 * q_ew.x * q_ew.z; dq34 = 2 * q_ew.y * q_ew.z;
+        n_e = {-(dq24 + dq13), -(dq34 - dq12), -(1 - 2 * (q_ew.x * q_ew.x + q_ew.y * q_ew.y))};
+    } else if constexpr (KIN == FB_KIN_ECEF) {
+        pos0 = x[KX + 4]; pos1 = x[KX + 5]; pos2 = x[KX + 6];
+        n_e = {pos0, pos1, pos2};   // state n-vector, normalised only in f_step! (kinematics.jl:286, 317-320)
+    } else {
+        pos0 = x[KX + 3]; pos1 = x[KX + 4];
+        double sla, slo, clo;
+        sincos_step(pos0, sla, ned_cla); sincos_step(pos1, slo, clo);
+        n_e = {ned_cla * clo, ned_cla * slo, sla};   // geodesy.jl:97-101
+    }
     const v3 r_p = {prop_r[0], prop_r[1], prop_r[2]};
 
     if constexpr (ROLE == 1) {
@@ -87,8 +107,15 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double w_eng = x[FB_X_ENG_OMEGA];
         const double x_frc = x[FB_X_ENG_FRC], x_idle = x[FB_X_ENG_IDLE], x_fuel = x[FB_X_FUEL];
         {   // every state row this role reads is read HERE (pinned: the compiler may not sink a read towards its use, past the point)
-            double pin_w = w_eng, pin_f = x_frc, pin_i = x_idle, pin_u = x_fuel, pin_h = h_e, pin_q0 = q_ew.w, pin_q1 = q_ew.x, pin_q2 = q_ew.y, pin_q3 = q_ew.z;
-            asm volatile("" : "+v"(pin_w), "+v"(pin_f), "+v"(pin_i), "+v"(pin_u), "+v"(pin_h), "+v"(pin_q0), "+v"(pin_q1), "+v"(pin_q2), "+v"(pin_q3));
+            double pin_w = w_eng, pin_f = x_frc, pin_i = x_idle, pin_u = x_fuel, pin_h = h_e;
+            asm volatile("" : "+v"(pin_w), "+v"(pin_f), "+v"(pin_i), "+v"(pin_u), "+v"(pin_h));
+            if constexpr (KIN == FB_KIN_WA) {
+                double pin_q0 = q_ew.w, pin_q1 = q_ew.x, pin_q2 = q_ew.y, pin_q3 = q_ew.z;
+                asm volatile("" : "+v"(pin_q0), "+v"(pin_q1), "+v"(pin_q2), "+v"(pin_q3));
+            } else {
+                double pin_p0 = pos0, pin_p1 = pos1, pin_p2 = pos2;
+                asm volatile("" : "+v"(pin_p0), "+v"(pin_p1), "+v"(pin_p2));
+            }
         }
         emit.xpub(DUO_PT_R);   // ----- point R: state rows read (role D may rewrite the kinematics rows; this wave's previous evaluation is complete) -----
         double lat, lon;
@@ -207,11 +234,26 @@ DUO_MARK(1, 6);   // engine head done
         lds_cptr RA = T.rk + LDS_AERO;
         const v3 w_eb_b = {x[FB_X_OMEGA_EB_B], x[FB_X_OMEGA_EB_B + 1], x[FB_X_OMEGA_EB_B + 2]};
         const v3 v_eb_b = {x[FB_X_V_EB_B], x[FB_X_V_EB_B + 1], x[FB_X_V_EB_B + 2]};
-        const quat q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
-        double s_nw, c_nw;
-        half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
-        const quat q_nw = {c_nw, 0.0, 0.0, s_nw};
-        const quat q_nb = {c_nw * q_wb.w - s_nw * q_wb.z, c_nw * q_wb.x - s_nw * q_wb.y, c_nw * q_wb.y + s_nw * q_wb.x, c_nw * q_wb.z + s_nw * q_wb.w};
+        [[maybe_unused]] quat q_wb = {1, 0, 0, 0}, q_nw = {1, 0, 0, 0}, q_en = {1, 0, 0, 0}, q_eb_s = {1, 0, 0, 0};
+        [[maybe_unused]] double ned_s2 = 0, ned_c2 = 1, ned_s3 = 0, ned_c3 = 1;
+        quat q_nb;
+        if constexpr (KIN == FB_KIN_WA) {
+            q_wb = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+            double s_nw, c_nw;
+            half_angle_cs(-(dq34 + dq12), dq24 - dq13, c_nw, s_nw);
+            q_nw = {c_nw, 0.0, 0.0, s_nw};
+            q_nb = {c_nw * q_wb.w - s_nw * q_wb.z, c_nw * q_wb.x - s_nw * q_wb.y, c_nw * q_wb.y + s_nw * q_wb.x, c_nw * q_wb.z + s_nw * q_wb.w};
+        } else if constexpr (KIN == FB_KIN_ECEF) {
+            q_eb_s = {x[KX], x[KX + 1], x[KX + 2], x[KX + 3]};
+            q_en = ltf_quat(n_e);
+            q_nb = qmul(qconj(q_en), q_eb_s);
+        } else {
+            double s1, c1;   // Rz(ψ) ∘ Ry(θ) ∘ Rx(φ) (attitude.jl:393-395), the products without their terms in the factors' zeros
+            sincos_step(0.5 * x[KX], s1, c1); sincos_step(0.5 * x[KX + 1], ned_s2, ned_c2); sincos_step(0.5 * x[KX + 2], ned_s3, ned_c3);
+            const quat zy = {c1 * ned_c2, -(s1 * ned_s2), c1 * ned_s2, ned_c2 * s1};
+            q_nb = {zy.w * ned_c3 - zy.x * ned_s3, zy.w * ned_s3 + ned_c3 * zy.x, ned_c3 * zy.y + zy.z * ned_s3, ned_c3 * zy.z - zy.y * ned_s3};
+            q_en = ltf_quat(n_e);
+        }
         // wind-relative velocity (atmosphere.jl:269-283)
         const v3 v_ew_n = {env.wind_n, env.wind_e, env.wind_d};
         const v3 v_ew_b = qrot_inv(q_nb, v_ew_n);
@@ -222,7 +264,10 @@ DUO_MARK(1, 6);   // engine head done
         }
         emit.xpub(DUO_PT_V);   // ----- point V: velocity at the propeller put -----
         DUO_MARK(2, 1);   // head, velocity at the propeller put
-        const quat q_eb = qmul(q_ew, q_wb);
+        quat q_eb;
+        if constexpr (KIN == FB_KIN_WA) q_eb = qmul(q_ew, q_wb);
+        else if constexpr (KIN == FB_KIN_ECEF) q_eb = q_eb_s;
+        else q_eb = qmul(q_en, q_nb);
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
@@ -274,11 +319,33 @@ DUO_MARK(1, 6);   // engine head done
         const double i_RE = RN_h * i_REN, i_RN = RE_h * i_REN;
         const v3 v_eb_n = qrot(q_nb, v_eb_b);
         const v3 w_ew_n = {v_eb_n.y * i_RE, -v_eb_n.x * i_RN, 0.0};
+        v3 w_wb_b;
+        if constexpr (KIN == FB_KIN_ECEF) {   // kinematics.jl:282-320
+            w_wb_b = w_eb_b - qrot_inv(q_nb, w_ew_n);
+            const quat a = qmul(q_eb, quat{0.0, w_eb_b.x, w_eb_b.y, w_eb_b.z});   // Attitude.dt(q_eb, ω_eb_b)
+            const v3 nd = qrot(q_en, cross(w_ew_n, v3{0.0, 0.0, -1.0}));           // :309
+            const double kq1[4] = {0.5 * a.w, 0.5 * a.x, 0.5 * a.y, 0.5 * a.z};
+            const double kq2[5] = {nd.x, nd.y, nd.z, -v_eb_n.z, 0.0};
+            emit_rows<4>(emit, KX, kq1);
+            emit_rows<5>(emit, KX + 4, kq2);
+        } else if constexpr (KIN == FB_KIN_NED) {   // kinematics.jl:366-425, in the forms of rhs() (sin / cos of θ, φ from the half-angle pairs)
+            w_wb_b = w_eb_b - qrot_inv(q_nb, w_ew_n);
+            const double tan_lat = n_e.z * rsqrt(n_e.x * n_e.x + n_e.y * n_e.y);
+            const double sph = 2 * (ned_s3 * ned_c3), cph = ned_c3 * ned_c3 - ned_s3 * ned_s3;
+            const double sth = 2 * (ned_s2 * ned_c2), cth = ned_c2 * ned_c2 - ned_s2 * ned_s2;
+            const double sec = 1.0 / cth, tth = sth * sec, i_cla = 1.0 / ned_cla;
+            const v3 w_en_n = {w_ew_n.x, w_ew_n.y, -v_eb_n.y * tan_lat / (R_E + h_e)};
+            const v3 w_nb_b = w_eb_b - qrot_inv(q_nb, w_en_n);
+            const double kq1[4] = {sph * sec * w_nb_b.y + cph * sec * w_nb_b.z, cph * w_nb_b.y - sph * w_nb_b.z,
+                                   w_nb_b.x + sph * tth * w_nb_b.y + cph * tth * w_nb_b.z, -w_en_n.y};
+            const double kq2[5] = {w_en_n.x * i_cla, -v_eb_n.z, 0.0, 0.0, 0.0};
+            emit_rows<4>(emit, KX, kq1);
+            emit_rows<5>(emit, KX + 4, kq2);
+        } else {
         const double cpsi = q_nw.w * q_nw.w - q_nw.z * q_nw.z, spsi = 2 * (q_nw.w * q_nw.z);
         const v3 w_ew_w = {cpsi * w_ew_n.x + spsi * w_ew_n.y, cpsi * w_ew_n.y - spsi * w_ew_n.x, 0.0};
         const v3 w_ew_b = qrot_inv(q_wb, w_ew_w);
-        const v3 w_wb_b = w_eb_b - w_ew_b;
-        {
+        w_wb_b = w_eb_b - w_ew_b;
             const quat a = {-(q_wb.x * w_wb_b.x + q_wb.y * w_wb_b.y + q_wb.z * w_wb_b.z),
                             q_wb.w * w_wb_b.x + (q_wb.y * w_wb_b.z - q_wb.z * w_wb_b.y),
                             q_wb.w * w_wb_b.y + (q_wb.z * w_wb_b.x - q_wb.x * w_wb_b.z),

@@ -3,8 +3,8 @@
 // Mapping: one lane = one aircraft; state is structure-of-arrays in HBM (x[k*N + i]) so every load / store is one coalesced
 // 512-B request per wave. The three small tables are copied into LDS once per workgroup. The stepping kernels keep an aircraft's
 // state on chip (LDS panels, see "the stepping kernel" below) for the `nsteps` RK4 steps of a launch, so HBM traffic per
-// aircraft-step is (27 x 8 B read + 27 x 8 B write + flags) / nsteps. Cessna172Sv0 / WA / fp64 is stepped by the wave-specialised
-// k_step_duo (512-thread workgroups: two waves per aircraft group, c172_duo_device.hpp), everything else by k_step_air.
+// aircraft-step is (27 x 8 B read + 27 x 8 B write + flags) / nsteps. Cessna172Sv0 in fp64 (WA, ECEF, NED) is stepped by the wave-specialised
+// k_step_duo<KIN> (512-thread workgroups: two waves per aircraft group, c172_duo_device.hpp), everything else by k_step_air.
 //
 // Stepper semantics (lib/FlightCore/src/sim.jl:204-218,301-328 + OrdinaryDiffEq RK4):
 //   k1 = f(x_n) ; k2 = f(x_n + dt/2 k1) ; k3 = f(x_n + dt/2 k2) ; k4 = f(x_n + dt k3)
@@ -1085,7 +1085,6 @@ template <int KIN>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
     using SV = StateLds<B, false>;
-    static_assert(KIN == FB_KIN_WA, "the wave-specialised stepper is built for the WA mechanisation");
     __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs_duo())
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
@@ -1191,7 +1190,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     emit.xwait(DUO_PT_X);
                     (void)xv; (void)aux; (void)inl;
 #else
-                    rhs_duo<1>(xv, 0, eng, inl, a.env, T, emit, aux);
+                    rhs_duo<KIN, 1>(xv, 0, eng, inl, a.env, T, emit, aux);
 #endif
                 }
             } else duo_publish(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
@@ -1268,7 +1267,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 emit.xpub(DUO_PT_V); emit.xwait(DUO_PT_R); emit.xwait(DUO_PT_A); emit.xwait(DUO_PT_W); emit.xpub(DUO_PT_X);
                 (void)xv; (void)inl; (void)d0;
 #else
-                bits = rhs_duo<2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
+                bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
 #endif
             }
         } else duo_publish(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
@@ -1287,7 +1286,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             step++;
             bool mod = false;
             if (run) {
-                auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229
+                auto renorm = [&](int k0, int len) {   // normalize_block!(v, 1e-8), kinematics.jl:114-118; WA :226-229, ECEF :317-320, NED: none
                     double q[4] = {0, 0, 0, 0}, n2 = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (k < len) { q[k] = xs_l[SV::row(k0 + k) * B + t]; n2 += q[k] * q[k]; }
@@ -1298,7 +1297,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                         mod = true;
                     }
                 };
-                renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4);
+                if constexpr (KIN == FB_KIN_WA) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_EW, 4); }
+                else if constexpr (KIN == FB_KIN_ECEF) { renorm(FB_X_Q_WB, 4); renorm(FB_X_Q_WB + 4, 3); }
                 int stall = (d & D_STALL) ? 1 : 0, eng = (d >> D_ENG_SHIFT) & 3;
                 const int stall0 = stall, eng0 = eng;
                 if (aux.alpha > c172::alpha_stall_hi) stall = 1;

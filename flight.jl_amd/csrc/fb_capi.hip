@@ -149,8 +149,8 @@ static row_map_t row_map_of(fb_handle h) {
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
     } while (0)
-// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): Cessna172Sv0 / WA / fp64 is stepped by the
-// wave-specialised k_step_duo (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air
+// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): Cessna172Sv0 in fp64 (any mechanisation) is stepped by the
+// wave-specialised k_step_duo<KIN> (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air<KIN>
 static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
 #define FB_STEP_X2(KIN, GRID, A, K)                                                                                                   \
@@ -173,10 +173,12 @@ static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
             hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
         } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
-            hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                 \
+            if (h->duo) hipLaunchKernelGGL(k_step_duo<FB_KIN_ECEF>, grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);  \
+            else hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                            \
             hipLaunchKernelGGL((k_step_air<FB_KIN_ECEF, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                  \
         } else if (h->kin == FB_KIN_NED) {                                                                                            \
-            hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                  \
+            if (h->duo) hipLaunchKernelGGL(k_step_duo<FB_KIN_NED>, grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);   \
+            else hipLaunchKernelGGL(k_step_air<FB_KIN_NED>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                             \
             hipLaunchKernelGGL((k_step_air<FB_KIN_NED, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                   \
         } else if (h->dtype == FB_F32) {   /* fp32 airborne stepper; lanes near the ground go to the fp64 ground-capable kernel */    \
             hipLaunchKernelGGL(fbf::k_step_f32, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                         \
@@ -282,7 +284,7 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     HIPCHK(hipSetDevice(device_id));
     fb_handle h = new fb_handle_s();
     // the wave-specialised stepper exists for Cessna172Sv0 / WA / fp64 only; every other handle steps with k_step_air and needs no duo_pld
-    h->duo = model_id == FB_MODEL_C172S0 && kin_id == FB_KIN_WA && dtype == FB_F64 && env_step_duo();
+    h->duo = model_id == FB_MODEL_C172S0 && dtype == FB_F64 && env_step_duo();
     h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
     h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
     h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;

@@ -1,5 +1,5 @@
-"""The two airborne fp64 steppers of Cessna172Sv0 / WA against each other: the wave-specialised k_step_duo (two waves per SIMD,
-the default) and the one-wave-per-SIMD k_step_air (FLIGHTBATCH_DUO=0). Same physics, different evaluation order and fma
+"""The two airborne fp64 steppers of Cessna172Sv0 against each other, in each kinematic mechanisation: the wave-specialised k_step_duo (two
+waves per SIMD, the default) and the one-wave-per-SIMD k_step_air (FLIGHTBATCH_DUO=0). Same physics, different evaluation order and fma
 contraction: they agree to rounding, lane by lane, including on the lanes that are not ordinary — beyond the end of a ragged batch,
 terminated before the launch, sitting on the ground, sinking through the hand-over clearance in the middle of a launch."""
 import os
@@ -10,11 +10,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _world(fb, n, duo):
+H_E_ROW = {"WA": 20, "ECEF": 19, "NED": 17}     # the ellipsoidal altitude in the C ABI's state of each mechanisation
+
+
+def _world(fb, n, duo, kin="WA"):
     old = os.environ.get("FLIGHTBATCH_DUO")
     os.environ["FLIGHTBATCH_DUO"] = "1" if duo else "0"
     try:
-        return fb.BatchedWorld(n)
+        return fb.BatchedWorld(n, kinematics=kin)
     finally:
         if old is None:
             del os.environ["FLIGHTBATCH_DUO"]
@@ -26,16 +29,17 @@ def _scale(x):
     return np.maximum(np.abs(x), 1e-3)
 
 
-@pytest.mark.parametrize("n,spl", [(1000, 50), (333, 7), (64, 1)])
-def test_duo_and_air_steppers_agree(fb, n, spl):
+@pytest.mark.parametrize("n,spl,kin", [(1000, 50, "WA"), (333, 7, "WA"), (64, 1, "WA"), (1000, 50, "ECEF"), (333, 7, "NED"), (1000, 50, "NED"), (64, 1, "ECEF")])
+def test_duo_and_air_steppers_agree(fb, n, spl, kin):
     rng = np.random.default_rng(23 + n)
+    he = H_E_ROW[kin]
     h_trn = 250.0
     cruise = rng.random(n) < 0.6
     h = np.where(cruise, h_trn + rng.uniform(300, 4000, n), h_trn + rng.uniform(11, 30, n))       # the rest: short final, will cross 10 m
     gam = np.where(cruise, np.deg2rad(rng.uniform(-2, 4, n)), -np.deg2rad(rng.uniform(2, 5, n)))
     tp = fb.TrimParameters(EAS=np.where(cruise, rng.uniform(38, 58, n), rng.uniform(33, 40, n)), h_e=h, γ_wb_n=gam,
                            flaps=np.where(cruise, 0.0, 1.0), ψ_nb=rng.uniform(-3, 3, n))
-    ref = _world(fb, n, False)
+    ref = _world(fb, n, False, kin)
     ref.set_params(h_terrain=h_trn)
     fb.f_init(ref, tp)
     x0, s0, u0, ui0 = ref.x, ref.s, ref.u.copy(), ref.ui
@@ -45,8 +49,8 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
     u0[fb.K["FB_U_M_PILOT"]] = rng.uniform(50, 100, n)             # per-aircraft payload: the mass-property sums differ lane by lane
     x0 = x0.copy()
     far = np.nonzero(cruise & ok)[0][:8]
-    x0[fb.K["FB_X_H_E"], far[:4]] = 90e3                            # above the ISA model (found by role P: FB_ST_ISA_RANGE)
-    x0[fb.K["FB_X_H_E"], far[4:]] = -1500.0                         # below the altitude range (FB_ST_ALT_RANGE)
+    x0[he, far[:4]] = 90e3                                          # above the ISA model (FB_ST_ISA_RANGE)
+    x0[he, far[4:]] = -1500.0                                       # below the altitude range (FB_ST_ALT_RANGE)
     st0 = np.zeros(n, np.int32)
     st0[rng.random(n) < 0.05] = fb.K["FB_ST_NAN"]                  # terminated before the launch: must be left alone
     if n >= 512:
@@ -54,7 +58,7 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
         cruise[320:384] = True                                     # once, and the workgroup's barriers go on without them
     out = {}
     for duo in (False, True):
-        w = _world(fb, n, duo)
+        w = _world(fb, n, duo, kin)
         w.set_params(h_terrain=h_trn)
         w.set_state(x0, s0); w.u = u0; w.ui = ui0
         fb._lib.check(fb.lib.fb_set_status(w._h, st0.ctypes.data_as(fb._lib.C.POINTER(fb._lib.C.c_int32))))
@@ -70,9 +74,9 @@ def test_duo_and_air_steppers_agree(fb, n, spl):
     assert np.array_equal(xd[:, dead0], x0[:, dead0])               # untouched
     live = ok & (sta == 0)
     err = np.abs(xd - xa) / _scale(xa)
-    agl = xa[fb.K["FB_X_H_E"]] - h_trn                              # (ellipsoidal, good enough to tell who came near the ground)
+    agl = xa[he] - h_trn                                            # (ellipsoidal, good enough to tell who came near the ground)
     low = agl < 12 + 20                                             # these spent launches in the ground-capable pass, which both share
-    print("duo vs air after 300 steps: max scaled difference %.2e (aircraft that stayed high), %.2e (went low); handed over: %d" % (
+    print(kin, "duo vs air after 300 steps: max scaled difference %.2e (aircraft that stayed high), %.2e (went low); handed over: %d" % (
         err[:, live & ~low].max(), err[:, live & low].max() if (live & low).any() else 0.0, int((live & low).sum())))
     assert live.sum() > n // 3
     assert err[:, live & ~low].max() < 1e-10
