@@ -283,7 +283,7 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (device_id >= ndev) return fail("device_id out of range");
     HIPCHK(hipSetDevice(device_id));
     fb_handle h = new fb_handle_s();
-    // the wave-specialised stepper exists for Cessna172Sv0 / WA / fp64 only; every other handle steps with k_step_air and needs no duo_pld
+    // the wave-specialised stepper exists for Cessna172Sv0 in fp64 (any mechanisation); every other handle steps with k_step_air and needs no duo_pld
     h->duo = model_id == FB_MODEL_C172S0 && dtype == FB_F64 && env_step_duo();
     h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
     h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;

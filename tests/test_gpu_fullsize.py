@@ -139,3 +139,51 @@ def test_config3_per_gpu_share_xv2_autopilot(fb, oracle):
     fb.step(sim2, 10.0); w2.sync()
     assert np.array_equal(w2.x, x1[:, sel]) and np.array_equal(w2.cs, cs1[:, sel])
     w2.close(); w.close()
+
+
+@pytest.mark.parametrize("kin", ["ECEF", "NED"])
+def test_config2_full_size_other_mechanisations(fb, oracle, kin):
+    """configs[2]'s batch (N = 1 048 576 on bench.py's lattice) in the ECEF and NED mechanisations, stepped by k_step_duo<KIN>: invariants on
+    ALL aircraft after 4 launches of 50 steps, a stratified sample of 512 against the oracle in the same mechanisation, and big batch ==
+    small batch bit for bit."""
+    import bench
+    K = fb.K
+    n = bench.N_TOTAL
+    nk = {"ECEF": 8, "NED": 6}[kin]
+    EAS, h, psi, cell = bench.lattice(0)
+    w = fb.BatchedWorld(n, kinematics=kin)
+    fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+    assert w.trim_success.all()
+    x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+    assert x0.shape[0] == 18 + nk
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    for _ in range(4):
+        fb.step(sim, 0.5)
+    w.sync()
+    x1, s1, st = w.x, w.s, w.status
+    assert (st == 0).all() and np.isfinite(x1).all()
+    assert (x1[8] < x0[8]).all(), "fuel must strictly decrease on every aircraft"
+    assert (x1[2:8] == 0).all() and (s1[1] == 2).all()
+    if kin == "ECEF":
+        for q in (x1[12:16], x1[16:19]):      # q_eb and n_e: renormalised by f_step! beyond 1e-8 (kinematics.jl:317-320)
+            assert np.abs(np.sqrt((q * q).sum(0)) - 1.0).max() <= 1e-8 * (1 + 1e-6)
+    sel = bench.stratified_sample(cell, per_cell=1)[::2]
+    assert sel.size == 512
+    xs = np.ascontiguousarray(x0[:, sel]); ss = np.ascontiguousarray(s0[:, sel]); us = np.ascontiguousarray(u0[:, sel]); uis = np.ascontiguousarray(ui0[sel])
+    oracle.lib.fo_set_kinematics(K["FB_KIN_" + kin])
+    try:
+        xo27 = np.zeros((27, sel.size)); xo27[:12 + nk] = xs[:12 + nk]; xo27[21:] = xs[12 + nk:]
+        xo, so, sto = oracle.step(xo27, us, uis, ss, oracle.default_env(), 0.01, 200, threads=min(oracle.max_threads(), bench.usable_cores()))
+    finally:
+        oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
+    assert (sto == 0).all() and np.array_equal(so, s1[:, sel])
+    xo_abi = np.vstack([xo[:12 + nk], xo[21:]])
+    err = np.abs(x1[:, sel] - xo_abi) / np.maximum(np.abs(xo_abi), 1.0)
+    print("configs[2] in %s at N = 1 048 576: max error of 512 stratified aircraft after 200 steps: %.3e" % (kin, err.max()))
+    assert err.max() < 1e-6
+    w2 = fb.BatchedWorld(sel.size, kinematics=kin)
+    w2.set_state(xs, ss); w2.u = us; w2.ui = uis
+    sim2 = fb.Simulation(w2, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.step(sim2, 2.0); w2.sync()
+    assert np.array_equal(w2.x, x1[:, sel])
+    w2.close(); w.close()
