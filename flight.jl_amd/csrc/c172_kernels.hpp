@@ -35,8 +35,8 @@ namespace fbd {
 //   * the skid azimuth by the stepping kernels' table atan2; reciprocal square roots where the reference divides by a square root;
 //   * F_b = N (q_sc f_c) from the rotation already made for N, instead of rotating N f_c again.
 template <bool FAST>
-__device__ FB_GROUND_ATTR void ground_common(quat q_eb, quat q_nb, GroundCommon& c) {
-    c.q_en = qmul(q_eb, qconj(q_nb));
+__device__ FB_GROUND_ATTR void ground_common(quat q_eb, quat q_en, GroundCommon& c) {
+    c.q_en = q_en;
     if constexpr (FAST) {
         // qrot(q, (0,0,1)) = (2 (q_y q_w + q_z q_x), 2 (q_z q_y - q_x q_w), 1 - 2 (q_x^2 + q_y^2)), term by term as the generic form makes them
         auto rot_z = [](quat q) { return v3{(2 * q.y) * q.w - (2 * q.z) * (-q.x), (2 * q.z) * q.y - (2 * q.x) * q.w, 1 + ((2 * q.x) * (-q.x) - (2 * q.y) * q.y)}; };

@@ -294,3 +294,51 @@ def test_x2_crash_under_autopilot(fb, oracle):
     assert cerr[:, term | flying].max() < 1e-6 and cerr.max() < 1e-4, (cerr[:, term | flying].max(), cerr.max())
     assert np.array_equal(w.s, o["s"])
     w.close()
+
+
+@pytest.mark.parametrize("kin", ["WA", "ECEF", "NED"])
+def test_steep_descents_into_the_ground_in_every_mechanisation(fb, oracle, kin):
+    """Rolling, steep descents (sink 7-17 m/s) from 8-30 m onto the terrain, in each kinematic mechanisation against the oracle in the same
+    one: the aircraft that hit hard end in GroundCrash — one wheel first, 10 cm into the ground within a step, 170 kN on a strut — and their
+    frozen state, status word, step and place must match. The step that carries an aircraft into contact is where the RK stages' off-unit
+    attitude quaternion matters: kinematics.y.q_en is q_eb ∘ q_nb' in WA (kinematics.jl:195: off unit by |q_wb|² at a stage) but ltf(n_e)
+    itself in ECEF and NED (:293, :377); until the end of round 3 the contact branch formed it the WA way in every mechanisation, and
+    ECEF aircraft ended 6·10⁻⁵ away from the oracle (found by the 10 000-step ECEF soak, tools/soak_duo.py)."""
+    K = fb.K
+    n = 4096
+    nk = {"WA": 9, "ECEF": 8, "NED": 6}[kin]
+    rng = np.random.default_rng(83)
+    h_trn = 120.0
+    lat, lon = 0.6, -1.1
+    N0 = geoid(oracle, np.array([lat]), np.array([lon]))[0]
+    tp = fb.TrimParameters(EAS=rng.uniform(45.0, 58.0, n), h_e=h_trn + N0 + 1.9 + rng.uniform(8.0, 30.0, n), ψ_nb=rng.uniform(-np.pi, np.pi, n),
+                           γ_wb_n=-rng.uniform(0.15, 0.30, n), n_e=(np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)))
+    w = fb.BatchedWorld(n, kinematics=kin)
+    w.set_params(h_terrain=h_trn)
+    fb.f_init(w, tp)
+    x0, s0, u0, ui0 = w.x, w.s, w.u.copy(), w.ui
+    u0[K["FB_U_AILERON"]] += rng.uniform(-0.4, 0.4, n)      # they roll on the way down: one wheel first
+    u0[K["FB_U_ELEVATOR"]] += rng.uniform(-0.1, 0.1, n)
+    w.u = u0
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=40)
+    fb.step(sim, 4.0); w.sync()
+    env = oracle.default_env(h_trn=h_trn)
+    oracle.lib.fo_set_kinematics(K["FB_KIN_" + kin])
+    try:
+        x27 = np.zeros((27, n)); x27[:12 + nk] = x0[:12 + nk]; x27[21:] = x0[12 + nk:]
+        xo27, so, sto, tso, two = oracle.step_term(x27, u0, ui0, s0, env, 0.01, 400, threads=16)
+    finally:
+        oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
+    xo = np.vstack([xo27[:12 + nk], xo27[21:]])
+    st = w.status
+    tstep, twhere = w.termination
+    term = sto != 0
+    print(f"{kin}: {int(term.sum())} of {n} ended; status words {np.unique(sto)}, places {np.unique(two[term])}")
+    assert term.sum() >= 1000 and np.array_equal(st, sto) and np.array_equal(tstep, tso) and np.array_equal(twhere, two)
+    assert (sto[term] == K["FB_ST_GROUND_CRASH"]).all()
+    err = np.abs(w.x - xo) / np.maximum(np.abs(xo), 1.0)
+    per = err[:, term].max(0)
+    print(f"{kin}: frozen state of the crashed aircraft against the oracle: quantiles 50 / 99 / 100 % {np.quantile(per, [0.5, 0.99, 1.0])}")
+    assert per.max() < 1e-6
+    assert np.array_equal(w.s[:, term], so[:, term])
+    w.close()
