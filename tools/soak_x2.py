@@ -1,6 +1,6 @@
 """One-off long run of the Cessna172Xv2 stepper (control laws inside the stepping kernel) against the CPU oracle: 100 s of closed-loop
 flight (10 000 RK4 steps, 5 000 control updates) for aircraft on randomised trims, every one in its own pair of control modes with its
-own references — in both forms of the gain lookup (shared cell / per-lookup headers).   python tools/soak_x2.py [n=1024]"""
+own references — in both forms of the gain lookup (shared cell / per-lookup headers).   python tools/soak_x2.py [n=1024] [WA|ECEF|NED]"""
 import os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ import flightbatch as fb
 import bench
 from oracle_binding import OracleX
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+kin = sys.argv[2] if len(sys.argv) > 2 else "WA"
 K = fb.K
 DT = 0.01
 rng = np.random.default_rng(41)
@@ -18,12 +19,14 @@ orc = bench._oracle()
 X = OracleX(orc, gains)
 env = orc.default_env()
 perm = np.array([k if k < K["FB_X2_ACT"] else (27 + k - K["FB_X2_ACT"] if k < K["FB_X2_KIN"] else k - K["FB_NACT"]) for k in range(34)])
+perm = np.array([r for r in perm if r not in {"WA": (), "ECEF": (20,), "NED": (18, 19, 20)}[kin]])   # C ABI row -> oracle / device row; the mechanisation's unused rows dropped
+orc.lib.fo_set_kinematics(K["FB_KIN_" + kin])
 modes_lon = rng.integers(0, 9, n); modes_lat = rng.integers(0, 5, n)
 dref = dict(EAS=rng.uniform(-3, 3, n), CLM=rng.uniform(-1.5, 1.5, n), PHI=rng.uniform(-0.3, 0.3, n), CHI=rng.uniform(-0.5, 0.5, n))
 ref = None
 for same_grid in ("1", "0"):
     os.environ["FLIGHTBATCH_CTL_SAME_GRID"] = same_grid
-    w = fb.Cessna172Xv2World(n, gains=gains)
+    w = fb.Cessna172Xv2World(n, gains=gains, kinematics=kin)
     sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=50)
     fb.init(sim, tp)
     cu = w.cu
@@ -34,12 +37,12 @@ for same_grid in ("1", "0"):
         o = X.trim_init(tp.pack(n), fb.TrimState(n), env, 2 * DT)
         o["status"] = np.zeros(n, np.int32); o["nstep"] = 0
         o["cu"] = np.ascontiguousarray(o["cu"]); o["cu"][:] = cu
-        o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
+        o["x"][:] = 0; o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
         t0 = time.time(); X.step_term(o, env, DT, 2, 10000, threads=min(orc.max_threads(), bench.usable_cores()))
         print("oracle: %d aircraft x 10000 closed-loop steps in %.1f s" % (n, time.time() - t0), flush=True)
         ref = o
     t0 = time.time(); fb.step(sim, 100.0); w.sync()
-    print("GPU (same_grid=%s): %d aircraft x 10000 steps in %.2f s" % (same_grid, n, time.time() - t0), flush=True)
+    print("GPU (%s, same_grid=%s): %d aircraft x 10000 steps in %.2f s" % (kin, same_grid, n, time.time() - t0), flush=True)
     term = ref["status"] != 0      # terminated aircraft are compared like the rest: frozen where the reference stops (FC/sim.jl:561-570)
     tsg, twg = w.termination
     sc = np.ones_like(ref["x"]); sc[:27] = bench.state_floor(ref["x"][:27])
@@ -51,3 +54,4 @@ for same_grid in ("1", "0"):
              err[:, ~term].max(), int((~term).sum()), int(err[:, ~term].max(axis=1).argmax()), err[:, term].max() if term.any() else 0.0, cerr.max(),
              np.array_equal(w.cs[K["FB_CS_LON_MODE"]], ref["cs"][K["FB_CS_LON_MODE"]])), flush=True)
     w.close()
+orc.lib.fo_set_kinematics(K["FB_KIN_WA"])
