@@ -16,14 +16,14 @@ from flightbatch.guidance import Segment  # noqa: E402
 LOC = (np.deg2rad(47.80433), np.deg2rad(12.997)); H_ORTH = 427.2; PSI = np.deg2rad(157.0)   # c172_demos.jl:17-19
 
 
-def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False):
+def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False, kinematics="WA"):
     """hold_decrab = False: the demo's callback to the letter — it leaves `seg.u.hor_gdc_req` set in the flare, so the guidance law puts the
     lateral channel back on track hold (χ_β) at its next update and the de-crab (φ_β with β_ref = ψ − χ_12) lasts one control period.
     hold_decrab = True: the request is dropped at the flare, so the bank + sideslip mode stays in force until touchdown (a variant, not
     the demo)."""
     K = fb.K
     rng = np.random.default_rng(seed)
-    w = fb.Cessna172Xv2World(n)
+    w = fb.Cessna172Xv2World(n, kinematics=kinematics)               # Cessna172Xv2(kinematics): WA (the demo's), ECEF or NED
     w.set_params(h_terrain=H_ORTH, wind_ned=(0.0, 6.0, 0.0))          # HorizontalTerrain(h_LOWS15); atmosphere.wind.u.E = 6
     # ellipsoidal altitude of the runway: orthometric + geoid height at the threshold (asked from the device model itself)
     probe = fb.TrimParameters(n_e=np.array([np.cos(LOC[0]) * np.cos(LOC[1]), np.cos(LOC[0]) * np.sin(LOC[1]), np.sin(LOC[0])]), h_e=1000.0)

@@ -27,6 +27,23 @@ def test_crosswind_landing_batch(fb, hold_decrab):
     assert out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2         # stopped, sitting on its wheels
 
 
+@pytest.mark.parametrize("kin", ["ECEF", "NED"])
+def test_crosswind_landing_in_the_other_mechanisations(fb, kin):
+    """The same scripted landing with Cessna172Xv2(ECEF()) / Cessna172Xv2(NED()): guidance on the tapped latitude / longitude, the flare,
+    touchdown, nose-wheel steering and braking through the ground-capable instance of that mechanisation. The touchdown points must be
+    those of the WA run to within a metre (the mechanisations integrate the same motion)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import crosswind_landing as demo
+    ref = demo.run(n=32, t_end=150.0, seed=3)
+    out = demo.run(n=32, t_end=150.0, seed=3, kinematics=kin)
+    td = out["touchdown"]
+    assert (out["status"] == 0).all() and (out["phase"] == 3).all()
+    assert np.isfinite(td).all() and np.abs(td[2]).max() < 3.0 and out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2
+    d = np.abs(td - ref["touchdown"])
+    print(kin, "touchdown against the WA run: time %.3f s, along track %.3f m, cross track %.3f m" % (d[0].max(), d[1].max(), d[2].max()))
+    assert d[0].max() < 0.1 and d[1].max() < 2.0 and d[2].max() < 0.2
+
+
 def test_crosswind_landing_is_reproducible(fb):
     """The same scenario twice in one process, bit for bit — through the airborne pass, the hand-over, the ground-capable pass and the
     in-kernel control laws. (A kernel miscompiled at full register pressure — spill code before the exec restore of a join block,
