@@ -783,3 +783,40 @@ def test_ground_roll_with_steering_and_brakes_matches_oracle(fb, oracle):
     # the reference's operations in their place (-DFB_GROUND_REFERENCE_FORMS) give these same three numbers to three digits.
     assert q[0] < 1e-6 and q[1] < 1e-5 and q[2] < 1e-3
     w.close()
+
+
+@pytest.mark.parametrize("kin", ["ECEF", "NED"])
+def test_f_step_in_the_other_mechanisations(fb, oracle, kin):
+    """f_step!(world) for Cessna172Sv0(ECEF()) — q_eb and n_e renormalised beyond 1e-8 (kinematics.jl:317-320) — and (NED()) — nothing to
+    renormalise (:409) — with the stall hysteresis, the engine's state machine and the regulator resets, against the oracle."""
+    K = fb.K
+    n = 512
+    nk = {"ECEF": 8, "NED": 6}[kin]
+    w = fb.BatchedWorld(n, kinematics=kin)
+    fb.f_init(w, lattice_trim_params(fb, n, seed=5))
+    rng = np.random.default_rng(4)
+    x = w.x; s = w.s; ui = w.ui
+    if kin == "ECEF":
+        x[12] = np.where(rng.random(n) < 0.5, 3.0, x[12])          # q_eb[1] = 3 forces renormalisation
+        x[16:19] *= (1 + 1e-7 * rng.random(n))                      # n_e: norm drift > 1e-8 on some, below it on others
+    x[2:8] = rng.normal(0, 1, (6, n))
+    v0 = 12 + nk + 3
+    x[v0] = np.where(rng.random(n) < 0.3, 12.0, x[v0]); x[v0 + 2] = np.where(rng.random(n) < 0.3, 8.0, x[v0 + 2])   # high alpha -> stall
+    s[0] = rng.integers(0, 2, n); s[1] = rng.integers(0, 3, n)
+    x[9] = rng.uniform(10, 300, n)
+    x[8] = np.where(rng.random(n) < 0.2, -0.01, x[8])
+    ui = ui | np.where(rng.random(n) < 0.5, 1, 0).astype(np.int32) | np.where(rng.random(n) < 0.2, 2, 0).astype(np.int32)
+    w.set_state(x, s); w.ui = ui
+    fb.f_step(w); w.sync()
+    oracle.lib.fo_set_kinematics(K["FB_KIN_" + kin])
+    try:
+        x27 = np.zeros((27, n)); x27[:12 + nk] = x[:12 + nk]; x27[21:] = x[12 + nk:]
+        xo27, so, sto = oracle.f_step(x27, w.u, ui, s, oracle.default_env())
+    finally:
+        oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
+    xo = np.vstack([xo27[:12 + nk], xo27[21:]])
+    assert (w.s == so).all()
+    assert np.max(np.abs(w.x - xo) / np.maximum(np.abs(xo), 1e-3)) < 1e-14
+    if kin == "ECEF":
+        assert (np.abs(np.sqrt((w.x[12:16] ** 2).sum(0)) - 1) < 1e-8 * (1 + 1e-6)).all() and (np.abs(np.sqrt((w.x[16:19] ** 2).sum(0)) - 1) <= 1e-7).all()
+    w.close()
