@@ -238,16 +238,18 @@ def refine_lookup(blob, offsets, recs, k, along_EAS=True):
     return np.concatenate([blob[:o], hdr, fine.reshape(-1), blob[o + 6 + nE * nH * rec:]])
 
 
-@pytest.mark.parametrize("variant", ["same_grid", "per_lookup_headers", "one_lookup_refined"])
-def test_x2_control_laws_fuzz(fb, oracle, gains, variant, monkeypatch):
+@pytest.mark.parametrize("variant,kin", [("same_grid", "WA"), ("per_lookup_headers", "WA"), ("one_lookup_refined", "WA"), ("same_grid", "ECEF"), ("same_grid", "NED")])
+def test_x2_control_laws_fuzz(fb, oracle, gains, variant, kin, monkeypatch):
     """f_periodic!(Unconditional(), world) — guidance + control laws — from 16 384 random controller records: every pair of
     previous / requested modes (so every bumpless-transfer branch), arbitrary compensator states and saturation flags, references
     all over the place, gain lookups inside, on the edge of and outside the (EAS, h) grid; record and inputs against the oracle.
     Variants: the shared-cell lookup (the reference's ten lookups sit on one grid), the per-lookup headers forced on the same blob,
     and a blob whose q2e and v2t lookups are resampled on finer grids (the library must notice that the grids differ; the oracle
-    runs on the original blob: the functions are the same. The blob must still fit the 6144 doubles fb_f_periodic stages in LDS)."""
+    runs on the original blob: the functions are the same. The blob must still fit the 6144 doubles fb_f_periodic stages in LDS). The
+    first variant also for Cessna172Xv2(ECEF()) / (NED()): k_x2_ctl<KIN> takes its inputs from that mechanisation's evaluation."""
     K = fb.K
     n = 16384
+    dyn0 = K["FB_X2_DYN"] - {"WA": 0, "ECEF": 1, "NED": 3}[kin]      # first row of w_eb_b in the C ABI's state of this mechanisation
     gains_gpu = gains
     if variant == "per_lookup_headers": monkeypatch.setenv("FLIGHTBATCH_CTL_SAME_GRID", "0")
     if variant == "one_lookup_refined":
@@ -263,11 +265,11 @@ def test_x2_control_laws_fuzz(fb, oracle, gains, variant, monkeypatch):
         assert gains_gpu.size <= 6144
     rng = np.random.default_rng(99)
     tp = fb.TrimParameters(EAS=rng.uniform(36, 56, n), h_e=rng.uniform(100, 3300, n), ψ_nb=rng.uniform(-3, 3, n))
-    w = fb.Cessna172Xv2World(n, gains=gains_gpu)
+    w = fb.Cessna172Xv2World(n, gains=gains_gpu, kinematics=kin)
     sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False)
     fb.init(sim, tp)
     x = w.x
-    x[K["FB_X2_DYN"]:K["FB_X2_DYN"] + 3] += rng.normal(0, 0.05, (3, n)); x[K["FB_X2_DYN"] + 3:] += rng.normal(0, 2.0, (3, n))
+    x[dyn0:dyn0 + 3] += rng.normal(0, 0.05, (3, n)); x[dyn0 + 3:] += rng.normal(0, 2.0, (3, n))
     x[K["FB_X2_ACT"]:K["FB_X2_ACT"] + 4] += rng.normal(0, 0.2, (4, n))
     w.set_state(x, w.s)
     cu = w.cu
@@ -293,12 +295,16 @@ def test_x2_control_laws_fuzz(fb, oracle, gains, variant, monkeypatch):
     for k in ("THROTTLE_CMD",):
         cs[K["FB_CS_" + k]] = rng.uniform(0, 1, n)
     w.cu = cu; w.cs = cs
-    perm = ref_to_dev_rows(K)
+    perm = abi_to_dev_rows(K, kin)
     X = OracleX(oracle, gains)
     st = dict(x=np.zeros((34, n)), u=w.u, ui=w.ui, s=w.s, cu=cu.copy(), cs=cs.copy())
     st["x"][perm] = w.x
     fb.f_periodic(w); w.sync()
-    X.f_periodic(st, oracle.default_env(), 0.02)
+    oracle.lib.fo_set_kinematics(K["FB_KIN_" + kin])
+    try:
+        X.f_periodic(st, oracle.default_env(), 0.02)
+    finally:
+        oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
     dcs = np.abs(w.cs - st["cs"]) / np.maximum(np.abs(st["cs"]), 1.0)
     dcu = np.abs(w.cu - st["cu"]) / np.maximum(np.abs(st["cu"]), 1.0)
     print("control-law fuzz: record %.2e (row %d), inputs %.2e" % (dcs.max(), dcs.max(1).argmax(), dcu.max()))
