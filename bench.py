@@ -385,6 +385,20 @@ def extra_x2(fb, C, args, timed=None):
     return out
 
 
+# configs[4] computes in fp32 and BASELINE.md asks for it "reported with its own tolerance": the stated bounds on an fp32 Cessna172Sv0 after
+# 10 s (1000 steps) against the fp64 oracle, in physical units (q_ew and h_e are integrated in fp64: their increments are below one fp32
+# ulp), and on an fp32 Robot2D against its fp64 oracle as a scaled error. The same numbers are asserted by tests/test_gpu_f32.py and by
+# tests/test_gpu_fullsize.py::test_config4_mixed_fp32_fleet_as_stated.
+F32_TOLERANCE = {"rates_rad_s": 5e-6, "velocity_m_s": 2e-3, "altitude_m": 0.05, "q_wb": 2e-5, "q_ew": 1e-8, "engine_speed_rad_s": 0.05,
+                 "robot2d_scaled": 2e-3}
+
+
+def f32_abs_errors(x, xo, ok):
+    d = np.abs(x - xo)[:, ok]
+    return {"rates_rad_s": float(d[21:24].max()), "velocity_m_s": float(d[24:27].max()), "altitude_m": float(d[20].max()),
+            "q_wb": float(d[12:16].max()), "q_ew": float(d[16:20].max()), "engine_speed_rad_s": float(d[9].max())}
+
+
 def extra_fleet(fb, C, args):
     """BASELINE.json configs[4] on one GPU: N = 1 M vehicles, 50 % Cessna172Sv0 / 50 % Robot2D interleaved, fp32, dt = 0.01, Δt = 0.02."""
     n = N_TOTAL
@@ -429,11 +443,13 @@ def extra_fleet(fb, C, args):
     fb.step(sim, 10.0); w.sync()
     xo, so, sto = orc.step(x0, u0, ui0, s0, orc.default_env(), DT, 1000, threads=min(orc.max_threads(), usable_cores()))
     ok = (sto == 0) & (w.status == 0)
-    d = np.abs(w.x - xo)[:, ok]
-    out["rel_err_vs_cpu"] = {"max_scaled_error": float(scaled_error(w.x, xo)[:, ok].max()), "tolerance": None,
-                             "absolute": {"rates_rad_s": float(d[21:24].max()), "velocity_m_s": float(d[24:27].max()), "altitude_m": float(d[20].max()),
-                                          "q_wb": float(d[12:16].max()), "q_ew": float(d[16:20].max())},
-                             "sample": f"{int(ok.sum())} fp32 aircraft of the fleet's lattice x 1000 RK4 steps vs the fp64 oracle (C++ port)"}
+    absolute = f32_abs_errors(w.x, xo, ok)
+    out["rel_err_vs_cpu"] = {"max_scaled_error": float(scaled_error(w.x, xo)[:, ok].max()),
+                             "tolerance": {k: v for k, v in F32_TOLERANCE.items() if k in absolute},
+                             "within_tolerance": bool(all(absolute[k] < F32_TOLERANCE[k] for k in absolute)),
+                             "absolute": absolute,
+                             "sample": f"{int(ok.sum())} fp32 aircraft of the fleet's lattice x 1000 RK4 steps vs the fp64 oracle (C++ port); "
+                                       "tolerance: the stated fp32 bounds, physical units (tests/test_gpu_f32.py, test_config4_mixed_fp32_fleet_as_stated)"}
     w.close()
     return out
 
@@ -537,12 +553,15 @@ def main():
                             "valu_busy": pj.get("valu_busy"),
                             "source": "rocprofv3 SQ_INSTS_VALU_* counters, profiles/" + PROFILE_COUNTERS + " (source hash " + here + ")"}
         line = {
-            "metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
+            # N > 1: the metric NAME says which of the two multi-GPU figures `value` is, so that a reader (or a driver) cannot set the weak-scaling
+            # number (N x 1 048 576 aircraft) against BASELINE's whole-node figure at N = 1 M, which rides along as `strong_scaling`
+            "metric": "aircraft-steps/sec" + ("" if world == 1 else (" (weak scaling: 1 048 576 aircraft PER GPU)" if scaling == "weak" else " (whole node at N = 1 M: strong scaling)")),
+            "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["elapsed"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"N={head['n_total']} Cessna172Sv0 " + (f"over {world} GPUs (contiguous shards of {n}), " if world > 1 and scaling == "strong" else
-                                                                            (f"({n} on each of {world} GPUs: configs[2] per GPU), " if world > 1 else "")) +
+                                                                            (f"({n} on each of {world} GPUs: configs[2] PER GPU — weak scaling, NOT BASELINE's whole-node N = 1 M figure: see strong_scaling), " if world > 1 else "")) +
                                     "randomised trim (EAS 35-55 m/s x h 200-3000 m x heading lattice, LCG-permuted), " +
                                     ("fp64" if args.dtype == "f64" else "fp32 airborne stepper (positions integrated in fp64)") + ", dt=0.01 (BASELINE.json configs[2])"),
                        "aircraft_total": head["n_total"], "aircraft_per_gpu": n, "rk4_steps_per_launch": args.inner, "rk4_steps_per_contract_step": args.inner, "dt": DT,

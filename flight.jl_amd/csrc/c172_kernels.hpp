@@ -233,6 +233,13 @@ struct KArgs {
 // (altitude below h_min: FP/kinematics.jl:190,199 -> geodesy.jl:218-221; ISA range: atmosphere.jl:133), the struts after them
 // (landinggear.jl:240, 321), the centre of mass last (dynamics.jl:477-486). (A strut's assertion ahead of a LATER strut's altitude
 // error is not told apart: both need the wheels on the ground AND below h_min.)
+// A status bit raised outside fb_step (the single-call verbs): the record says so, with the step count of the moment — unless the
+// aircraft already carries a record (fb_get_termination promises a valid step and place next to every termination bit)
+FBD void mark_outside_step(int32_t* status, long long* term_step, int32_t* term_where, long long step0, int64_t i, int32_t st) {
+    if (st == 0) return;
+    if ((status[i] & ~FB_ST_NAN) == 0 && (st & ~FB_ST_NAN) != 0) { term_where[i] = FB_TERM_OUTSIDE_STEP; term_step[i] = step0; }
+    status[i] |= st;
+}
 FBD int32_t first_exception(int32_t bits) {
     if (bits & FB_ST_ALT_RANGE) return FB_ST_ALT_RANGE;
     if (bits & FB_ST_ISA_RANGE) return FB_ST_ISA_RANGE;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
 #pragma unroll
         for (int k = 0; k < NXT; k++) xdot[(int64_t)k * a.n + i] = xd[k];
     }
-    a.status[i] |= st;
+    mark_outside_step(a.status, a.term_step, a.term_where, a.step0, i, st);
 }
 
 // f_step!(world). The reference acts on the y left behind by the last f_ode!; f_ode! is a pure
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * a.n + i] = x[k];
     a.s[i] = stall;
     a.s[a.n + i] = eng;
-    a.status[i] |= st;
+    mark_outside_step(a.status, a.term_step, a.term_where, a.step0, i, st);
 }
 
 // ---- nsteps x step!(sim), fused: the stepping kernel ------------------------------------------------------------------------------
@@ -569,6 +576,14 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     [[maybe_unused]] int tkey = TKEY_NONE;     // per lane
     [[maybe_unused]] bool replaying = false;   // wave-uniform
     bool mine = true;                          // per lane: this pass steps the lane
+    // What a lane carries from the loop into the epilogue is declared ABOVE the replay's entry point and (re)loaded for the replayed lanes
+    // only: the other lanes of the wave — the ones that finished the launch, or crashed in f_step! — sit the second pass out and must
+    // write back what THEIR launch left (stall flag, engine state, actuator positions, steps completed), not the launch-start values.
+    constexpr int NAL = GROUND ? (int)FB_NACT : (int)FB_ACT_BRAKE_LEFT;   // actuators tracked through the stages (on the ground the brakes are inputs of the RHS like the rest)
+    static_assert(FB_ACT_BRAKE_LEFT == 5 && FB_ACT_BRAKE_RIGHT == 6 && FB_NACT == 7, "brakes are the last two actuators");
+    double xa[X ? NAL : 1], ca[X ? NAL : 1];
+    int steps_alive = 0;
+    int stall = 0, eng = 0;
 restart:
     if (mine) {
         bool to_ground = false;
@@ -600,13 +615,12 @@ restart:
     InT in;
     // actuator positions x_n and commands. Only the five the airborne RHS reads are tracked through the stages; the two brake
     // actuators are advanced at the end, over the steps this lane completed, with the same closed form.
-    constexpr int NAL = GROUND ? (int)FB_NACT : (int)FB_ACT_BRAKE_LEFT;   // (on the ground the brakes are inputs of the RHS like the rest)
-    static_assert(FB_ACT_BRAKE_LEFT == 5 && FB_ACT_BRAKE_RIGHT == 6 && FB_NACT == 7, "brakes are the last two actuators");
-    double xa[X ? NAL : 1], ca[X ? NAL : 1];
-    int steps_alive = 0;
+    if (mine) steps_alive = 0;
     if constexpr (X) {
+        if (mine) {
 #pragma unroll
-        for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+            for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+        }
         in.xa = nullptr; in.u_glob = a.u + i; in.n = a.n; in.ui = a.ui[i];
         sum_payload_of(in);
     } else {
@@ -616,7 +630,7 @@ restart:
         in.sum_payload();
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
-    int stall = a.s[i], eng = a.s[a.n + i];
+    if (mine) { stall = a.s[i]; eng = a.s[a.n + i]; }
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     const double z = dt / ACT_TAU;
     // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a
@@ -968,8 +982,23 @@ struct DuoSync {
                   // the divergent `if (run)` of the evaluation, where a counter incremented in place would advance for the running lanes only)
     int failed;
 };
+// Release / acquire. The counter store is a workgroup-scope RELEASE of this wave's LDS traffic: `s_waitcnt lgkmcnt(0)` ahead of it — every
+// ds_write above has been performed, every ds_read above has returned — which is what the LLVM AMDGPU memory model prescribes for a
+// workgroup-scope release fence over the local address space on gfx9 (the builtin fence, also with the "local" address-space argument,
+// adds vmcnt(0) on this compiler: it would stall role D on its aerodynamic constants' global loads at every point, so the wait is
+// written out). The ACQUIRE side needs no instruction of its own: the poll's ds_read has returned (lgkmcnt(0) ahead of the
+// v_readfirstlane that consumes it) before any LDS access below the loop is issued, and the LDS performs one wave's accesses in issue
+// order. -DFB_DUO_RELEASE_WAIT=0 builds the round-3 form (compiler barriers only; it rests on that in-order service for the stores
+// too) for A/B timing: profiles/r04_ab_fence.txt.
+#ifndef FB_DUO_RELEASE_WAIT
+#define FB_DUO_RELEASE_WAIT 1
+#endif
 FBD void duo_publish(DuoSync& sy, int k) {
+#if FB_DUO_RELEASE_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and, for the compiler: every LDS access above stays above ...)
+#else
     asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above ...)
+#endif
     *sy.mine = sy.base + k + 1;
     asm volatile("" ::: "memory");   // (... and every one below stays below)
 }
@@ -1196,6 +1225,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             } else duo_publish(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
             sy.base += DUO_NPT;
         }
+        // a wait of this role that ran into its bound (role D never arrived): the pair went on with a stale hand-over, so its aircraft
+        // are flagged here too (role D flags them when ITS waits fail; atomics: both roles may write the word)
+        if (__builtin_amdgcn_ballot_w64(sy.failed != 0) != 0 && valid) atomicOr(&a.status[i], (int32_t)FB_ST_NAN);
         return;
     }
     // ================= role D =================
@@ -1341,7 +1373,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         bad = bad || !isfinite(v);
         a.x[(int64_t)k * a.n + i] = v;
     }
-    if (bad || __builtin_amdgcn_ballot_w64(sy.failed != 0) != 0) a.status[i] |= FB_ST_NAN;   // (sy.failed: a synchronisation wait ran into its bound — the partner wave never arrived)
+    if (bad || __builtin_amdgcn_ballot_w64(sy.failed != 0) != 0) atomicOr(&a.status[i], (int32_t)FB_ST_NAN);   // (sy.failed: a synchronisation wait ran into its bound — the partner wave never arrived)
     a.s[i] = (d & D_STALL) ? 1 : 0;
     a.s[a.n + i] = (d >> D_ENG_SHIFT) & 3;
 }

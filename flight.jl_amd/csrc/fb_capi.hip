@@ -110,6 +110,22 @@ static int32_t check_ready(fb_handle h) {
     return 0;
 }
 static dim3 grid_for(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+// init! clears terminations (FC/sim.jl:390-414): the status words AND the termination record go together, so that a record can never
+// outlive the exception it describes
+static hipError_t clear_terminations(fb_handle h) {
+    if (hipError_t e = hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream)) return e;
+    if (hipError_t e = hipMemsetAsync(h->term_step, 0, sizeof(long long) * h->n, h->stream)) return e;
+    return hipMemsetAsync(h->term_where, 0, sizeof(int32_t) * h->n, h->stream);
+}
+// fb_set_status: an aircraft whose word the host makes non-zero without a record gets (step count, FB_TERM_OUTSIDE_STEP); one whose word
+// is cleared loses its record
+__global__ void k_mark_host_status(const int32_t* status, long long* term_step, int32_t* term_where, long long step0, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool term = (status[i] & ~FB_ST_NAN) != 0;
+    if (!term) { term_where[i] = FB_TERM_NONE; term_step[i] = 0; }
+    else if (term_where[i] == FB_TERM_NONE) { term_where[i] = FB_TERM_OUTSIDE_STEP; term_step[i] = step0; }
+}
 static bool is_x2(fb_handle h) { return h->model == FB_MODEL_C172X2; }
 // anything that changes x, s, u or the environment from outside the stepping kernel invalidates the carried FSAL derivative
 static void fsal_invalidate(fb_handle h) {
@@ -448,14 +464,14 @@ static int32_t set_state_impl(fb_handle h, const double* x, const int32_t* s, bo
     HIPCHK(hipSetDevice(h->device));
     if (h->model == FB_MODEL_ROBOT2D) {
         if (x) { if (int32_t rc = r2_upload(h, h->r2, h->r2->r, x, FB_R2_NX)) return rc; }
-        if (init) HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));
+        if (init) HIPCHK(clear_terminations(h));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (init) { h->r2->steps_done = 0; h->t = 0.0; }
         return 0;
     }
     if (x) { if (int32_t rc = copy_rows(h, h->x, x, nullptr, nx_of(h), row_map_of(h))) return rc; }
     if (s) HIPCHK(hipMemcpyAsync(h->s, s, sizeof(int32_t) * FB_NS * h->n, hipMemcpyHostToDevice, h->stream));
-    if (init) HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * h->n, h->stream));  // init! clears terminations (sim.jl:390-414)
+    if (init) HIPCHK(clear_terminations(h));  // init! clears terminations (sim.jl:390-414)
     HIPCHK(hipStreamSynchronize(h->stream));
     if (init) { h->t = 0.0; h->steps_done = 0; }
     return 0;
@@ -531,7 +547,7 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
         HIPCHK(hipGetLastError());
     }
     h->steps_done = 0;
-    HIPCHK(hipMemsetAsync(h->status, 0, sizeof(int32_t) * n, h->stream));
+    HIPCHK(clear_terminations(h));
     HIPCHK(hipMemcpyAsync(trim_state, d_ts, sizeof(double) * FB_NTS * n, hipMemcpyDeviceToHost, h->stream));
     if (success) HIPCHK(hipMemcpyAsync(success, h->trim_ok, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
     if (cost) HIPCHK(hipMemcpyAsync(cost, d_cost, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -561,7 +577,7 @@ int32_t fb_f_step(fb_handle h) {
         if (int32_t rc = r2_ready(h)) return rc;
         HIPCHK(hipSetDevice(h->device));
         R2State* R = h->r2;
-        R2_DISPATCH(k_r2_f_step);
+        R2_DISPATCH(k_r2_f_step, (long long)R->steps_done);
         return 0;
     }
     if (int32_t rc = check_ready(h)) return rc;
@@ -794,6 +810,28 @@ int32_t fb_set_status(fb_handle h, const int32_t* status) {
     if (!h || !status) return fail("null argument");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->status, status, sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    const long long step0 = h->model == FB_MODEL_ROBOT2D ? (long long)h->r2->steps_done : (long long)h->steps_done;
+    hipLaunchKernelGGL(k_mark_host_status, grid_for(h->n, 256), dim3(256), 0, h->stream, (const int32_t*)h->status, h->term_step, h->term_where, step0, h->n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_set_termination(fb_handle h, const int64_t* step, const int32_t* where) {
+    if (!h || !step || !where) return fail("null argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int32_t> st((size_t)h->n), wh((size_t)h->n);
+    std::vector<long long> ts((size_t)h->n);
+    HIPCHK(hipMemcpyAsync(st.data(), h->status, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->n; i++) {
+        const bool term = (st[(size_t)i] & ~FB_ST_NAN) != 0;
+        if (term && (where[i] < FB_TERM_OUTSIDE_STEP || where[i] > FB_TERM_F_ODE_REEVAL || step[i] < 0))
+            return fail("fb_set_termination: aircraft %lld carries a termination bit and the record (%lld, %d) is not one fb_get_termination returns", (long long)i, (long long)step[i], (int)where[i]);
+        ts[(size_t)i] = term ? (long long)step[i] : 0;
+        wh[(size_t)i] = term ? where[i] : (int32_t)FB_TERM_NONE;
+    }
+    HIPCHK(hipMemcpyAsync(h->term_step, ts.data(), sizeof(long long) * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->term_where, wh.data(), sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -837,8 +875,8 @@ int32_t fb_get_termination(fb_handle h, int64_t* step, int32_t* where) {
     if (step) HIPCHK(hipMemcpyAsync(ts.data(), h->term_step, sizeof(long long) * h->n, hipMemcpyDeviceToHost, h->stream));
     if (where) HIPCHK(hipMemcpyAsync(where, h->term_where, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    // the record is written when an aircraft terminates and means something only next to a termination bit (init clears the
-    // status words, not the record)
+    // the record is written when an aircraft terminates and means something only next to a termination bit (whatever clears the status
+    // words clears the record with them: clear_terminations)
     for (int64_t i = 0; i < h->n; i++) {
         const bool term = (st[(size_t)i] & ~FB_ST_NAN) != 0;
         if (step) step[i] = term ? (int64_t)ts[(size_t)i] : -1;

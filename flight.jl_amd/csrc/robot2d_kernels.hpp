@@ -174,10 +174,13 @@ __global__ __launch_bounds__(256) void k_r2_f_periodic(R2Args<T> a) {
     for (int k = 4; k < 10; k++) a.r[(int64_t)k * a.n + i] = r[k];
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_r2_f_step(R2Args<T> a) {
+__global__ __launch_bounds__(256) void k_r2_f_step(R2Args<T> a, long long step0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    if (fabs((double)a.r[(int64_t)2 * a.n + i]) > 45 * (3.14159265358979323846 / 180)) a.status[i] |= FB_ST_LOST_BALANCE;
+    if (fabs((double)a.r[(int64_t)2 * a.n + i]) > 45 * (3.14159265358979323846 / 180)) {
+        if (a.status[i] == 0) { a.term_where[i] = FB_TERM_OUTSIDE_STEP; a.term_step[i] = step0; }   // (the verb, not fb_step: see fb_get_termination)
+        a.status[i] |= FB_ST_LOST_BALANCE;
+    }
 }
 // f_init!(robot, InitParameters(u_m, ω, η)) (robot2d.jl:214-228, 563-570)
 template <class T>
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void k_r2_init(R2Args<T> a, const T* ip /*[3 x
     const T r[10] = {w, (w + (a.p.k_m * u_m) / a.p.b_m) * a.p.R, T(0), eta, clampT(u_m, T(-1), T(1)), T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
     for (int k = 0; k < 10; k++) a.r[(int64_t)k * a.n + i] = r[k];
-    a.status[i] = 0;
+    a.status[i] = 0; a.term_where[i] = FB_TERM_NONE; a.term_step[i] = 0;   // (init! clears terminations, record included)
 }
 
 }  // namespace fbr

@@ -62,6 +62,7 @@ def _load():
         "fb_get_step_count": ([H, C.POINTER(I64)], C.c_int32),
         "fb_set_step_count": ([H, I64, C.c_double], C.c_int32),
         "fb_set_status": ([H, I32], C.c_int32),
+        "fb_set_termination": ([H, C.POINTER(I64), I32], C.c_int32),
         "fb_log_configure": ([H, I64, I64, I32, C.c_int32], C.c_int32),
         "fb_log_clear": ([H], C.c_int32),
         "fb_log_record": ([H], C.c_int32),

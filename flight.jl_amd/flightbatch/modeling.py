@@ -242,7 +242,8 @@ class BatchedWorld:
         cnt = C.c_int64()
         check(lib.fb_get_step_count(self._h, C.byref(cnt)))
         ck = {k: getattr(self, k) for k in self._CKPT_ARRAYS}
-        ck.update(status=self.status, step_count=np.int64(cnt.value), t=np.float64(lib.fb_time(self._h)))
+        tstep, twhere = self.termination
+        ck.update(status=self.status, term_step=tstep, term_where=twhere, step_count=np.int64(cnt.value), t=np.float64(lib.fb_time(self._h)))
         return ck
 
     def restore(self, ck: dict) -> None:
@@ -254,8 +255,12 @@ class BatchedWorld:
             if k not in ("x", "s"):
                 setattr(self, k, ck[k])
         st = np.ascontiguousarray(ck["status"], dtype=np.int32)
-        check(lib.fb_set_status(self._h, _pi(st)))
         check(lib.fb_set_step_count(self._h, int(ck["step_count"]), float(ck["t"])))
+        check(lib.fb_set_status(self._h, _pi(st)))
+        if "term_step" in ck:   # (checkpoints written before the record was part of them: fb_set_status has marked the words FB_TERM_OUTSIDE_STEP)
+            ts = np.ascontiguousarray(ck["term_step"], dtype=np.int64)
+            tw = np.ascontiguousarray(ck["term_where"], dtype=np.int32)
+            check(lib.fb_set_termination(self._h, ts.ctypes.data_as(C.POINTER(C.c_int64)), _pi(tw)))
         self.t = float(ck["t"])
 
 

@@ -97,6 +97,8 @@ enum {
  * has no termination record.) */
 enum {
     FB_TERM_NONE = 0,
+    FB_TERM_OUTSIDE_STEP = 1,   /* the status bit was not raised by fb_step: a single-call verb (fb_f_ode / fb_f_step) raised it, or the host
+                                   set it (fb_set_status) without a record of its own; step = RK updates completed at that moment */
     FB_TERM_F_ODE_K2 = 2,
     FB_TERM_F_ODE_K3 = 3,
     FB_TERM_F_ODE_K4 = 4,
@@ -328,6 +330,11 @@ int32_t fb_status(fb_handle h, int32_t* status);
  * thrown (-1: not terminated), where [N] = FB_TERM_* (see above). Either pointer may be NULL. ≙ sim.t and the stack frame of the
  * exception the reference reports (FC/sim.jl:561-570). */
 int32_t fb_get_termination(fb_handle h, int64_t* step, int32_t* where);
+/* Checkpoint restore of that record (beside fb_set_status; there is no reference counterpart: a Julia session keeps its exception).
+ * step [N], where [N] as fb_get_termination returned them; entries of aircraft whose status word is zero are ignored. Every call that
+ * clears the status words (fb_trim, fb_set_state, Robot2D's fb_f_init) clears the record too; fb_set_status alone gives an
+ * aircraft whose word becomes non-zero without a record (FB_TERM_OUTSIDE_STEP, the current step count). */
+int32_t fb_set_termination(fb_handle h, const int64_t* step, const int32_t* where);
 
 /* Trajectory collection across GPUs: one RCCL all-gather of the state panels over xGMI; no other
  * communication exists on this path. One process per GPU; rank 0 calls fb_comm_unique_id and the host distributes the 128

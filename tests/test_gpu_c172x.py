@@ -3,6 +3,8 @@ and against the reference's closed-loop tolerances (lib/FlightApps/test/c172/tes
 import numpy as np
 import pytest
 
+import conditioning
+
 from oracle_binding import OracleX
 from test_gpu_parity import lattice_trim_params, state_scale
 
@@ -407,7 +409,12 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
         o["status"] = np.zeros(n, np.int32); o["nstep"] = 0
         s0 = a["start"]
         o["cu"] = np.ascontiguousarray(s0["cu"]); o["x"][:] = 0; o["x"][perm] = s0["x"]; o["cs"] = s0["cs"]; o["u"] = s0["u"]; o["ui"] = s0["ui"]; o["s"] = s0["s"]
+        o_start = {k: np.array(v, copy=True) for k, v in o.items() if isinstance(v, np.ndarray)}
         X.step_term(o, env, 0.01, 2, 1200)
+        # the oracle against itself (tests/conditioning.py): v_eb_b nudged once per aircraft as it comes within wheel reach of the runway
+        h_row_o = {"WA": 20, "ECEF": 19, "NED": 17}[kin]
+        pert_ulp = conditioning.x2_perturbed_runs(X, o_start, env, 1200, h_row_o, N0, None, K=2, seed=1, threads=16)
+        pert_rel = conditioning.x2_perturbed_runs(X, o_start, env, 1200, h_row_o, N0, 1e-12, K=4, seed=2, threads=16)
     finally:
         oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
     st, sto = a["status"], o["status"]
@@ -425,19 +432,25 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
           f"({int(flying.sum())}) | rolling {err[:, rolling].max() if rolling.any() else 0.0:.2e} ({int(rolling.sum())})")
     assert err[:, term].max() < 1e-6                      # (tolerances: see test_x2_crash_under_autopilot)
     assert not flying.any() or err[:, flying].max() < 1e-6
-    # the survivors have spent up to ten seconds bouncing and rolling under an autopilot that still demands a descent: stick-slip on six
-    # friction regulators (device rows 2-7: integrators with k_i = 400 1/s behind a sign-tested anti-windup halt, landinggear.jl:420-470).
-    # 99 % of them stay within 1e-5 of the oracle in every state (median 1e-7). About one aircraft in a thousand halts a regulator a step
-    # apart from the oracle's and carries the difference from there on (observed: 5e-3 on one regulator state of one lane with every other
-    # state of that lane within 1e-5; 1e-2 on a regulator and, through it, 1e-5 rad/s on the body rates of one lane that is almost at
-    # rest) — WHICH lane it is changes with any change of rounding anywhere in the contact code (it moved from the ECEF run to the
-    # WA run when one radius of curvature in the contact code was tried with a reciprocal square root instead of a division). So: the 99th percentile, a bound on how many lanes may be off, and on how far.
-    per_lane = err[:, rolling].max(0)
-    off = per_lane > 1e-4
-    print(f"Xv2({kin}) rolling: per-aircraft max error quantiles 50/99/100 % {np.quantile(per_lane, [0.5, 0.99, 1.0])}; beyond 1e-4: {int(off.sum())} of {int(rolling.sum())}")
-    assert rolling.sum() >= 100 and np.quantile(per_lane, 0.99) < 1e-5 and off.sum() <= 3 and per_lane.max() < 5e-2
+    # The survivors have spent up to ten seconds bouncing and rolling under an autopilot that still demands a descent: stick-slip on six
+    # friction regulators (device rows 2-7: integrators with k_i = 400 1/s behind a sign-tested anti-windup halt, landinggear.jl:411-476).
+    # How ill-conditioned that is, on these very aircraft, is MEASURED (tests/conditioning.py): the oracle is run again with v_eb_b of every
+    # aircraft nudged once as it reaches the runway — by one ulp, and by 1e-12 (the GPU's own distance from the oracle after an airborne
+    # approach) — and the GPU is held, aircraft by aircraft, to max(1e-6, 10 x |oracle − oracle'|): an aircraft whose envelope is below 1e-7
+    # holds the north star's 1e-6. State and control-law record together.
     cerr = np.abs(a["cs"] - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)
-    assert cerr[:, term | flying].max() < 1e-6 and np.quantile(cerr[:, rolling].max(0), 0.99) < 1e-5 and cerr.max() < 5e-2
+    assert cerr[:, term | flying].max() < 1e-6
+
+    def lane_err(xx, cc):   # per-aircraft max scaled distance from the nominal oracle run, state rows (oracle order) and control-law record
+        return np.maximum((np.abs(xx - o["x"]) / x_scale(o["x"])).max(0), (np.abs(cc - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)).max(0))
+    assert rolling.sum() >= 100
+    per_lane = np.maximum(err.max(0), cerr.max(0))[rolling]
+    E_ulp = np.stack([lane_err(p["x"], p["cs"])[rolling] for p in pert_ulp])
+    E_rel = np.stack([lane_err(p["x"], p["cs"])[rolling] for p in pert_rel])
+    assert all(p["nudged"][rolling].mean() > 0.95 for p in pert_ulp + pert_rel)   # (the rest came within 8 m of the runway in the last steps only)
+    print(f"Xv2({kin}) rolling ({int(rolling.sum())} aircraft): oracle vs oracle' with ONE ULP on v_eb_b at touchdown: per-aircraft quantiles 50/90/99/100 % "
+          f"{np.quantile(E_ulp.ravel(), [0.5, 0.9, 0.99, 1.0])}; beyond 1e-6: {int((E_ulp.max(0) > 1e-6).sum())}, beyond 1e-4: {int((E_ulp.max(0) > 1e-4).sum())}")
+    conditioning.check_against_envelope(per_lane, E_rel, f"Xv2({kin}) rolling")
     assert np.array_equal(a["s"], o["s"])
 
 

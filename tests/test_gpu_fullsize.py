@@ -187,3 +187,84 @@ def test_config2_full_size_other_mechanisations(fb, oracle, kin):
     fb.step(sim2, 2.0); w2.sync()
     assert np.array_equal(w2.x, x1[:, sel])
     w2.close(); w.close()
+
+
+def test_config4_mixed_fp32_fleet_as_stated(fb, oracle):
+    """BASELINE.json configs[4] as stated, on one GPU: a MixedFleet of 524 288 fp32 Cessna172Sv0 (bench.py's lattice(1): the reference's
+    Cessna172Sv0 at randomised C172.TrimParameters, FA/c172/c172s/c172s0.jl:14-18) and 524 288 fp32 Robot2D (FA/robot2d/robot2d.jl:526-570),
+    interleaved in the caller's order, dt = 0.01, Δt = 0.02, 10 s. Invariants on ALL 1 048 576 vehicles; packed == homogeneous bit for
+    bit; 1024 aircraft and 1024 robots against the fp64 oracle under the STATED fp32 tolerances (bench.F32_TOLERANCE — the numbers
+    bench.py's extra.fleet leg reports as its tolerance)."""
+    import ctypes as C
+    import bench
+    from test_oracle_robot2d import DEFAULT_VP, gains_from_h5, run
+    from test_gpu_robot2d import oracle_init
+    tol = bench.F32_TOLERANCE
+    n = bench.N_TOTAL
+    KC, KR = fb.K["FB_MODEL_C172S0"], fb.K["FB_MODEL_ROBOT2D"]
+    types = np.where(np.arange(n) % 2 == 0, KC, KR)
+    fleet = fb.MixedFleet(types, {KC: lambda m: fb.BatchedWorld(m, dtype="f32"), KR: lambda m: fb.Robot2DWorld(m, dtype="f32")})
+    fleet.simulate(dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    nc, nr = fleet.index[KC].size, fleet.index[KR].size
+    assert nc == n // 2 and nr == n // 2
+    EAS, h, psi, cell = bench.lattice(1)
+    EAS, h, psi, cell = EAS[:nc], h[:nc], psi[:nc], cell[:nc]
+    rng = np.random.default_rng(404)
+    ipar = fb.InitParameters(u_m=rng.uniform(-0.1, 0.1, nr), ω=rng.uniform(-0.05, 0.05, nr), η=rng.uniform(-1, 1, nr))
+    v_ref = rng.uniform(-0.3, 0.3, nr)
+    fleet.init({KC: fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi), KR: ipar})
+    cw, rw = fleet.worlds[KC], fleet.worlds[KR]
+    assert cw.trim_success.all()
+    ur = np.zeros((4, nr)); ur[0] = 1; ur[2] = v_ref; rw.u = ur                      # mode_v, a velocity reference per robot
+    x0, s0, u0, ui0 = cw.x, cw.s, cw.u, cw.ui
+    r0 = rw.x
+    for _ in range(20):
+        fleet.step(0.5)
+    fleet.sync()
+    x = fleet.gather("x")
+    st = fleet.gather("status", fill=-1)
+    is_r = types == KR
+    # ---- invariants on ALL vehicles
+    assert x.shape == (27, n) and (st == 0).all(), f"{int((st != 0).sum())} vehicles terminated"
+    xc, xr = x[:, ~is_r], x[:10, is_r]
+    assert np.isfinite(xc).all() and np.isfinite(xr).all() and np.isnan(x[10:, is_r]).all()
+    assert (xc[8] < x0[8]).all(), "fuel must strictly decrease on every aircraft"
+    assert (xc[2:8] == 0).all() and (cw.s[1] == 2).all()
+    assert np.abs(np.sqrt((xc[12:16] ** 2).sum(0)) - 1.0).max() < 1e-6          # fp32 attitude quaternion
+    assert np.abs(np.sqrt((xc[16:20] ** 2).sum(0)) - 1.0).max() <= 1e-8 * (1 + 1e-6)   # the position quaternion is integrated in fp64
+    assert np.abs(xc[20] - x0[20]).max() < 30.0
+    assert np.abs(xr[1] - v_ref).max() < 0.05, "every robot within 0.05 m/s of its velocity reference after 10 s"
+    assert np.array_equal(xc, cw.x) and np.array_equal(xr, rw.x)
+    # ---- packed == homogeneous, bit for bit (a sample of each model stepped in worlds of its own: results do not depend on the
+    # batch size, the lane position or what else runs on the GPU)
+    sel = bench.stratified_sample(cell, per_cell=1)
+    assert sel.size == 1024
+    w2 = fb.BatchedWorld(sel.size, dtype="f32")
+    xs, ss, us, uis = (np.ascontiguousarray(x0[:, sel]), np.ascontiguousarray(s0[:, sel]), np.ascontiguousarray(u0[:, sel]), np.ascontiguousarray(ui0[sel]))
+    w2.set_state(xs, ss); w2.u = us; w2.ui = uis
+    sim2 = fb.Simulation(w2, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.step(sim2, 10.0); w2.sync()
+    assert np.array_equal(w2.x, xc[:, sel]), "fp32 aircraft: packed fleet != homogeneous batch"
+    selr = np.sort(rng.choice(nr, 1024, replace=False))
+    r2 = fb.Robot2DWorld(selr.size, dtype="f32")
+    r2.set_state(np.ascontiguousarray(r0[:, selr])); r2.u = np.ascontiguousarray(ur[:, selr])
+    simr = fb.Simulation(r2, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    fb.step(simr, 10.0); r2.sync()
+    assert np.array_equal(r2.x, xr[:, selr]), "fp32 robots: packed fleet != homogeneous batch"
+    w2.close(); r2.close()
+    # ---- the samples against the fp64 oracle, stated fp32 tolerances
+    xo, so, sto = oracle.step(xs, us, uis, ss, oracle.default_env(), 0.01, 1000, threads=min(oracle.max_threads(), bench.usable_cores()))
+    assert (sto == 0).all() and np.array_equal(so, cw.s[:, sel])
+    e = bench.f32_abs_errors(xc[:, sel], xo, np.ones(sel.size, bool))
+    print("configs[4], 1024 fp32 aircraft of the fleet vs the fp64 oracle after 1000 steps:", {k: "%.2e" % v for k, v in e.items()})
+    for k, v in e.items():
+        assert v < tol[k], (k, v, tol[k])
+    vp = DEFAULT_VP.copy(); gp = gains_from_h5()
+    ro = oracle_init(oracle.lib, vp, np.ascontiguousarray(ipar.pack(nr)[:, selr]))
+    assert np.abs(ro - r0[:, selr]).max() < 1e-6                                   # (the oracle's f_init! and the fp32 device's agree)
+    sto_r = run(oracle.lib, vp, gp, ro, np.ascontiguousarray(ur[:, selr]), 0.01, 2, 1, 0, 1000)
+    assert (sto_r == 0).all()
+    er = np.max(np.abs(xr[:, selr] - ro) / np.maximum(np.abs(ro), 1.0))
+    print("configs[4], 1024 fp32 robots of the fleet vs the fp64 oracle after 1000 steps: max scaled error %.2e" % er)
+    assert er < tol["robot2d_scaled"]
+    fleet.close()
