@@ -414,7 +414,7 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
         # the oracle against itself (tests/conditioning.py): v_eb_b nudged once per aircraft as it comes within wheel reach of the runway
         h_row_o = {"WA": 20, "ECEF": 19, "NED": 17}[kin]
         pert_ulp = conditioning.x2_perturbed_runs(X, o_start, env, 1200, h_row_o, N0, None, K=2, seed=1, threads=16)
-        pert_rel = conditioning.x2_perturbed_runs(X, o_start, env, 1200, h_row_o, N0, 1e-12, K=4, seed=2, threads=16)
+        pert_rel = conditioning.x2_perturbed_runs(X, o_start, env, 1200, h_row_o, N0, 1e-12, K=4, jitter=conditioning.ULP_R, seed=2, threads=16)
     finally:
         oracle.lib.fo_set_kinematics(K["FB_KIN_WA"])
     st, sto = a["status"], o["status"]
@@ -435,9 +435,10 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
     # The survivors have spent up to ten seconds bouncing and rolling under an autopilot that still demands a descent: stick-slip on six
     # friction regulators (device rows 2-7: integrators with k_i = 400 1/s behind a sign-tested anti-windup halt, landinggear.jl:411-476).
     # How ill-conditioned that is, on these very aircraft, is MEASURED (tests/conditioning.py): the oracle is run again with v_eb_b of every
-    # aircraft nudged once as it reaches the runway — by one ulp, and by 1e-12 (the GPU's own distance from the oracle after an airborne
-    # approach) — and the GPU is held, aircraft by aircraft, to max(1e-6, 10 x |oracle − oracle'|): an aircraft whose envelope is below 1e-7
-    # holds the north star's 1e-6. State and control-law record together.
+    # aircraft nudged once as it reaches the runway — by one ulp (quoted in the log), and by 1e-12 (the GPU's own distance from the oracle
+    # after an airborne approach) with the altitude jittered by one ulp of the geocentric radius per step, the resolution of the contact
+    # geometry — and the GPU is held, aircraft by aircraft, to max(1e-6, 10 x |oracle − oracle'|): an aircraft whose envelope is below
+    # 1e-7 holds the north star's 1e-6. State and control-law record together.
     cerr = np.abs(a["cs"] - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)
     assert cerr[:, term | flying].max() < 1e-6
 

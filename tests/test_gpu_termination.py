@@ -270,7 +270,7 @@ def test_x2_crash_under_autopilot(fb, oracle):
     fb.step(sim, 12.0); w.sync()
     o_start = {k: np.array(v, copy=True) for k, v in o.items() if isinstance(v, np.ndarray)}
     X.step_term(o, env, 0.01, 2, 1200)
-    pert = conditioning.x2_perturbed_runs(X, o_start, env, 1200, 20, N0, 1e-12, K=4, seed=3, threads=16)   # the oracle against itself, below
+    pert = conditioning.x2_perturbed_runs(X, o_start, env, 1200, 20, N0, 1e-12, K=4, jitter=conditioning.ULP_R, seed=3, threads=16)   # the oracle against itself, below
     st, sto = w.status, o["status"]
     term = sto != 0
     print("Xv2 under autopilot:", int(term.sum()), "of", n, "crashed; status words", np.unique(sto), "places", np.unique(o["term_where"]))
@@ -290,7 +290,7 @@ def test_x2_crash_under_autopilot(fb, oracle):
     # the crashed aircraft (the point of this test) and the ones still in the air hold the north-star tolerance. The survivors of a
     # 6-10 m/s touchdown have spent up to ten seconds bouncing on dampers and stick-slip friction regulators (k_i = 400 1/s,
     # landinggear.jl:411-476): they are held to the MEASURED conditioning of that roll — the oracle run again with v_eb_b nudged by 1e-12
-    # at touchdown (tests/conditioning.py): per aircraft max(1e-6, 10 x |oracle - oracle'|), state and control-law record together
+    # at touchdown and the altitude jittered by one ulp of the geocentric radius per step (tests/conditioning.py): per aircraft max(1e-6, 10 x |oracle - oracle'|), state and control-law record together
     assert err[:, term].max() < 1e-6
     assert not flying.any() or err[:, flying].max() < 1e-6
     cerr = np.abs(w.cs - o["cs"]) / np.maximum(np.abs(o["cs"]), 1.0)
