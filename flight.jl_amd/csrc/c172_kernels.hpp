@@ -584,6 +584,13 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     double xa[X ? NAL : 1], ca[X ? NAL : 1];
     int steps_alive = 0;
     int stall = 0, eng = 0;
+    // (-DFB_REPLAY_BYSTANDER_DEFECT rebuilds the defect this guards against — every lane of a replayed wave reloading the launch-start
+    // values — so that the regression tests can be seen to fail on it: tests/test_gpu_termination.py, profiles/r04_replay_defect.txt)
+#ifdef FB_REPLAY_BYSTANDER_DEFECT
+#define FB_REPLAY_MINE true
+#else
+#define FB_REPLAY_MINE mine
+#endif
 restart:
     if (mine) {
         bool to_ground = false;
@@ -615,9 +622,9 @@ restart:
     InT in;
     // actuator positions x_n and commands. Only the five the airborne RHS reads are tracked through the stages; the two brake
     // actuators are advanced at the end, over the steps this lane completed, with the same closed form.
-    if (mine) steps_alive = 0;
+    if (FB_REPLAY_MINE) steps_alive = 0;
     if constexpr (X) {
-        if (mine) {
+        if (FB_REPLAY_MINE) {
 #pragma unroll
             for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
         }
@@ -630,7 +637,7 @@ restart:
         in.sum_payload();
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
-    if (mine) { stall = a.s[i]; eng = a.s[a.n + i]; }
+    if (FB_REPLAY_MINE) { stall = a.s[i]; eng = a.s[a.n + i]; }
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     const double z = dt / ACT_TAU;
     // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a

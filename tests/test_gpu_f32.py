@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def test_f32_trajectory_error_against_fp64_oracle(fb, oracle):
     """10 s of perturbed flight with fp32 arithmetic (positions integrated in fp64) against the fp64 oracle, in physical units:
-    body rates within 5e-6 rad/s, velocities within 2e-3 m/s, altitude within 5 cm, attitude quaternion within 2e-5 — three
+    body rates within 1e-5 rad/s, velocities within 2e-3 m/s, altitude within 5 cm, attitude quaternion within 2e-5 — three
     orders above the fp64 path's contract, and documented as such; discrete states and status agree."""
     n = 4096
     tp = lattice_trim_params(fb, n, seed=41)
@@ -40,7 +40,7 @@ def test_f32_trajectory_error_against_fp64_oracle(fb, oracle):
     print("absolute: rates %.1e rad/s, velocity %.1e m/s, altitude %.1e m, q_wb %.1e, q_ew %.1e, engine speed %.1e rad/s"
           % (d[21:24].max(), d[24:27].max(), d[20].max(), d[12:16].max(), d[16:20].max(), d[9].max()))
     tol = F32_TOLERANCE   # the stated fp32 bounds (bench.py: the same numbers go into extra.fleet.rel_err_vs_cpu.tolerance)
-    assert tol["rates_rad_s"] == 5e-6 and tol["velocity_m_s"] == 2e-3 and tol["altitude_m"] == 0.05 and tol["q_wb"] == 2e-5 and tol["engine_speed_rad_s"] == 0.05
+    assert tol["rates_rad_s"] == 1e-5 and tol["velocity_m_s"] == 2e-3 and tol["altitude_m"] == 0.05 and tol["q_wb"] == 2e-5 and tol["engine_speed_rad_s"] == 0.05
     assert d[21:24].max() < tol["rates_rad_s"] and d[24:27].max() < tol["velocity_m_s"] and d[20].max() < tol["altitude_m"]
     assert d[12:16].max() < tol["q_wb"] and d[9].max() < tol["engine_speed_rad_s"]
     # the aircraft did move over the Earth, and its position is as good as the velocity allows (the reason the position rows

@@ -358,15 +358,17 @@ def test_survivors_sharing_a_wave_with_a_thrower_keep_their_own_launch(fb, oracl
     left — here their stall flag and engine state CHANGE during the launch (a stall flag that starts set at a small angle of attack is
     cleared by the first f_step!, c172.jl:720; an engine stop request takes the running engine to `off`, piston.jl:300-312), so a write-back
     of launch-start values (the defect: s at t for a state x at t + K dt) shows in `s` and, one launch later, in the engine-speed row.
-    Throwers (a descent through h_o = -1000 m) and survivors (a climb away from it, within the 10 m of the floor that keep a lane in the
-    ground-capable pass) are interleaved at random, so practically every 64-lane wave holds both; every aircraft against the oracle."""
+    Throwers (a descent through h_e = -1000 m where the geoid is below the ellipsoid) and survivors (a slow climb away from it, within the
+    10 m of the floor that keep a lane in the ground-capable pass) are interleaved at random, so practically every 64-lane wave holds both;
+    every aircraft against the oracle. (Seen to fail on a library built with -DFB_REPLAY_BYSTANDER_DEFECT: profiles/r04_replay_defect.txt.)"""
     n = 4096
     rng = np.random.default_rng(97)
-    lat = np.zeros(n); lon = np.zeros(n)
-    N = geoid(oracle, lat[:1], lon[:1])[0]
+    lat = np.full(n, 0.05); lon = np.full(n, 1.38)     # the geoid is ~100 m BELOW the ellipsoid here: h_e reaches h_min first, and a lane
+    N = geoid(oracle, lat[:1], lon[:1])[0]              # within 10 m of it is stepped by the ground-capable pass (the one that replays)
+    assert N < -50
     thrower = rng.random(n) < 0.5
-    h_e = -1000.0 + N + np.where(thrower, rng.uniform(0.05, 6.0, n), rng.uniform(1.0, 5.0, n))
-    climb = np.where(thrower, -rng.uniform(3.0, 9.0, n), rng.uniform(0.5, 2.0, n))
+    h_e = -1000.0 + np.where(thrower, rng.uniform(2.5, 8.0, n), rng.uniform(4.0, 7.0, n))
+    climb = np.where(thrower, -rng.uniform(3.0, 9.0, n), rng.uniform(0.3, 1.0, n))
     x, s, u, ui = flying_batch(fb, oracle, n, 97, lat, lon, h_e, climb, {})
     s = s.copy(); ui = ui.copy()
     flagged = rng.random(n) < 0.5
@@ -401,7 +403,7 @@ def test_x2_survivors_sharing_a_wave_with_a_thrower_keep_their_actuators(fb, ora
     K = fb.K
     n = 2048
     rng = np.random.default_rng(101)
-    N0 = geoid(oracle, np.zeros(1), np.zeros(1))[0]
+    assert geoid(oracle, np.array([0.05]), np.array([1.38]))[0] < -50
     tp = fb.TrimParameters(EAS=rng.uniform(42.0, 55.0, n), h_e=1000.0, ψ_nb=rng.uniform(-np.pi, np.pi, n))
     w = fb.Cessna172Xv2World(n, gains=gains)
     w.set_params(h_terrain=-5000.0)
@@ -413,13 +415,13 @@ def test_x2_survivors_sharing_a_wave_with_a_thrower_keep_their_actuators(fb, ora
     xw = w.x
     he_row = int(np.where(perm == 20)[0][0])
     qew_rows = [int(np.where(perm == 16 + k)[0][0]) for k in range(4)]
-    xw[qew_rows] = q_ew_from_latlon(np.zeros(n), np.zeros(n))
-    xw[he_row] = -1000.0 + N0 + np.where(thrower, rng.uniform(0.3, 5.0, n), rng.uniform(2.0, 6.0, n))
+    xw[qew_rows] = q_ew_from_latlon(np.full(n, 0.05), np.full(n, 1.38))      # geoid ~100 m below the ellipsoid: h_e reaches h_min first
+    xw[he_row] = -1000.0 + np.where(thrower, rng.uniform(2.5, 7.0, n), rng.uniform(4.0, 8.0, n))   # (within 10 m of it: the ground-capable pass)
     w.x = xw
     cu = w.cu
     cu[K["FB_CU_LON_MODE_REQ"]] = float(fb.ModeControlLon.EAS_clm)
     cu[K["FB_CU_LAT_MODE_REQ"]] = float(fb.ModeControlLat.φ_β)
-    cu[K["FB_CU_CLM_REF"]] = np.where(thrower, -rng.uniform(5.0, 12.0, n), rng.uniform(1.0, 3.0, n))
+    cu[K["FB_CU_CLM_REF"]] = np.where(thrower, -rng.uniform(5.0, 12.0, n), rng.uniform(0.3, 1.0, n))
     cu[K["FB_CU_PHI_REF"]] = rng.uniform(-0.3, 0.3, n)            # the lateral channel moves aileron and rudder too
     w.cu = cu
     uu = w.u
@@ -432,8 +434,8 @@ def test_x2_survivors_sharing_a_wave_with_a_thrower_keep_their_actuators(fb, ora
     o["cu"] = np.ascontiguousarray(cu.copy())
     o["x"][perm] = w.x; o["cs"] = w.cs; o["u"] = w.u; o["ui"] = w.ui; o["s"] = w.s
     act0 = o["x"][27:34].copy()
-    fb.step(sim, 3.0); w.sync()
-    X.step_term(o, env, 0.01, 2, 300)
+    fb.step(sim, 2.0); w.sync()
+    X.step_term(o, env, 0.01, 2, 200)
     st, sto = w.status, o["status"]
     term = sto != 0
     print("Xv2 through the altitude floor:", int(term.sum()), "of", n, "ended; places", np.unique(o["term_where"][term]))
