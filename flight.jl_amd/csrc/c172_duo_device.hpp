@@ -61,6 +61,8 @@ enum { DUO_PT_T = 0, DUO_PT_V = 1, DUO_PT_X = 2,    // role D: top of the loop; 
        DUO_NPT = 3 };
 constexpr int XD_FP = 0, XD_TAUP = 3, XD_HROT = 6, XD_RHO = 7, XD_HO = 8, XD_ROWS = 9;   // exchange rows (0-5 overlaid, see above)
 constexpr int XD_VP = XD_FP;   // role D -> role P before barrier A: the velocity at the propeller, in the rows that carry F_p after it
+// rows of KArgs::duo_tap a tapped evaluation of the Cessna172Xv2 instance writes (the DUO_TAP_* enum of c172_kernels.hpp, which checks these)
+constexpr int DUO_TAP_THETA_ROW = 0, DUO_TAP_WX_ROW = 2, DUO_TAP_VD_ROW = 5, DUO_TAP_EAS_ROW = 7, DUO_TAP_ALPHA_ROW = 8, DUO_TAP_LAT_ROW = 10;
 
 template <int KIN, int ROLE, class In, class Emit, class XV>
 __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state, const In& in, const Env& env, const Tables& T, const Emit& emit, StepAux& aux) {
@@ -69,6 +71,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
     static_assert(KIN == FB_KIN_WA || KIN == FB_KIN_ECEF || KIN == FB_KIN_NED, "kinematic mechanisation");
     int32_t st = 0;
     constexpr int KX = FB_X_Q_WB;
+    constexpr bool X = Emit::x2;   // Cessna172Xv2 (k_step_duo<KIN, true>): see the kernel's header
     auto gkp = [&](int off) -> gk_cptr { return T.gk + off; };
     auto atan2m = [&](double y, double x0) -> double { return atan2_step(y, x0, T.rk + LDS_ATAN); };
     auto atan2p = [&](double y, double x0) -> double { return atan2_step<true>(y, x0, T.rk + LDS_ATAN); };   // x0 >= 0, not both zero
@@ -122,6 +125,12 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         const double N_geoid = geoid_height<true>(T, n_e, lat, lon);
         const double h_o = h_e - N_geoid;
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
+        if constexpr (X) {
+            if (emit.tap) {   // kinematics.y.ϕ_λ as the guidance reads it (rhs(): the states themselves in the NED mechanisation)
+                const double ll[2] = {KIN == FB_KIN_NED ? pos0 : lat, KIN == FB_KIN_NED ? pos1 : lon};
+                emit.template tap_rows<2>(DUO_TAP_LAT_ROW, ll);
+            }
+        }
         // ----- air data (atmosphere.jl:220-242) -----
         DUO_MARK(1, 1);   // geoid done
         double T_air, p_air, lnp_air;
@@ -271,7 +280,7 @@ DUO_MARK(1, 6);   // engine head done
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
-        in.fetch_aero(ac);
+        if constexpr (!X) in.fetch_aero(ac);   // (launch constants; Cessna172Xv2: this evaluation's, behind role P's point R below)
         double alpha = 0, beta = 0, cos_al = 1, sin_al = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
             const double r2 = v_wb_b.x * v_wb_b.x + v_wb_b.z * v_wb_b.z;
@@ -282,6 +291,7 @@ DUO_MARK(1, 6);   // engine head done
             if (r_ok) { cos_al = v_wb_b.x * ir; sin_al = v_wb_b.z * ir; }   // cos, sin of atan2(z, x) (atan2(0, 0) = 0)
         }
         DUO_MARK(2, 2);   // airflow angles
+        if constexpr (X) { if (emit.tap) { const double ab[2] = {alpha, beta}; emit.template tap_rows<2>(DUO_TAP_ALPHA_ROW, ab); } }
         const double V = fmax(TAS, V_min);
         const double afd = 1 / tau_filt * (alpha - x[FB_X_ALPHA_FILT]);
         const double bfd = 1 / tau_filt * (beta - x[FB_X_BETA_FILT]);
@@ -290,6 +300,12 @@ DUO_MARK(1, 6);   // engine head done
         const double i2V = 1 / (2 * V);
         const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
         const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
+        if constexpr (X) {
+            // Cessna172Xv2: role P has formed this evaluation's deflection-only sums ahead of its point R (which releases global memory there):
+            // the fetch is in flight while the knots are located
+            emit.xwait(DUO_PT_R);
+            in.fetch_aero(ac);
+        }
         const loc l_al26 = grid_locate<26, true, AUX_AL26>(A + AT_CD_ALPHA_K, RA + AT_CD_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CD_ALPHA_K), T.gk);
         const loc l_al17 = grid_locate<17, true, AUX_AL17>(A + AT_CL_ALPHA_K, RA + AT_CL_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CL_ALPHA_K), T.gk);
         const loc l_al2 = grid_locate<2, true>(A + AT_ALPHA2_K, RA + AT_ALPHA2_K, al, true, true, gkp(LDS_AERO + AT_ALPHA2_K));
@@ -305,7 +321,7 @@ DUO_MARK(1, 6);   // engine head done
         const double cl_al = lerp2(A + AT_CL_ALPHA_V, 17, l_al17, l_stall) + ac.cl_df;
         const double cl_r = lerp2(A + AT_CL_R_V, 2, l_al2, l_df2);
         DUO_MARK(2, 4);   // lookups done
-        emit.xwait(DUO_PT_R);   // ----- role P's point R: it has read q_ew, h_e (the kinematics rows may be rewritten) and finished its previous
+        if constexpr (!X) emit.xwait(DUO_PT_R);   // ----- role P's point R: it has read q_ew, h_e (the kinematics rows may be rewritten) and finished its previous
                                 // evaluation (the fuel row, which it emits last of all, is there; it will not emit it again before this wave's X) -----
         const double x_fuel = x[FB_X_FUEL];
         DUO_MARK(2, 5);   // past R
@@ -320,6 +336,23 @@ DUO_MARK(1, 6);   // engine head done
         const v3 v_eb_n = qrot(q_nb, v_eb_b);
         const v3 w_ew_n = {v_eb_n.y * i_RE, -v_eb_n.x * i_RN, 0.0};
         v3 w_wb_b;
+        if constexpr (X) {
+            if (emit.tap) {
+                // kinematics.y as the control laws read it (rhs(), WITH_Y; attitude.jl:382-391): theta, phi, the ground track angle, the NED velocity's
+                // down component — ahead of the emits below, which rewrite the rows the NED mechanisation's angles are read from
+                double tp[2];
+                if constexpr (KIN == FB_KIN_NED) { tp[0] = x[KX + 1]; tp[1] = x[KX + 2]; }
+                else {
+                    const double q1 = q_nb.w, q2 = q_nb.x, q3 = q_nb.y, q4 = q_nb.z;
+                    tp[0] = asin(fmin(fmax(2 * (q1 * q3 - q2 * q4), -1.0), 1.0));
+                    tp[1] = atan2m(2 * (q1 * q2 + q3 * q4), 1 - 2 * (q2 * q2 + q3 * q3));
+                }
+                const bool chi_ok = KIN == FB_KIN_NED || norm(v_eb_n) > 0.1;   // the NED mechanisation has no low-speed guard (kinematics.jl:395-396)
+                const double vc[2] = {v_eb_n.z, chi_ok ? atan2m(v_eb_n.y, v_eb_n.x) : 0.0};
+                emit.template tap_rows<2>(DUO_TAP_THETA_ROW, tp);
+                emit.template tap_rows<2>(DUO_TAP_VD_ROW, vc);
+            }
+        }
         if constexpr (KIN == FB_KIN_ECEF) {   // kinematics.jl:282-320
             w_wb_b = w_eb_b - qrot_inv(q_nb, w_ew_n);
             const quat a = qmul(q_eb, quat{0.0, w_eb_b.x, w_eb_b.y, w_eb_b.z});   // Attitude.dt(q_eb, ω_eb_b)
@@ -357,6 +390,7 @@ DUO_MARK(1, 6);   // engine head done
             emit_rows<4>(emit, KX, kq1);
             emit_rows<5>(emit, KX + 4, kq2);
         }
+        if constexpr (X) { if (emit.tap) { const double w3[3] = {w_wb_b.x, w_wb_b.y, w_wb_b.z}; emit.template tap_rows<3>(DUO_TAP_WX_ROW, w3); } }
         DUO_MARK(2, 6);   // kinematics rows emitted
         // ----- fuel mass, mass properties, gravity at the CoM -----
         const double m_fuel_total = m_res + x_fuel * (m_full - m_res);
@@ -378,6 +412,7 @@ DUO_MARK(1, 6);   // engine head done
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         if (!(h_o * wgs::a < 84852.0 * (wgs::a + h_o))) st |= FB_ST_ISA_RANGE;   // geopotential altitude h a / (a + h) beyond the last ISA layer
         const double q_dyn = 0.5 * rho * (TAS * TAS);
+        if constexpr (X) { if (emit.tap) { const double e1[1] = {TAS * sqrt(rho / isa::rho_std)}; emit.template tap_rows<1>(DUO_TAP_EAS_ROW, e1); } }   // air.y.EAS (rhs(), atmosphere.jl:239)
         const double p_nd = w_wb_b.x * b * i2V, q_nd = w_wb_b.y * c * i2V, r_nd = w_wb_b.z * b * i2V;
         const double dh_nd = (h_o - env.h_trn) / b;
         const loc l_ge = grid_locate<13, true, AUX_GE>(A + AT_GE_K, RA + AT_GE_K, dh_nd, true, true, gkp(LDS_AERO + AT_GE_K), T.gk);

@@ -224,6 +224,8 @@ struct KArgs {
     double* ctl_bak;      // [(FB_NCS + FB_NCU) x n] the airborne pass's copy of cs | cu at launch start (restored for lanes it hands over)
     double* duo_pld;      // [DUO_NCONST x n] k_step_duo: per-aircraft constants of the launch (the deflection-only aerodynamic terms),
                           // written by its prologue and fetched at the start of every evaluation's aerodynamics block
+                          // (Cessna172Xv2: of the EVALUATION — role P forms them from the actuators' stage positions and hands them over here)
+    double* duo_tap;      // [DUO_NTAP x n] k_step_duo<KIN, true>: what the two halves of a control update hand each other (DUO_TAP_*)
     // the termination record (fb_get_termination): written once, when an aircraft's simulation ends
     long long* term_step; // [n] RK updates completed since the last init when the exception was thrown
     int32_t* term_where;  // [n] FB_TERM_*
@@ -233,6 +235,16 @@ struct KArgs {
 // (altitude below h_min: FP/kinematics.jl:190,199 -> geodesy.jl:218-221; ISA range: atmosphere.jl:133), the struts after them
 // (landinggear.jl:240, 321), the centre of mass last (dynamics.jl:477-486). (A strut's assertion ahead of a LATER strut's altitude
 // error is not told apart: both need the wheels on the ground AND below h_min.)
+// The kernel's own argument block, re-read where it is needed: a stepping kernel that keeps a dozen of its arguments in SGPRs across its
+// loop for something that happens once per control period (the arguments of a control update, the base of the tap rows) pays for them
+// with SGPR spills inside the loop. kernarg() returns the kernarg segment — KArgs is the first parameter of every stepping kernel — through
+// an opaque copy, so that loads through it are issued where they stand (scalar loads, one exposed round trip per use).
+typedef __attribute__((address_space(4))) const KArgs* kargs_cptr;
+FBD kargs_cptr kernarg() {
+    kargs_cptr p = (kargs_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 // A status bit raised outside fb_step (the single-call verbs): the record says so, with the step count of the moment — unless the
 // aircraft already carries a record (fb_get_termination promises a valid step and place next to every termination bit)
 FBD void mark_outside_step(int32_t* status, long long* term_step, int32_t* term_where, long long step0, int64_t i, int32_t st) {
@@ -909,6 +921,113 @@ restart:
     a.s[a.n + i] = eng;
 }
 
+// ---- the same update in two halves, for the wave-specialised stepper (k_step_duo<KIN, true>) ---------------------------------------
+// Two waves serve an aircraft there, and an update on ONE of them is a 36 k-cycle dependent chain (profiles/r03_x2_update_stamps.txt) with
+// the other idle. The longitudinal laws (c172x_ctl.jl:286-446: throttle, elevator) and the lateral ones (:880-983: aileron, rudder) are
+// independent once the guidance has run, so role P's wave runs x2_periodic_lon and role D's x2_periodic_lat, side by side. What they read
+// of vehicle.y was tapped from the step's last f_ode! by BOTH roles (each the outputs its own part of the evaluation forms) into the rows
+// of KArgs::duo_tap; each half runs the guidance for itself (CtlMemHalfT says who writes what to memory). Same arguments-in-registers
+// discipline as x2_periodic; the state rows a half needs it reads from the x_n panel in LDS (x_{n+1}, before f_step! touches it).
+enum { DUO_TAP_THETA = 0, DUO_TAP_PHI, DUO_TAP_WX, DUO_TAP_WY, DUO_TAP_WZ, DUO_TAP_VD, DUO_TAP_CHI, DUO_TAP_EAS, DUO_TAP_ALPHA, DUO_TAP_BETA,   // role D's
+       DUO_TAP_LAT, DUO_TAP_LON, DUO_TAP_POS, DUO_TAP_CMD = DUO_TAP_POS + 4, DUO_NTAP = DUO_TAP_CMD + 4 };                                  // role P's
+static_assert(DUO_TAP_THETA == DUO_TAP_THETA_ROW && DUO_TAP_PHI == DUO_TAP_THETA_ROW + 1 && DUO_TAP_WX == DUO_TAP_WX_ROW && DUO_TAP_WZ == DUO_TAP_WX_ROW + 2 &&
+              DUO_TAP_VD == DUO_TAP_VD_ROW && DUO_TAP_CHI == DUO_TAP_VD_ROW + 1 && DUO_TAP_EAS == DUO_TAP_EAS_ROW && DUO_TAP_ALPHA == DUO_TAP_ALPHA_ROW &&
+              DUO_TAP_BETA == DUO_TAP_ALPHA_ROW + 1 && DUO_TAP_LAT == DUO_TAP_LAT_ROW && DUO_TAP_LON == DUO_TAP_LAT_ROW + 1, "rhs_duo's tap rows");
+struct Ctl2 { double c0, c1; };
+struct CtlHalfArgs {   // (unpacked from the scalar arguments inside the callee: see x2_periodic)
+    const double* cu; double* cs; const double* gains; const double* tap;
+    int64_t n; double dT; CtlOffsets off;
+};
+FBD CtlHalfArgs ctl_half_args(const double* a_cu, double* a_cs, const double* a_gains, const double* a_tap, int64_t a_n, double a_dT, uint32_t o01, uint32_t o23,
+                              uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg) {
+    CtlHalfArgs h;
+    h.cu = uni(a_cu); h.cs = uni(a_cs); h.gains = uni(a_gains); h.tap = uni(a_tap); h.n = uni(a_n); h.dT = uni(a_dT);
+    const uint32_t op[5] = {o01, o23, o45, o67, o89};
+#pragma unroll
+    for (int k = 0; k < 10; k++) h.off.off[k] = uni((int)((op[k / 2] >> (16 * (k % 2))) & 0xffffu));
+    h.off.total = uni((int)(tsg & 0xffffu));
+    h.off.same_grid = uni((int)(tsg >> 16));
+    return h;
+}
+#ifdef FB_STAMP
+// diagnostic builds (tools/stamp_x2_duo.py): per-phase cycles of the two halves of an update, wave 0 (longitudinal, slots 21-25 + ctl_lon's 27-29)
+// and wave 4 (lateral, slots 16-20) of workgroup 0
+__device__ unsigned long long g_half_last[2];
+template <int HALF> __device__ __forceinline__ void half_stamp(int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 255) == 0) {
+            if (k >= 0) { g_stamp_acc[k] += t - g_half_last[HALF - 1]; g_stamp_cnt[k] += 1; }
+            g_half_last[HALF - 1] = __builtin_amdgcn_s_memtime();
+            if (HALF == CTL_HALF_LON) g_stamp_last = g_half_last[0];   // (ctl_lon's own fences measure from here)
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define FB_HALF_STAMP(HALF, k) half_stamp<HALF>(k)
+#else
+#define FB_HALF_STAMP(HALF, k) do { } while (0)
+#endif
+// xs: &x_n panel[lane] of the calling workgroup (rows of DUO_B lanes, the airborne row numbering); h_e: the mechanisation's altitude state
+template <int HALF>
+__device__ __noinline__ Ctl2 x2_periodic_half(const double* a_cu, double* a_cs, const double* a_gains, const double* a_tap, int64_t a_n, double a_dT, uint32_t o01,
+                                              uint32_t o23, uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, double h_e, lds_cptr xs) {
+    constexpr int B = 256;   // (= DUO_B, defined below)
+    using SV = StateLds<B, false>;
+    FB_HALF_STAMP(HALF, -1);
+    const CtlHalfArgs A = ctl_half_args(a_cu, a_cs, a_gains, a_tap, a_n, a_dT, o01, o23, o45, o67, o89, tsg);
+    const int64_t n = A.n;
+    typedef __attribute__((address_space(1))) double* gptr;
+    typedef ctlg_cptr gcptr;
+    double lu[FB_NCU];
+    const gcptr t0 = (gcptr)(uintptr_t)A.tap + i;
+    auto TAP = [&](int k) { return t0[(int64_t)k * n]; };
+    auto XS = [&](int k) { return xs[SV::row(k) * B]; };
+    CtlIn v;
+    {   // one burst: the tapped outputs and the input rows in flight together (the compiler drops the rows this half never reads)
+        const gcptr u0 = (gcptr)(uintptr_t)A.cu + i;
+        v.lat = TAP(DUO_TAP_LAT); v.lon = TAP(DUO_TAP_LON); v.EAS = TAP(DUO_TAP_EAS); v.phi = TAP(DUO_TAP_PHI);
+        if constexpr (HALF == CTL_HALF_LON) {
+            v.theta = TAP(DUO_TAP_THETA); v.clm = -TAP(DUO_TAP_VD); v.alpha = TAP(DUO_TAP_ALPHA);
+            v.w_wb_b = {0.0, TAP(DUO_TAP_WY), TAP(DUO_TAP_WZ)};
+            v.pos[0] = TAP(DUO_TAP_POS + 0); v.pos[2] = TAP(DUO_TAP_POS + 2); v.cmd[0] = TAP(DUO_TAP_CMD + 0); v.cmd[2] = TAP(DUO_TAP_CMD + 2);
+            v.pos[1] = v.pos[3] = v.cmd[1] = v.cmd[3] = 0; v.chi = 0; v.beta = 0;
+        } else {
+            v.chi = TAP(DUO_TAP_CHI); v.beta = TAP(DUO_TAP_BETA);
+            v.w_wb_b = {TAP(DUO_TAP_WX), 0.0, 0.0};
+            v.pos[1] = TAP(DUO_TAP_POS + 1); v.pos[3] = TAP(DUO_TAP_POS + 3); v.cmd[1] = TAP(DUO_TAP_CMD + 1); v.cmd[3] = TAP(DUO_TAP_CMD + 3);
+            v.pos[0] = v.pos[2] = v.cmd[0] = v.cmd[2] = 0; v.theta = 0; v.clm = 0; v.alpha = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < FB_NCU; k++) lu[k] = u0[(int64_t)k * n];
+    }
+    v.h_e = h_e;
+    v.w_eb_b = {XS(FB_X_OMEGA_EB_B), XS(FB_X_OMEGA_EB_B + 1), XS(FB_X_OMEGA_EB_B + 2)};
+    v.alpha_filt = XS(FB_X_ALPHA_FILT); v.beta_filt = XS(FB_X_BETA_FILT);
+    v.n_eng = XS(FB_X_ENG_OMEGA) / c172::w_rated;
+    v.on_gnd = false;   // (the airborne pass: no strut has weight on its wheel)
+    const CtlMemHalfT<gptr, HALF> M = {(gptr)(uintptr_t)A.cu + i, (gptr)(uintptr_t)A.cs + i, n, lu};
+    FB_HALF_STAMP(HALF, HALF == CTL_HALF_LON ? 22 : 16);   // entry, arguments, the burst of loads
+    gdc_update(M, v);
+    FB_HALF_STAMP(HALF, HALF == CTL_HALF_LON ? 23 : 17);   // guidance
+    const CtlTabT<gcptr> tab = ctl_tab((gcptr)(uintptr_t)A.gains, A.off, v.EAS, v.h_e);
+    if constexpr (HALF == CTL_HALF_LON) {
+        ctl_lon<true>(tab, M, A.dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
+        FB_HALF_STAMP(HALF, 24);   // (behind ctl_lon's fence 29: the LQR run and the stores)
+        return {clampd(M.S(FB_CS_THROTTLE_CMD), 0, 1), clampd(M.S(FB_CS_ELEVATOR_CMD), -1, 1)};
+    } else {
+        const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
+        LatGains G;   // (not read: the gains are taken where they are used)
+        G.P = {0, 0, 0, 0};
+        ctl_lat<true>(tab, M, A.dT, v, lat_req, G);
+        FB_HALF_STAMP(HALF, 19);   // lateral laws
+        return {clampd(M.S(FB_CS_AILERON_CMD), -1, 1), clampd(M.S(FB_CS_RUDDER_CMD), -1, 1)};
+    }
+}
+
 // ---- the wave-specialised airborne stepper (Cessna172Sv0) --------------------------------------------------------------------------
 // k_step_air is bound by what ONE wave per SIMD can issue: its 151 KB of LDS panels and ~400 registers leave room for no second
 // wave, every instruction costs the lone wave ~4.3 cycles and nothing hides an LDS round trip. k_step_duo serves the
@@ -1000,12 +1119,19 @@ struct DuoSync {
 #ifndef FB_DUO_RELEASE_WAIT
 #define FB_DUO_RELEASE_WAIT 1
 #endif
+// GLOBAL: the release also covers this wave's global-memory traffic (vmcnt(0): the Cessna172Xv2 instance hands values over through global
+// memory too — the evaluation's aerodynamic sums, the tapped outputs of a control update; the two waves of a pair share their CU's vector
+// L1, so a workgroup-scope release / acquire needs no cache maintenance).
+template <bool GLOBAL = false>
 FBD void duo_publish(DuoSync& sy, int k) {
+    if constexpr (GLOBAL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else {
 #if FB_DUO_RELEASE_WAIT
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and, for the compiler: every LDS access above stays above ...)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (and, for the compiler: every LDS access above stays above ...)
 #else
-    asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above ...)
+        asm volatile("" ::: "memory");   // (compiler: every LDS access above stays above ...)
 #endif
+    }
     *sy.mine = sy.base + k + 1;
     asm volatile("" ::: "memory");   // (... and every one below stays below)
 }
@@ -1042,9 +1168,11 @@ FBD void duo_wait(DuoSync& sy, int k) {
 #endif
 }
 
-template <int ROLE>
+template <int ROLE, bool X = false>
 struct DuoEmit {
     static constexpr int role = ROLE;
+    static constexpr bool x2 = X;   // the Cessna172Xv2 instance: role D fetches the evaluation's aerodynamic sums behind role P's point R, every publication
+                                    // releases global memory too, and a tapped evaluation (`tap`) stores the control laws' inputs to rows of KArgs::duo_tap
     typedef void batched_tag;
     using SV = StateLds<DUO_B, false>;
     lds_cptr xs_l;     // x_n panel
@@ -1057,6 +1185,17 @@ struct DuoEmit {
     bool last;
     int t;
     DuoSync* sync;     // this wave's side of the pair's synchronisation counters
+    bool tap;          // wave-uniform (Cessna172Xv2): this is the step's last f_ode! and a control update follows it
+    int64_t ai;        // the lane's aircraft
+    // rows k0 .. k0 + N - 1 of KArgs::duo_tap (base and stride re-read from the kernel's arguments: once per control period, see kernarg())
+    template <int N>
+    __device__ __forceinline__ void tap_rows(int k0, const double (&v)[N]) const {
+        const kargs_cptr ka = kernarg();
+        double* const g = ka->duo_tap + ai;
+        const int64_t n = ka->n;
+#pragma unroll
+        for (int e = 0; e < N; e++) g[(int64_t)(k0 + e) * n] = v[e];
+    }
     // panel rows: 0-1 filters (D), 2 fuel, 3-5 engine (P), 6-14 q_wb q_ew h_e (D), 15-20 angular and linear velocity (D)
     __device__ __forceinline__ static constexpr bool owned(int j) {
         if (SV::skip(j)) return false;
@@ -1096,7 +1235,7 @@ struct DuoEmit {
     }
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
-    __device__ __forceinline__ void xpub(int k) const { duo_publish(*sync, k); }
+    __device__ __forceinline__ void xpub(int k) const { duo_publish<X>(*sync, k); }
     __device__ __forceinline__ void xwait(int k) const { duo_wait(*sync, k); }
 };
 // every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
@@ -1115,11 +1254,29 @@ constexpr bool duo_rows_ok() {
 static_assert(duo_rows_ok(), "k_step_duo: row ownership / stage-sum slots");
 static_assert(DuoEmit<1>::owned(FB_X_FUEL) && DuoEmit<1>::owned(FB_X_ENG_OMEGA) && DuoEmit<2>::owned(FB_X_Q_WB) && DuoEmit<2>::owned(FB_X_V_EB_B + 2),
               "rhs_duo emits the engine and fuel rows in role P, everything else in role D");
-enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2 };   // per-lane flag word
-enum { DUO_C_EXIT = 4 };                                            // per-pair control word: stage | EXIT
-template <int KIN>
+enum { DUO_F_RUN = 1, DUO_F_ZERO_ACC = 2, DUO_F_ENG_SHIFT = 2, DUO_F_CTL = 16 };   // per-lane flag word (CTL: this lane takes part in the control update that follows)
+enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair control word: stage | EXIT | TAP (this evaluation is tapped) | CMD (new lateral commands put)
+// Cessna172Xv2 (X = true; configs[3]): the same pair of waves, and
+//   * the five actuators the airborne evaluation reads (throttle, aileron, elevator, rudder, flaps: closed-form RK4, see k_step_air) ride in
+//     role P's registers — it has ~85 to spare, role D none. Role P forms the throttle position for its engine and, at the head of every
+//     evaluation, the deflection-only aerodynamic sums of that stage's surface positions (InputsAgg::sum_aero, ~100 instructions that role
+//     D's critical path does not pay), and hands them to role D through the rows of KArgs::duo_pld — the rows role D fetches its launch
+//     constants from in the Sv0 instance; role D fetches them behind role P's point R (which therefore releases global memory too);
+//   * f_periodic!(avionics, vehicle) runs inside the launch like in k_step_air, in two halves side by side: the step's last f_ode! is TAPPED
+//     by both roles (each stores the outputs its part of the evaluation forms to the rows of KArgs::duo_tap), role D keeps the book as
+//     always (f_step!, then flags with DUO_F_CTL for the lanes that take part) and publishes a fourth point U; then role P's wave runs the
+//     longitudinal laws and role D's the lateral ones (x2_periodic_half). Role P keeps its two new commands, role D puts its two into the
+//     exchange rows that carry density and altitude during an evaluation (DUO_C_CMD); role P publishes F when its half is done, which role
+//     D waits for before the next evaluation's T (so the record's rows are at rest whenever an evaluation runs, and when a lane's record is
+//     put back from ctl_bak at the end). Callback order as in the reference: cb_step, then cb_periodic (FC/sim.jl:204-218).
+//   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
+//     stepped here, the ground-capable pass evaluates its own.
+constexpr int DUO_PT_U = 3, DUO_PT_F = 3;   // role D: flags of the update written; role P: its half of the update done
+template <int KIN, bool X = false>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
+    constexpr int NPT = X ? DUO_NPT + 1 : DUO_NPT;   // points per iteration of the evaluation loop
+    constexpr int NAL = FB_ACT_BRAKE_LEFT;           // actuators the airborne evaluation reads
     using SV = StateLds<B, false>;
     __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs_duo())
     __shared__ double rk[LDS_RK_DOUBLES];
@@ -1161,23 +1318,55 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                   (volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? 4 + pair : pair)), 0, 0};
     const bool valid = i < a.n && a.status[i] == 0;
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    // role D's per-lane bookkeeping word, kept in LDS between evaluations (role P reads it once, when the launch is over)
+    enum { D_ALIVE = 1, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };   // (no lane ends its simulation here: a status bit is a hand-over)
     // what an evaluation at stage `stg` needs (wave-uniform)
     struct StageK { bool last; double eb, ee, em; lds_cptr xrd_l; lds_ptr xwr_l; };
     auto stage_k = [&](int stg) {
         StageK k;
         k.last = stg == 3;
-        k.eb = (stg == 1 || stg == 2) ? 2.0 : 1.0; k.ee = k.last ? dt6 : (stg == 2 ? dt : hdt); k.em = k.last ? 0.0 : 1.0;
+        if constexpr (X) {
+            // (formed here from an opaque copy of dt: as loop invariants in VGPRs, dt / 2 and dt / 6 are what the Cessna172Xv2 instance's
+            // allocation spills — and reloads in every evaluation)
+            double dtl = a.dt;
+            asm volatile("" : "+s"(dtl));
+            k.eb = (stg == 1 || stg == 2) ? 2.0 : 1.0; k.ee = k.last ? dtl / 6 : (stg == 2 ? dtl : dtl / 2); k.em = k.last ? 0.0 : 1.0;
+        } else {
+            k.eb = (stg == 1 || stg == 2) ? 2.0 : 1.0; k.ee = k.last ? dt6 : (stg == 2 ? dt : hdt); k.em = k.last ? 0.0 : 1.0;
+        }
         // panel roles: stage 0 evaluates x_n straight from xs_l, stages 1-3 the state the previous stage left in xc_l; stages 0-2
         // write the next evaluation state to xc_l, stage 3 the new x_n to xs_l
         k.xrd_l = stg == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
         k.xwr_l = k.last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         return k;
     };
+    // one half of a control update (the arguments re-read from the kernel's argument block where the call stands: kernarg())
+    [[maybe_unused]] auto ctl_half = [&](auto half, int64_t lane) {
+        const kargs_cptr ka = kernarg();
+        auto pk = [&](int k) { return (uint32_t)ka->ctl_off.off[k] | ((uint32_t)ka->ctl_off.off[k + 1] << 16); };
+        return x2_periodic_half<decltype(half)::value>(ka->cu, ka->cs, ka->gains, ka->duo_tap, ka->n, ka->ctl_dT, pk(0), pk(2), pk(4), pk(6), pk(8),
+                                                       (uint32_t)ka->ctl_off.total | ((uint32_t)ka->ctl_off.same_grid << 16), lane,
+                                                       xs_l[SV::row(h_e_row<KIN>()) * B + t], (lds_cptr)xs_l + t);
+    };
     if (role == 1) {
         // ================= role P =================
         InputsDuoP in;
         in.throttle = 0; in.mixture = 0; in.ui = 0;
-        if (valid) {
+        [[maybe_unused]] double xa[X ? NAL : 1], ca[X ? NAL : 1];   // Cessna172Xv2: actuator positions x_n and the commands in force
+        if constexpr (X) {
+#pragma unroll
+            for (int k = 0; k < NAL; k++) { xa[k] = 0; ca[k] = 0; }
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+                in.mixture = clampd(a.u[(int64_t)FB_U_MIXTURE * a.n + i], 0, 1);
+                in.ui = a.ui[i];
+                if (a.ctl_ratio > 0) {   // its half of the launch-start copy of the control-law record (role D copies cu)
+#pragma unroll 1
+                    for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
+                }
+            }
+        } else if (valid) {
             Inputs in0;
             load_inputs(a, i, in0);
             in.throttle = in0.throttle; in.mixture = in0.mixture; in.ui = in0.ui;
@@ -1187,6 +1376,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
+        [[maybe_unused]] const double z0 = dt / ACT_TAU;
 #pragma unroll 1
         while (true) {
             DUO_MARK(1, 15);  // (arrival at the top of the loop, counted from the previous evaluation's start)
@@ -1194,6 +1384,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             DUO_MARK(1, 0);
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
+            if constexpr (X) {
+                if (c & DUO_C_CMD) {   // the lateral half of the update that has just run has put its two commands (role D's wave, rows rho / h_o)
+                    if (f & DUO_F_CTL) { ca[FB_ACT_AILERON] = xch_l[(XD_RHO - 6) * B + t]; ca[FB_ACT_RUDDER] = xch_l[(XD_HO - 6) * B + t]; }
+                }
+            }
             if (c & DUO_C_EXIT) break;
             const bool run = f & DUO_F_RUN;
             const int eng = (f >> DUO_F_ENG_SHIFT) & 3;
@@ -1203,16 +1398,50 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll
                 for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
             }
-            const StageK sk = stage_k(c & 3);
+            const int stg = c & 3;
+            const StageK sk = stage_k(stg);
             int lds_off = 0;
             asm volatile("" : "+s"(lds_off));   // (see k_step_air: keeps the loop-invariant table / input loads from being hoisted into registers)
             const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
+            [[maybe_unused]] const bool tap = X && (c & DUO_C_TAP);
             if (__builtin_amdgcn_ballot_w64(run) != 0) {   // (the same in both waves of a pair)
                 if (run) {
                     StepAux aux;
                     InputsDuoP inl = in;
+                    if constexpr (X) {
+                        // the actuators' stage positions (closed-form RK4, see k_step_air) -> throttle for the engine; the deflection-only
+                        // aerodynamic sums of this stage's surface positions -> role D, through memory (it fetches them behind point R)
+                        double z = z0;
+                        asm volatile("" : "+v"(z));   // (opaque: the stage multipliers are formed here, not hoisted out of the loop into registers that then spill)
+                        const double ms = stg == 0 ? 1.0 : (stg == 1 ? 1 - z / 2 : (stg == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+                        double xa_s[FB_NACT];
+#pragma unroll
+                        for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                        xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
+                        const InputsX ix = {xa_s, nullptr, a.n, in.ui};
+                        inl.throttle = ix.get_throttle();
+                        InputsAgg ia;
+                        ia.de = ix.get_de(); ia.da = ix.get_da(); ia.dr = ix.get_dr(); ia.df = ix.get_df();
+                        ia.sum_aero((lds_cptr)lds + LDS_AERO + lds_off, (lds_cptr)rk + LDS_AERO + lds_off);
+                        const double ac[DUO_NCONST] = {ia.cd_in, ia.cd_df, ia.cy_in, ia.cl_in, ia.cl_df, ia.croll_in, ia.cm_in, ia.cn_in,
+                                                       (double)ia.l_df4.i, ia.l_df4.w, (double)ia.l_df2.i, ia.l_df2.w};
+                        int64_t il = i;
+                        asm volatile("" : "+v"(il));   // (opaque: the row addresses are formed here — hoisted, they are spilled and reloaded)
+                        double* const g = a.duo_pld + il;
+#pragma unroll
+                        for (int k = 0; k < DUO_NCONST; k++) g[(int64_t)k * a.n] = ac[k];
+                    }
+                    DUO_MARK(1, 12);   // (Cessna172Xv2: stage positions and aerodynamic sums formed and stored)
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
-                    const DuoEmit<1> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
+                    const DuoEmit<1, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
+                                                tap, i};
+                    if constexpr (X) {
+                        if (tap) {   // what the control laws read of the actuators: the Ranged positions of the state x_{n+1} (InputsX::pos), and the commands this f_ode! saw
+                            static_assert(DUO_TAP_CMD == DUO_TAP_POS + 4, "positions, then commands");
+                            const double pc[8] = {clampd(xa[0], 0.0, 1.0), clampd(xa[1], -1.0, 1.0), clampd(xa[2], -1.0, 1.0), clampd(xa[3], -1.0, 1.0), ca[0], ca[1], ca[2], ca[3]};
+                            emit.template tap_rows<8>(DUO_TAP_POS, pc);
+                        }
+                    }
                     const SV xv = {sk.xrd_l + t + lds_off};
 #if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 2
                     // timing diagnostic (tools/duo_alone.sh): role D alone on its SIMD — role P puts plausible constants and publishes its points
@@ -1228,9 +1457,48 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #else
                     rhs_duo<KIN, 1>(xv, 0, eng, inl, a.env, T, emit, aux);
 #endif
+                    if constexpr (X) {
+                        if (sk.last) {
+                            double z = z0;
+                            asm volatile("" : "+v"(z));
+                            const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
+#pragma unroll
+                            for (int k = 0; k < NAL; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * P;
+                        }
+                    }
                 }
-            } else duo_publish(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
-            sy.base += DUO_NPT;
+            } else duo_publish<X>(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
+            if constexpr (X) {
+                if (tap) {
+                    // f_periodic!(avionics, vehicle), the longitudinal half: role D has run f_step! on x_{n+1} and written the flags (DUO_F_CTL: the
+                    // lanes that take part — a lane its evaluation has just handed over does not)
+                    DUO_MARK(1, 13);   // arrives at U
+                    duo_wait(sy, DUO_PT_U);
+                    DUO_MARK(1, 14);   // past U
+                    const bool ctl = flags_l[t] & DUO_F_CTL;
+#ifdef FB_X2_SKIP_LON   // (timing diagnostics: one half of the update alone)
+                    if (false) {
+#else
+                    if (ctl) {
+#endif
+                        const Ctl2 co = ctl_half(std::integral_constant<int, CTL_HALF_LON>{}, i);
+                        ca[FB_ACT_THROTTLE] = co.c0; ca[FB_ACT_ELEVATOR] = co.c1;   // in force from the next stage on
+                    }
+                    DUO_MARK(1, 7);    // longitudinal half done
+                    duo_publish<true>(sy, DUO_PT_F);
+                }
+            }
+            sy.base += NPT;
+        }
+        if constexpr (X) {
+            // the actuator positions of the lanes this launch commits (role D's bookkeeping word says which: it is final behind the EXIT word)
+            const int d = dst_l[t];
+            if (valid && (d & D_ACTIVE) && !(d & D_HANDOFF)) {
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < NAL; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + i] = xa[k]; }
+                if (bad) atomicOr(&a.status[i], (int32_t)FB_ST_NAN);
+            }
         }
         // a wait of this role that ran into its bound (role D never arrived): the pair went on with a stale hand-over, so its aircraft
         // are flagged here too (role D flags them when ITS waits fail; atomics: both roles may write the word)
@@ -1240,7 +1508,6 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // ================= role D =================
     // The lane's bookkeeping state lives in an LDS word between evaluations (D_* bits): kept in registers it is what the allocator
     // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
-    enum { D_ALIVE = 1, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };   // (no lane ends its simulation here: a status bit is a hand-over)
     InputsDuoD in;
     in.pld_l = (lds_cptr)pld_l + t; in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
     {
@@ -1255,18 +1522,35 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             }
             if (to_ground) a.redo[i] = 1;
             stall = a.s[i]; eng = a.s[a.n + i];
-            InputsAgg in0;
-            load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO); in0.sum_payload();
-            pld_l[t] = in0.pld_M;
+            if constexpr (X) {
+                InputsXAgg in0;
+                in0.xa = nullptr; in0.u_glob = a.u + i; in0.n = a.n; in0.ui = a.ui[i];
+                sum_payload_of(in0);
+                pld_l[t] = in0.pld_M;
 #pragma unroll
-            for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
+                for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
-            const double ac[DUO_NCONST] = {in0.cd_in, in0.cd_df, in0.cy_in, in0.cl_in, in0.cl_df, in0.croll_in, in0.cm_in, in0.cn_in,
-                                           (double)in0.l_df4.i, in0.l_df4.w, (double)in0.l_df2.i, in0.l_df2.w};
+                for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
+                in.ui = in0.ui;
+                if (a.k1) a.k1_valid[i] = 0;   // (nothing is carried across launches here; the ground-capable pass evaluates its own k1)
+                if (a.ctl_ratio > 0 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
+#pragma unroll 1
+                    for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+                }
+            } else {
+                InputsAgg in0;
+                load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO); in0.sum_payload();
+                pld_l[t] = in0.pld_M;
 #pragma unroll
-            for (int k = 0; k < DUO_NCONST; k++) a.duo_pld[(int64_t)k * a.n + i] = ac[k];
-            in.ui = in0.ui;
+                for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
+                const double ac[DUO_NCONST] = {in0.cd_in, in0.cd_df, in0.cy_in, in0.cl_in, in0.cl_df, in0.croll_in, in0.cm_in, in0.cn_in,
+                                               (double)in0.l_df4.i, in0.l_df4.w, (double)in0.l_df2.i, in0.l_df2.w};
+#pragma unroll
+                for (int k = 0; k < DUO_NCONST; k++) a.duo_pld[(int64_t)k * a.n + i] = ac[k];
+                in.ui = in0.ui;
+            }
         }
 #pragma unroll
         for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;
@@ -1277,12 +1561,13 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // the wave-uniform stage machine (k_step_air's)
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false, exit_ = __builtin_amdgcn_ballot_w64(dst_l[t] & D_ALIVE) == 0;
+    [[maybe_unused]] bool tap_now = false, cmd_put = false;   // Cessna172Xv2: this evaluation is tapped / the update before it has put new lateral commands
     if ((threadIdx.x & 63) == 0) ctrl_l[pair] = exit_ ? DUO_C_EXIT : 0;
-    __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
+    if constexpr (!X) __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
-        duo_publish(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
+        duo_publish<X>(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
         DUO_MARK(2, 0);
         if (exit_) break;
         const StageK sk = stage_k(stage);
@@ -1298,7 +1583,13 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 const int d0 = dst_l[t];
                 InputsDuoD inl = in;
                 inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
-                const DuoEmit<2> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy};
+                if constexpr (X) {
+                    int64_t il = i;
+                    asm volatile("" : "+v"(il));   // (see role P)
+                    inl.aero_g = a.duo_pld + il;
+                }
+                const DuoEmit<2, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
+                                            tap_now, i};
                 const SV xv = {sk.xrd_l + t + lds_off};
 #if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 1
                 // timing diagnostic: role P alone on its SIMD — role D hands the velocity at the propeller over and waits
@@ -1309,15 +1600,16 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
 #endif
             }
-        } else duo_publish(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
+        } else duo_publish<X>(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
         // (f_step!, below, modifies x_{n+1} in place at the end of a step's last evaluation: role P has read what it reads of it — its
         // point R, which this wave has waited for in the evaluation)
-        sy.base += DUO_NPT;
         int d = dst_l[t];
         // within reach of the ground, or an exception (altitude / ISA range): nothing is committed for this lane, the ground-capable pass
         // steps it again from the launch-start state and ends its simulation where the reference would (see k_step_air, `tkey`)
         if (run && bits != 0) { d = (d | D_HANDOFF) & ~D_ALIVE; run = false; bits = 0; }
         bool zero_acc = false, advance = true;
+        [[maybe_unused]] const bool ctl_now = X && tap_now;   // this step closes a control period: f_periodic! follows its f_step! (FC/sim.jl:204-218)
+        [[maybe_unused]] const bool ctl_lane = ctl_now && run;   // (per lane: a lane handed over by this very evaluation gets no update — nothing of it is committed)
         if (redoing) { redoing = false; run = d & D_ALIVE; }   // the lanes that sat out the re-evaluation of k1 join again
         else if (stage == 0 && pending_cb) {
             // f_step! on x_{n+1}, which sits in xs_l (this evaluation's emits have already moved xc_l on to the next stage)
@@ -1365,13 +1657,55 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             pending_cb = (stage == 0);
         }
         dst_l[t] = d;
-        flags_l[t] = (run ? DUO_F_RUN : 0) | (zero_acc ? DUO_F_ZERO_ACC : 0) | (((d >> D_ENG_SHIFT) & 3) << DUO_F_ENG_SHIFT);
+        flags_l[t] = (run ? DUO_F_RUN : 0) | (zero_acc ? DUO_F_ZERO_ACC : 0) | (((d >> D_ENG_SHIFT) & 3) << DUO_F_ENG_SHIFT) | (ctl_lane ? DUO_F_CTL : 0);
+        if constexpr (X) {
+            cmd_put = false;
+            if (ctl_now) {
+                // f_periodic!(avionics, vehicle), the lateral half, on the outputs both roles tapped from the evaluation above (x_{n+1} as it was
+                // before f_step! renormalised the quaternions; the state rows the laws read — rates, filters, engine speed, altitude — f_step!
+                // does not touch). Role P's wave runs the longitudinal half meanwhile.
+                DUO_MARK(2, 12);   // f_step! done, flags written: at U
+                duo_publish<true>(sy, DUO_PT_U);
+#ifdef FB_X2_UPD_PRIO
+                __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO);
+#endif
+#ifdef FB_X2_SKIP_LAT
+                if (false) {
+#else
+                if (ctl_lane) {
+#endif
+                    const Ctl2 co = ctl_half(std::integral_constant<int, CTL_HALF_LAT>{}, i);
+                    xch_l[(XD_RHO - 6) * B + t] = co.c0; xch_l[(XD_HO - 6) * B + t] = co.c1;   // aileron, rudder commands -> role P (these rows are idle between evaluations)
+                }
+                cmd_put = true;
+                DUO_MARK(2, 13);   // lateral half done
+                duo_wait(sy, DUO_PT_F);   // role P's half is done: the record is at rest
+#ifdef FB_X2_UPD_PRIO
+                __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
+#endif
+                DUO_MARK(2, 14);   // past F
+            }
+            // the evaluation to come is the last f_ode! of a step that closes a control period?
+            tap_now = a.ctl_ratio > 0 && !exit_ && stage == 0 && pending_cb && !redoing && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;
+        }
         if ((threadIdx.x & 63) == 0)
-            ctrl_l[pair] = stage | (exit_ ? DUO_C_EXIT : 0);
+            ctrl_l[pair] = stage | (exit_ ? DUO_C_EXIT : 0) | (tap_now ? DUO_C_TAP : 0) | (cmd_put ? DUO_C_CMD : 0);
+        sy.base += NPT;
     }
     const int d = dst_l[t];
     if (!(d & D_ACTIVE)) return;
-    if (d & D_HANDOFF) { a.redo[i] = 1; return; }
+    if (d & D_HANDOFF) {
+        if constexpr (X) {
+            if (a.ctl_ratio > 0) {   // nothing of this lane's launch is committed: undo the control-law updates it has made (both halves are at rest: point F)
+#pragma unroll 1
+                for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
+#pragma unroll 1
+                for (int k = 0; k < FB_NCU; k++) const_cast<double*>(a.cu)[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i];
+            }
+        }
+        a.redo[i] = 1;
+        return;
+    }
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
@@ -1379,6 +1713,18 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         const double v = xs_l[SV::row(k) * B + t];
         bad = bad || !isfinite(v);
         a.x[(int64_t)k * a.n + i] = v;
+    }
+    if constexpr (X) {
+        // the two brake actuators, which the airborne evaluation never reads, over the steps this launch has completed (every committed lane: `step`)
+        const double z = dt / ACT_TAU, P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
+#pragma unroll
+        for (int k = NAL; k < FB_NACT; k++) {
+            const double c = x2_command(a, i, k), x0 = a.x[(int64_t)(X2_ACT + k) * a.n + i];
+            double v = x0;
+            for (int m = 0; m < step; m++) v = c + (v - c) * P;   // step by step: bit-identical to the per-step update
+            bad = bad || !isfinite(v);
+            a.x[(int64_t)(X2_ACT + k) * a.n + i] = v;
+        }
     }
     if (bad || __builtin_amdgcn_ballot_w64(sy.failed != 0) != 0) atomicOr(&a.status[i], (int32_t)FB_ST_NAN);   // (sy.failed: a synchronisation wait ran into its bound — the partner wave never arrived)
     a.s[i] = (d & D_STALL) ? 1 : 0;

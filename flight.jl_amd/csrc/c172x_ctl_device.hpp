@@ -110,6 +110,40 @@ struct CtlMemCachedT {
     FBD Ref U(int k) const { return {cu + (int64_t)k * n, lu + k}; }
     FBD Ref S(int k) const { return {cs + (int64_t)k * n, ls + k}; }
 };
+// The same cache for the two HALVES of an update that the wave-specialised stepper runs side by side (x2_periodic_lon on role P's wave,
+// x2_periodic_lat on role D's, c172_kernels.hpp): the longitudinal and the lateral laws (c172x_ctl.jl:286-446 / :880-983) share nothing but
+// the tapped vehicle outputs and the guidance's references, so each half runs the guidance for itself — a few hundred instructions, in
+// parallel — and keeps the output it needs (h_ref + the EAS_alt request / chi_ref + the chi_beta request) in its own cache; to MEMORY each
+// row is written by exactly one half: the guidance's record rows and its longitudinal outputs by the longitudinal half, its lateral
+// outputs by the lateral one. Row indices are compile-time constants after inlining, so `wr` folds.
+enum { CTL_HALF_LON = 1, CTL_HALF_LAT = 2 };
+// Registers: a half runs on a wave that shares its SIMD with its partner, i.e. in 256 registers — half of what x2_periodic has, whose cache of
+// all 94 rows is 188 of them. Only the INPUT rows (cu: a dozen per half, read-only but for the guidance's two outputs) are cached here; the
+// record's rows (cs) are read and written in memory where the laws use them. (With both cached the halves spilled ~50 values each to scratch
+// memory and every reload was an exposed ~1 k-cycle round trip: 75 k cycles for the longitudinal half, profiles/r04_x2_half_stamps.txt.)
+template <class P, int HALF>
+struct CtlMemHalfT {
+    P cu, cs;
+    int64_t n;
+    double* lu;        // the caller's local copy of the cu rows
+    static constexpr bool writes_u(int k) { return HALF == CTL_HALF_LON ? !(k == FB_CU_CHI_REF || k == FB_CU_LAT_MODE_REQ) : !(k == FB_CU_H_REF || k == FB_CU_LON_MODE_REQ); }
+    static constexpr bool writes_s(int k) { return HALF == CTL_HALF_LON ? true : k < FB_CS_GDC_MODE; }
+    struct RefU {
+        P g; double* l; bool wr;
+        FBD operator double() const { return *l; }
+        FBD const RefU& operator=(double v) const { *l = v; if (wr) *g = v; return *this; }
+        FBD const RefU& operator=(const RefU& o) const { return *this = (double)o; }
+    };
+    struct RefS {   // (a row this half does not write to memory is one it never reads back: the guidance's record rows in the lateral half)
+        P g; bool wr;
+        FBD operator double() const { return *g; }
+        FBD const RefS& operator=(double v) const { if (wr) *g = v; return *this; }
+        FBD const RefS& operator=(const RefS& o) const { return *this = (double)o; }
+    };
+    FBD RefU U(int k) const { return {cu + (int64_t)k * n, lu + k, writes_u(k)}; }
+    FBD RefS S(int k) const { return {cs + (int64_t)k * n, writes_s(k)}; }
+};
+static_assert(FB_CS_GDC_MODE > FB_CS_CHI2PHI_PID + 2 && FB_CS_SEG_S_2B == FB_NCS - 1, "the guidance's record rows are the last rows of cs");
 // what the control laws read from vehicle.y (XLonRed/XLonFull/XLatRed, Zte/Ztv/Zvh/Zφβ/Zar: c172x_ctl.jl:84-199, 745-810)
 struct CtlIn {
     double EAS, h_e, theta, phi, clm, chi, lat, lon;
@@ -213,8 +247,86 @@ FBD void lqr_init(const MEM& M, int s0, const double* g, const double (&lo)[2], 
     lqr_run<NX>(M, s0, g, lo, hi, dT, x, z, z, out);
 }
 
+// The same LQR with its gains taken where they are used, through an accessor g(k) (k: the record's index) — for the halves of an update that
+// run in 256 registers (x2_periodic_half): interpolating the whole 36-double record first (144 corner loads, 36 results held for the run)
+// does not fit there, and what the allocator made of it was a load / wait / spill per gain (profiles/r04_x2_half_stamps.txt). Here every
+// gain is consumed as it arrives, in four groups whose corner loads are in flight together (compiler barriers between the groups keep the
+// scheduler from hoisting all 144): trims (x_trim, z_trim), then per output i: K_int, K_fwd, K_fbk, u_trim. Same operations, same order of
+// summation as lqr_run (x - x_trim is formed once per state instead of once per output: the same value).
+template <int REC, class P>
+struct LqrGainSrc {
+    P a00, a10, a01, a11;
+    double wE, wH;
+    // the gains idx[0..N): their 4 N corner values are loaded FIRST, all in flight together (the scheduling barrier keeps the interpolation
+    // arithmetic from being interleaved load by load, which is what the scheduler otherwise does under register pressure), then interpolated
+    // — element by element ctl_interp's expression
+    template <int N>
+    FBD void fetch(const int (&idx)[N], double (&v)[N]) const {
+        double r00[N], r01[N], r10[N], r11[N];
+#pragma unroll
+        for (int e = 0; e < N; e++) { r00[e] = a00[idx[e]]; r01[e] = a01[idx[e]]; r10[e] = a10[idx[e]]; r11[e] = a11[idx[e]]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < N; e++) v[e] = (1 - wE) * ((1 - wH) * r00[e] + wH * r01[e]) + wE * ((1 - wH) * r10[e] + wH * r11[e]);
+    }
+};
+template <int REC, class TAB, class P>
+FBD LqrGainSrc<REC, P> lqr_gain_src(const TAB& T, P lk, double EAS, double h) {
+    CtlCell c = T.cell;
+    if (!T.o.same_grid) c = ctl_cell(ctl_hdr(lk), EAS, h);
+    const P d = lk + FB_CTL_GRID_HDR;
+    return {d + c.r00 * REC, d + c.r10 * REC, d + c.r01 * REC, d + c.r11 * REC, c.wE, c.wH};
+}
+template <int NX, class MEM, class G>
+FBD void lqr_run_g(const MEM& M, int s0, const G& g, const double (&lo)[2], const double (&hi)[2], double dT, const double (&x)[NX],
+                   const double (&z)[2], const double (&z_ref)[2], double (&out)[2]) {
+    constexpr int KF = 0, KW = 2 * NX, KI = KW + 4, XT = KI + 4, UT = XT + NX, ZT = UT + 2;
+    const double st[4] = {M.S(s0), M.S(s0 + 1), M.S(s0 + 2), M.S(s0 + 3)};   // int_out_0[2], out_sat_0[2] (read before either output writes them)
+    const double dz0 = z_ref[0] - z[0], dz1 = z_ref[1] - z[1];
+    int i1[NX + 4];
+    double t1[NX + 4];
+#pragma unroll
+    for (int k = 0; k < NX + 4; k++) i1[k] = XT + k;   // x_trim[NX], u_trim[2], z_trim[2]: contiguous in the record
+    static_assert(UT == XT + NX && ZT == UT + 2, "record layout");
+    g.template fetch<NX + 4>(i1, t1);
+    double dx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; k++) dx[k] = x[k] - t1[k];
+    const double dt0 = z_ref[0] - t1[NX + 2], dt1 = z_ref[1] - t1[NX + 3];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int i2[NX + 4];
+        double t2[NX + 4];
+        i2[0] = KI + i; i2[1] = KI + i + 2; i2[2] = KW + i; i2[3] = KW + i + 2;
+#pragma unroll
+        for (int k = 0; k < NX; k++) i2[4 + k] = KF + i + 2 * k;
+        g.template fetch<NX + 4>(i2, t2);
+        const double int_in = t2[0] * dz0 + t2[1] * dz1;
+        const bool halted = sgnd(int_in * st[2 + i]) > 0;
+        const double int_out = st[i] + dT * int_in * (halted ? 0.0 : 1.0);
+        const double fwd = t2[2] * dt0 + t2[3] * dt1;
+        double fbk = t2[4] * dx[0];
+#pragma unroll
+        for (int k = 1; k < NX; k++) fbk += t2[4 + k] * dx[k];
+        const double out_free = t1[NX + i] + int_out + fwd - fbk;
+        M.S(s0 + i) = int_out;
+        M.S(s0 + 2 + i) = (out_free >= hi[i] ? 1.0 : 0.0) - (out_free <= lo[i] ? 1.0 : 0.0);
+        out[i] = fmin(fmax(out_free, lo[i]), hi[i]);
+    }
+}
+template <int NX, class MEM, class G>
+FBD void lqr_init_g(const MEM& M, int s0, const G& g, const double (&lo)[2], const double (&hi)[2], double dT) {
+    double x[NX], out[2];
+#pragma unroll
+    for (int k = 0; k < NX; k++) x[k] = 0;
+    const double z[2] = {0, 0};
+    M.S(s0) = 0; M.S(s0 + 1) = 0; M.S(s0 + 2) = 0; M.S(s0 + 3) = 0;
+    lqr_run_g<NX>(M, s0, g, lo, hi, dT, x, z, z, out);
+}
+
 // ---- longitudinal channel ------------------------------------------------------------------------------------------
-template <class TAB, class MEM>
+// STREAM: the LQR gains through lqr_gain_src / lqr_run_g (the halves of an update), instead of a record interpolated up front
+template <bool STREAM = false, class TAB, class MEM>
 FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
     double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
     const double EAS_ref = M.U(FB_CU_EAS_REF), clm_ref = M.U(FB_CU_CLM_REF), h_ref = M.U(FB_CU_H_REF);
@@ -285,29 +397,46 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
         }
         FB_X2_STAMP(28);
-        double g8[FB_CTL_LQR8_REC];
-        T.template lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g8);
-        FB_X2_STAMP(29);
         const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
-        M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
-        lqr_run<8>(M, FB_CS_TE2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
+        if constexpr (STREAM) {
+            M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
+            lqr_run_g<8>(M, FB_CS_TE2TE, lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(0), EAS, h_e), lo, hi, dT, x_red, z, z_ref, out);
+        } else {
+            double g8[FB_CTL_LQR8_REC];
+            T.template lookup<FB_CTL_LQR8_REC>(T.lk(0), EAS, h_e, g8);
+            FB_X2_STAMP(29);
+            M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
+            lqr_run<8>(M, FB_CS_TE2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
+        }
         throttle_cmd = out[0]; elevator_cmd = out[1];
     }
     if (mode == FB_LON_THR_EAS) {
-        double g8[FB_CTL_LQR8_REC];
-        T.template lookup<FB_CTL_LQR8_REC>(T.lk(1), EAS, h_e, g8);
-        if (changed) lqr_init<8>(M, FB_CS_TV2TE, g8, lo, hi, dT);
         const double z[2] = {v.cmd[0], EAS}, z_ref[2] = {throttle_ref, EAS_ref};
-        lqr_run<8>(M, FB_CS_TV2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
+        if constexpr (STREAM) {
+            const auto g = lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(1), EAS, h_e);
+            if (changed) lqr_init_g<8>(M, FB_CS_TV2TE, g, lo, hi, dT);
+            lqr_run_g<8>(M, FB_CS_TV2TE, g, lo, hi, dT, x_red, z, z_ref, out);
+        } else {
+            double g8[FB_CTL_LQR8_REC];
+            T.template lookup<FB_CTL_LQR8_REC>(T.lk(1), EAS, h_e, g8);
+            if (changed) lqr_init<8>(M, FB_CS_TV2TE, g8, lo, hi, dT);
+            lqr_run<8>(M, FB_CS_TV2TE, g8, lo, hi, dT, x_red, z, z_ref, out);
+        }
         throttle_cmd = out[0]; elevator_cmd = out[1];
     }
     if (mode == FB_LON_EAS_ALT) {
-        double g[FB_CTL_LQR9_REC];
-        T.template lookup<FB_CTL_LQR9_REC>(T.lk(2), EAS, h_e, g);
-        if (changed) lqr_init<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
         const double x_full[9] = {v.w_eb_b.y, theta, EAS, v.alpha, h_e, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
         const double z[2] = {EAS, h_e}, z_ref[2] = {EAS_ref, h_ref};
-        lqr_run<9>(M, FB_CS_VH2TE, g, lo, hi, dT, x_full, z, z_ref, out);
+        if constexpr (STREAM) {
+            const auto g = lqr_gain_src<FB_CTL_LQR9_REC>(T, T.lk(2), EAS, h_e);
+            if (changed) lqr_init_g<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
+            lqr_run_g<9>(M, FB_CS_VH2TE, g, lo, hi, dT, x_full, z, z_ref, out);
+        } else {
+            double g[FB_CTL_LQR9_REC];
+            T.template lookup<FB_CTL_LQR9_REC>(T.lk(2), EAS, h_e, g);
+            if (changed) lqr_init<9>(M, FB_CS_VH2TE, g, lo, hi, dT);
+            lqr_run<9>(M, FB_CS_VH2TE, g, lo, hi, dT, x_full, z, z_ref, out);
+        }
         throttle_cmd = out[0]; elevator_cmd = out[1];
     }
     M.S(FB_CS_LON_MODE) = mode;
@@ -374,7 +503,8 @@ FBD LatGains ctl_lat_gains(const TAB& T, const CtlIn& v, int mode_req) {
     }
     return G;
 }
-template <class TAB, class MEM>
+// STREAM (the halves of an update): G is not read — the LQR gains come through lqr_gain_src / lqr_run_g, the PID gains where their loop runs
+template <bool STREAM = false, class TAB, class MEM>
 FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req, const LatGains& G) {
     const double p_ref = M.U(FB_CU_P_REF), beta_ref = M.U(FB_CU_BETA_REF), chi_ref = M.U(FB_CU_CHI_REF);
     double phi_ref = M.U(FB_CU_PHI_REF);
@@ -390,13 +520,14 @@ FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     double out[2];
     if (mode == FB_LAT_SAS) {
         const double z[2] = {v.cmd[1], v.cmd[3]}, z_ref[2] = {aileron_ref, rudder_ref};
-        lqr_run<8>(M, FB_CS_AR2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
+        if constexpr (STREAM) lqr_run_g<8>(M, FB_CS_AR2AR, lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(6), EAS, h_e), lo, hi, dT, x_lat, z, z_ref, out);
+        else lqr_run<8>(M, FB_CS_AR2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
         aileron_cmd = out[0]; rudder_cmd = out[1];
     }
     if (mode == FB_LAT_P_BETA || mode == FB_LAT_PHI_BETA || mode == FB_LAT_CHI_BETA) {
         const double sat_ail = M.S(FB_CS_PHIBETA2AR + 2);
         if (mode == FB_LAT_P_BETA) {
-            const PidGains P = G.P;
+            const PidGains P = STREAM ? pid_gains(T, T.lk(8), EAS, h_e) : G.P;
             if (changed) {
                 integ_init(M, FB_CS_P2PHI_INT, dT);
                 pid_init(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT);
@@ -405,14 +536,21 @@ FBD void ctl_lat(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             const double io = integ_run(M, FB_CS_P2PHI_INT, dT, p_ref - v.w_wb_b.x, sat_ail);
             phi_ref = pid_run(M, FB_CS_P2PHI_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ail);
         } else if (mode == FB_LAT_CHI_BETA) {
-            const PidGains P = G.P;
+            const PidGains P = STREAM ? pid_gains(T, T.lk(9), EAS, h_e) : G.P;
             if (changed) { pid_init(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT); if (P.k_i != 0) M.S(FB_CS_CHI2PHI_PID) = M.S(FB_CS_PHIBETA2AR + 4); }
             phi_ref = pid_run(M, FB_CS_CHI2PHI_PID, P, -PI / 4, PI / 4, dT, wrap_to_pi(chi_ref - v.chi), sat_ail);
         }
-        if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT);
         const double z[2] = {v.phi, v.beta}, z_ref[2] = {phi_ref, beta_ref};
-        M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];
-        lqr_run<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
+        if constexpr (STREAM) {
+            const auto g = lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(7), EAS, h_e);
+            if (changed) lqr_init_g<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT);
+            M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];
+            lqr_run_g<8>(M, FB_CS_PHIBETA2AR, g, lo, hi, dT, x_lat, z, z_ref, out);
+        } else {
+            if (changed) lqr_init<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT);
+            M.S(FB_CS_PHIBETA2AR + 4) = z_ref[0]; M.S(FB_CS_PHIBETA2AR + 5) = z_ref[1];
+            lqr_run<8>(M, FB_CS_PHIBETA2AR, G.g8, lo, hi, dT, x_lat, z, z_ref, out);
+        }
         aileron_cmd = out[0]; rudder_cmd = out[1];
     }
     M.S(FB_CS_LAT_MODE) = mode;

@@ -67,6 +67,7 @@ struct fb_handle_s {
     double* q_pre = nullptr;   // [8 x n]
     double* ctl_bak = nullptr; // [(FB_NCS + FB_NCU) x n] scratch of the airborne pass (see KArgs::ctl_bak)
     double* duo_pld = nullptr; // [DUO_NCONST x n] scratch of k_step_duo (see KArgs::duo_pld)
+    double* duo_tap = nullptr; // [DUO_NTAP x n] Cessna172Xv2 on k_step_duo: the hand-over rows of a control update (KArgs::duo_tap)
     int32_t* redo = nullptr;   // [n] hand-over flags between the two passes of the stepping kernel
     double* k1 = nullptr;      // [FB_NX x n] Cessna172Xv2: FSAL derivative carried from launch to launch
     int32_t* k1_valid = nullptr;
@@ -89,7 +90,7 @@ static KArgs make_args(fb_handle h) {
     a.dt = h->params.dt;
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
-    a.gains = h->gains; a.ctl_bak = h->ctl_bak; a.duo_pld = h->duo_pld;
+    a.gains = h->gains; a.ctl_bak = h->ctl_bak; a.duo_pld = h->duo_pld; a.duo_tap = h->duo_tap;
     a.term_step = h->term_step; a.term_where = h->term_where; a.step0 = h->steps_done;
     for (int k = 0; k < 10; k++) a.ctl_off.off[k] = (int)h->gains_off[k];
     a.ctl_off.total = (int)h->gains_total;
@@ -165,13 +166,14 @@ static row_map_t row_map_of(fb_handle h) {
         else if (h->kin == FB_KIN_NED) hipLaunchKernelGGL((KERNEL<false, FB_KIN_NED>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<false, FB_KIN_WA>), GRID, BLOCK, 0, h->stream, __VA_ARGS__);                                  \
     } while (0)
-// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): Cessna172Sv0 in fp64 (any mechanisation) is stepped by the
-// wave-specialised k_step_duo<KIN> (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air<KIN>
+// FLIGHTBATCH_DUO (read when a handle is created; A/B switch for measurements): Cessna172Sv0 and Cessna172Xv2 in fp64 (any mechanisation) are stepped
+// by the wave-specialised k_step_duo<KIN, X> (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air<KIN, X>
 static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
 #define FB_STEP_X2(KIN, GRID, A, K)                                                                                                   \
     do {                                                                                                                              \
-        hipLaunchKernelGGL((k_step_air<KIN, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                     \
+        if (h->duo) hipLaunchKernelGGL((k_step_duo<KIN, true>), grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);         \
+        else hipLaunchKernelGGL((k_step_air<KIN, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                \
         hipLaunchKernelGGL((k_step_air<KIN, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
     } while (0)
 // the Cessna172Xv2 kernels that are not stepping kernels take the mechanisation alone
@@ -185,10 +187,8 @@ static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e
     do {                                                                                                                              \
         if (is_x2(h) && h->kin == FB_KIN_ECEF) FB_STEP_X2(FB_KIN_ECEF, GRID, A, K);                                                   \
         else if (is_x2(h) && h->kin == FB_KIN_NED) FB_STEP_X2(FB_KIN_NED, GRID, A, K);                                                \
-        else if (is_x2(h)) {                                                                                                          \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
-            hipLaunchKernelGGL((k_step_air<FB_KIN_WA, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
-        } else if (h->kin == FB_KIN_ECEF) {                                                                                           \
+        else if (is_x2(h)) FB_STEP_X2(FB_KIN_WA, GRID, A, K);                                                                         \
+        else if (h->kin == FB_KIN_ECEF) {                                                                                           \
             if (h->duo) hipLaunchKernelGGL(k_step_duo<FB_KIN_ECEF>, grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);  \
             else hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                            \
             hipLaunchKernelGGL((k_step_air<FB_KIN_ECEF, false, true>), grid_for(h->n, step_block<false, true>()), dim3(step_block<false, true>()), 0, h->stream, A, K);                  \
@@ -263,6 +263,7 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
     HIPCHK(hipMemsetAsync(h->term_where, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->redo, sizeof(int32_t) * n));
     if (h->duo) HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * n));   // (here, not in the first fb_step: hipMalloc synchronises the device)
+    if (h->duo && model_id == FB_MODEL_C172X2) HIPCHK(hipMalloc(&h->duo_tap, sizeof(double) * DUO_NTAP * n));
     HIPCHK(hipMemsetAsync(h->redo, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->tables, sizeof(double) * TABLE_BUF_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
@@ -299,8 +300,8 @@ int32_t fb_create(int32_t model_id, int32_t kin_id, int32_t dtype, int64_t n, in
     if (device_id >= ndev) return fail("device_id out of range");
     HIPCHK(hipSetDevice(device_id));
     fb_handle h = new fb_handle_s();
-    // the wave-specialised stepper exists for Cessna172Sv0 in fp64 (any mechanisation); every other handle steps with k_step_air and needs no duo_pld
-    h->duo = model_id == FB_MODEL_C172S0 && dtype == FB_F64 && env_step_duo();
+    // the wave-specialised stepper exists for Cessna172Sv0 and Cessna172Xv2 in fp64 (any mechanisation); every other handle steps with k_step_air and needs no duo_pld
+    h->duo = (model_id == FB_MODEL_C172S0 || model_id == FB_MODEL_C172X2) && dtype == FB_F64 && env_step_duo();
     h->model = model_id; h->kin = kin_id; h->dtype = dtype; h->device = device_id; h->n = n;
     h->params.dt = 0.02; h->params.periodic_n = 1; h->params.surface = 0;
     h->params.T_sl = isa::T_std; h->params.p_sl = isa::p_std;
@@ -323,7 +324,7 @@ int32_t fb_destroy(fb_handle h) {
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->term_step); hipFree(h->term_where); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
-    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
+    hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->duo_tap); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
     delete h;
