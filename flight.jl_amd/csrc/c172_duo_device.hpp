@@ -280,6 +280,7 @@ DUO_MARK(1, 6);   // engine head done
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
+        [[maybe_unused]] double ac_raw[12];
         if constexpr (!X) in.fetch_aero(ac);   // (launch constants; Cessna172Xv2: this evaluation's, behind role P's point R below)
         double alpha = 0, beta = 0, cos_al = 1, sin_al = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
@@ -304,7 +305,8 @@ DUO_MARK(1, 6);   // engine head done
             // Cessna172Xv2: role P has formed this evaluation's deflection-only sums ahead of its point R (which releases global memory there):
             // the fetch is in flight while the knots are located
             emit.xwait(DUO_PT_R);
-            in.fetch_aero(ac);
+            in.fetch_aero_raw(ac_raw);
+            __builtin_amdgcn_sched_barrier(0);   // (the loads above are issued before the knot scans, their first use stands behind them)
         }
         const loc l_al26 = grid_locate<26, true, AUX_AL26>(A + AT_CD_ALPHA_K, RA + AT_CD_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CD_ALPHA_K), T.gk);
         const loc l_al17 = grid_locate<17, true, AUX_AL17>(A + AT_CL_ALPHA_K, RA + AT_CL_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CL_ALPHA_K), T.gk);
@@ -312,6 +314,7 @@ DUO_MARK(1, 6);   // engine head done
         const loc l_be3 = grid_locate<3, true>(A + AT_CY_BETA_K, RA + AT_CY_BETA_K, be, true, true, gkp(LDS_AERO + AT_CY_BETA_K));
         const loc l_bu = grid_locate<3, true>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true, gkp(LDS_AERO + AT_UNIT3_K));
         DUO_MARK(2, 3);   // knot locations
+        if constexpr (X) { __builtin_amdgcn_sched_barrier(0); In::aero_from_raw(ac_raw, ac); }
         const loc l_stall = {0, stall ? 1.0 : 0.0};
         const loc l_df4 = ac.l_df4, l_df2 = ac.l_df2;
         // the lookups on those axes alone

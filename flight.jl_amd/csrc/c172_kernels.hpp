@@ -1069,8 +1069,15 @@ struct InputsDuoD {
     __device__ __forceinline__ double get_pld_J(int k) const { return pld_l[(4 + k) * DUO_B]; }
     __device__ __forceinline__ void fetch_aero(AeroC& c) const {
         double v[DUO_NCONST];
+        fetch_aero_raw(v);
+        aero_from_raw(v, c);
+    }
+    // (in two steps for the Cessna172Xv2 instance, which fetches behind a wait and wants the loads in flight while it locates the knots)
+    __device__ __forceinline__ void fetch_aero_raw(double (&v)[DUO_NCONST]) const {
 #pragma unroll
         for (int k = 0; k < DUO_NCONST; k++) v[k] = aero_g[(int64_t)k * n];
+    }
+    __device__ __forceinline__ static void aero_from_raw(const double (&v)[DUO_NCONST], AeroC& c) {
         c.cd_in = v[0]; c.cd_df = v[1]; c.cy_in = v[2]; c.cl_in = v[3]; c.cl_df = v[4]; c.croll_in = v[5]; c.cm_in = v[6]; c.cn_in = v[7];
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
@@ -1301,6 +1308,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #ifndef FB_DUO_PRIO_D
 #define FB_DUO_PRIO_D 2
 #endif
+#ifndef FB_X2_LON_PRIO
+#define FB_X2_LON_PRIO 3   // Cessna172Xv2: role P's wave during its half of a control update (see there)
+#endif
     if (role == 2) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
 #ifdef FB_DUO_PRIO_P
     if (role == 1) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_P);
@@ -1377,6 +1387,35 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #pragma unroll
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
         [[maybe_unused]] const double z0 = dt / ACT_TAU;
+        // Cessna172Xv2: the deflection-only aerodynamic sums (InputsAgg::sum_aero) of the surface actuators' positions at stage `stg_for`, for
+        // role D, through the rows of KArgs::duo_pld (role D fetches them behind this role's point R, which releases global memory too). Formed
+        // for every lane, running or not, from the lane's own actuator registers — so what is in memory is valid for the whole wave — and
+        // formed AHEAD: at the end of an iteration for the stage that normally follows, while role D finishes its evaluation and keeps the
+        // book; at the head of an evaluation only when that guess was wrong (a re-evaluation of k1, or new commands from a control update).
+        [[maybe_unused]] int sums_for = -1;   // wave-uniform: the stage whose sums are in memory (-1: none)
+        [[maybe_unused]] auto form_sums = [&](int stg_for, int lds_off) {
+            double z = z0;
+            asm volatile("" : "+v"(z));
+            const double ms = stg_for == 0 ? 1.0 : (stg_for == 1 ? 1 - z / 2 : (stg_for == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+            double xa_s[FB_NACT];
+#pragma unroll
+            for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+            xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
+            const InputsX ix = {xa_s, nullptr, a.n, in.ui};
+            InputsAgg ia;
+            ia.de = ix.get_de(); ia.da = ix.get_da(); ia.dr = ix.get_dr(); ia.df = ix.get_df();
+            ia.sum_aero((lds_cptr)lds + LDS_AERO + lds_off, (lds_cptr)rk + LDS_AERO + lds_off);
+            const double ac[DUO_NCONST] = {ia.cd_in, ia.cd_df, ia.cy_in, ia.cl_in, ia.cl_df, ia.croll_in, ia.cm_in, ia.cn_in,
+                                           (double)ia.l_df4.i, ia.l_df4.w, (double)ia.l_df2.i, ia.l_df2.w};
+            if (valid) {
+                int64_t il = i;
+                asm volatile("" : "+v"(il));   // (opaque: the row addresses are formed here — hoisted, they are spilled and reloaded)
+                double* const g = a.duo_pld + il;
+#pragma unroll
+                for (int k = 0; k < DUO_NCONST; k++) g[(int64_t)k * a.n] = ac[k];
+            }
+            sums_for = stg_for;
+        };
 #pragma unroll 1
         while (true) {
             DUO_MARK(1, 15);  // (arrival at the top of the loop, counted from the previous evaluation's start)
@@ -1404,32 +1443,19 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             asm volatile("" : "+s"(lds_off));   // (see k_step_air: keeps the loop-invariant table / input loads from being hoisted into registers)
             const Tables T = {(lds_cptr)lds + lds_off, a.egm96, (lds_cptr)rk + lds_off, (gk_cptr)a.tables + lds_off};
             [[maybe_unused]] const bool tap = X && (c & DUO_C_TAP);
+            if constexpr (X) { if (sums_for != stg || (c & DUO_C_CMD)) form_sums(stg, lds_off); }
             if (__builtin_amdgcn_ballot_w64(run) != 0) {   // (the same in both waves of a pair)
                 if (run) {
                     StepAux aux;
                     InputsDuoP inl = in;
                     if constexpr (X) {
-                        // the actuators' stage positions (closed-form RK4, see k_step_air) -> throttle for the engine; the deflection-only
-                        // aerodynamic sums of this stage's surface positions -> role D, through memory (it fetches them behind point R)
+                        // the throttle actuator's stage position (closed-form RK4, see k_step_air) for the engine; the deflection-only aerodynamic
+                        // sums of this stage's surface positions are in memory already when the speculation at the end of the previous
+                        // iteration was right (the usual case: the next stage, the same commands)
                         double z = z0;
                         asm volatile("" : "+v"(z));   // (opaque: the stage multipliers are formed here, not hoisted out of the loop into registers that then spill)
                         const double ms = stg == 0 ? 1.0 : (stg == 1 ? 1 - z / 2 : (stg == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
-                        double xa_s[FB_NACT];
-#pragma unroll
-                        for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
-                        xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
-                        const InputsX ix = {xa_s, nullptr, a.n, in.ui};
-                        inl.throttle = ix.get_throttle();
-                        InputsAgg ia;
-                        ia.de = ix.get_de(); ia.da = ix.get_da(); ia.dr = ix.get_dr(); ia.df = ix.get_df();
-                        ia.sum_aero((lds_cptr)lds + LDS_AERO + lds_off, (lds_cptr)rk + LDS_AERO + lds_off);
-                        const double ac[DUO_NCONST] = {ia.cd_in, ia.cd_df, ia.cy_in, ia.cl_in, ia.cl_df, ia.croll_in, ia.cm_in, ia.cn_in,
-                                                       (double)ia.l_df4.i, ia.l_df4.w, (double)ia.l_df2.i, ia.l_df2.w};
-                        int64_t il = i;
-                        asm volatile("" : "+v"(il));   // (opaque: the row addresses are formed here — hoisted, they are spilled and reloaded)
-                        double* const g = a.duo_pld + il;
-#pragma unroll
-                        for (int k = 0; k < DUO_NCONST; k++) g[(int64_t)k * a.n] = ac[k];
+                        inl.throttle = clampd(ca[FB_ACT_THROTTLE] + (xa[FB_ACT_THROTTLE] - ca[FB_ACT_THROTTLE]) * ms, 0.0, 1.0);   // InputsX::get_throttle
                     }
                     DUO_MARK(1, 12);   // (Cessna172Xv2: stage positions and aerodynamic sums formed and stored)
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
@@ -1476,6 +1502,10 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     duo_wait(sy, DUO_PT_U);
                     DUO_MARK(1, 14);   // past U
                     const bool ctl = flags_l[t] & DUO_F_CTL;
+                    // (issue priority: this half is the longer one and runs ahead of role D's; role D waits for it at priority 0. Measured —
+                    // profiles/r04_x2_update_ab.txt — the two halves do not overlap at role D's stepping priority: 0.156 ms per update of
+                    // 524 288 aircraft against 0.078 + 0.061 for the halves alone; with this half ahead 0.115)
+                    __builtin_amdgcn_s_setprio(FB_X2_LON_PRIO);
 #ifdef FB_X2_SKIP_LON   // (timing diagnostics: one half of the update alone)
                     if (false) {
 #else
@@ -1485,8 +1515,13 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                         ca[FB_ACT_THROTTLE] = co.c0; ca[FB_ACT_ELEVATOR] = co.c1;   // in force from the next stage on
                     }
                     DUO_MARK(1, 7);    // longitudinal half done
+                    __builtin_amdgcn_s_setprio(0);
                     duo_publish<true>(sy, DUO_PT_F);
                 }
+                // the sums of the stage that normally comes next, while role D finishes its evaluation and keeps the book
+#ifndef FB_X2_NO_SPECULATION
+                form_sums((stg + 1) & 3, lds_off);
+#endif
             }
             sy.base += NPT;
         }
@@ -1584,9 +1619,14 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 InputsDuoD inl = in;
                 inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
                 if constexpr (X) {
+                    // base and stride of the sums' rows, read from the kernel's arguments HERE, at the head of the evaluation (scalar loads that
+                    // complete long before the fetch behind point R: held in SGPRs across the whole loop they are spilled, and re-read in
+                    // front of the fetch they are two exposed round trips)
+                    const kargs_cptr ka = kernarg();
                     int64_t il = i;
                     asm volatile("" : "+v"(il));   // (see role P)
-                    inl.aero_g = a.duo_pld + il;
+                    inl.aero_g = ka->duo_pld + il;
+                    inl.n = ka->n;
                 }
                 const DuoEmit<2, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
                                             tap_now, i};
@@ -1669,6 +1709,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #ifdef FB_X2_UPD_PRIO
                 __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO);
 #endif
+#ifdef FB_X2_SERIAL   // (timing diagnostic: the lateral half only after the longitudinal one has finished)
+                duo_wait(sy, DUO_PT_F);
+#endif
 #ifdef FB_X2_SKIP_LAT
                 if (false) {
 #else
@@ -1679,7 +1722,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 }
                 cmd_put = true;
                 DUO_MARK(2, 13);   // lateral half done
+                __builtin_amdgcn_s_setprio(0);
                 duo_wait(sy, DUO_PT_F);   // role P's half is done: the record is at rest
+                __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
 #ifdef FB_X2_UPD_PRIO
                 __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
 #endif
