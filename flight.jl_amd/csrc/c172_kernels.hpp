@@ -1278,7 +1278,7 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //     put back from ctl_bak at the end). Callback order as in the reference: cb_step, then cb_periodic (FC/sim.jl:204-218).
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
 //     stepped here, the ground-capable pass evaluates its own.
-constexpr int DUO_PT_U = 3, DUO_PT_F = 3;   // role D: flags of the update written; role P: its half of the update done
+constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
 template <int KIN, bool X = false>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
