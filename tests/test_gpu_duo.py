@@ -123,3 +123,62 @@ def test_wave_pairs_leaving_at_different_steps(fb, oracle):
     xo, so, sto, tso, two = oracle.step_term(x, u, ui, s, oracle.default_env(), 0.01, 100, status=st0)
     assert np.array_equal(sto, std) and np.array_equal(tso[gone], tsd[gone]) and np.array_equal(two[gone], twd[gone])
     assert (np.abs(xd - xo) / np.maximum(np.abs(xo), 1e-3)).max() < 1e-9
+
+
+@pytest.mark.parametrize("n,spl,kin", [(1000, 50, "WA"), (333, 7, "ECEF"), (577, 25, "NED")])
+def test_x2_duo_and_air_steppers_agree(fb, n, spl, kin):
+    """Cessna172Xv2 under its autopilot on the two airborne steppers: the wave pair (k_step_duo<KIN, true>: actuators and aerodynamic sums on
+    role P, the control update in two halves side by side with streamed LQR gains) and the one-wave stepper (k_step_air<KIN, true>,
+    FLIGHTBATCH_DUO=0: the update as one call with the record cached). Same physics and control laws, another order of evaluation: state,
+    control-law record and discrete states agree to rounding on every aircraft — ragged batch, every pair of control modes, aircraft
+    terminated before the launch, aircraft on short final that cross into the ground-capable pass in the middle of a launch (their
+    control-law record is put back from ctl_bak and the lane stepped again from the launch-start state)."""
+    K = fb.K
+    gains = fb.ctl_gains.ctl_gains_blob()
+    rng = np.random.default_rng(77 + n)
+    h_trn = 250.0
+    cruise = rng.random(n) < 0.7
+    h = np.where(cruise, h_trn + rng.uniform(300, 3000, n), h_trn + rng.uniform(12, 30, n))
+    tp = fb.TrimParameters(EAS=np.where(cruise, rng.uniform(40, 55, n), rng.uniform(35, 42, n)), h_e=h,
+                           γ_wb_n=np.where(cruise, 0.0, -np.deg2rad(rng.uniform(2, 4, n))), flaps=np.where(cruise, 0.0, 1.0), ψ_nb=rng.uniform(-3, 3, n))
+    lon = rng.integers(0, 9, n); lat = rng.integers(0, 5, n)
+    st0 = np.zeros(n, np.int32); st0[rng.random(n) < 0.05] = K["FB_ST_NAN"]
+    out = {}
+    for duo in (False, True):
+        old = os.environ.get("FLIGHTBATCH_DUO")
+        os.environ["FLIGHTBATCH_DUO"] = "1" if duo else "0"
+        try:
+            w = fb.Cessna172Xv2World(n, gains=gains, kinematics=kin)
+        finally:
+            if old is None: del os.environ["FLIGHTBATCH_DUO"]
+            else: os.environ["FLIGHTBATCH_DUO"] = old
+        w.set_params(h_terrain=h_trn, wind_ned=(2.0, -1.0, 0.0))
+        sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=spl)
+        fb.init(sim, tp)
+        ok = w.trim_success
+        cu = w.cu
+        cu[K["FB_CU_LON_MODE_REQ"]] = np.where(cruise, lon, float(fb.ModeControlLon.EAS_clm))
+        cu[K["FB_CU_LAT_MODE_REQ"]] = np.where(cruise, lat, float(fb.ModeControlLat.φ_β))
+        cu[K["FB_CU_CLM_REF"]] = np.where(cruise, cu[K["FB_CU_CLM_REF"]] + 1.0, -3.0)
+        cu[K["FB_CU_EAS_REF"]] += 2.0; cu[K["FB_CU_PHI_REF"]] += 0.2; cu[K["FB_CU_H_REF"]] += 30.0
+        w.cu = cu
+        fb._lib.check(fb.lib.fb_set_status(w._h, st0.ctypes.data_as(fb._lib.C.POINTER(fb._lib.C.c_int32))))
+        fb.step(sim, 4.0); w.sync()
+        out[duo] = dict(x=w.x, cs=w.cs, s=w.s, status=w.status, ok=ok)
+        w.close()
+    a, b = out[False], out[True]
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["s"], b["s"])
+    live = a["ok"] & (a["status"] == 0)
+    he = {"WA": 20, "ECEF": 19, "NED": 17}[kin]
+    perm_he = he if he < K["FB_X2_ACT"] else he   # (the altitude row sits below the actuator block in the C ABI's order too)
+    landed = live & (a["x"][perm_he] - h_trn < 8.0)
+    flying = live & ~landed
+    assert flying.sum() > 0.4 * n and (~cruise & live).sum() > 0.1 * n
+    ex = np.abs(a["x"] - b["x"]) / np.maximum(np.abs(a["x"]), 1.0)
+    ec = np.abs(a["cs"] - b["cs"]) / np.maximum(np.abs(a["cs"]), 1.0)
+    print(f"Xv2({kin}) duo vs air after 400 steps ({spl} per launch): flying {int(flying.sum())}: state {ex[:, flying].max():.2e}, record {ec[:, flying].max():.2e}; "
+          f"handed to the ground-capable pass / rolling {int(landed.sum())}: state {ex[:, landed].max() if landed.any() else 0.0:.2e}")
+    assert ex[:, flying].max() < 1e-9 and ec[:, flying].max() < 1e-9
+    assert not landed.any() or np.quantile(ex[:, landed].max(0), 0.9) < 1e-6   # (on their wheels: ill-conditioned, see tests/conditioning.py; the two differ by rounding only)
+    dead = a["status"] != 0
+    assert np.array_equal(a["x"][:, dead], b["x"][:, dead])   # terminated before the launch: left alone by both
