@@ -1518,9 +1518,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     __builtin_amdgcn_s_setprio(0);
                     duo_publish<true>(sy, DUO_PT_F);
                 }
-                // the sums of the stage that normally comes next, while role D finishes its evaluation and keeps the book
+                // the sums of the stage that normally comes next, while role D finishes its evaluation and keeps the book — unless a control
+                // update has just run: role D's two new commands arrive with the next control word, and the sums are formed then, once
 #ifndef FB_X2_NO_SPECULATION
-                form_sums((stg + 1) & 3, lds_off);
+                if (tap) sums_for = -1;
+                else form_sums((stg + 1) & 3, lds_off);
 #endif
             }
             sy.base += NPT;
@@ -1877,78 +1879,121 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
 // repeated by continuation in the trim PARAMETERS from the reference's default TrimParameters() (EAS 50, h 1050, ...:
 // c172.jl:806-818, whose trim from TrimState() the reference's own test pins) towards the requested ones.
 constexpr int TRIM_N = 7;
-__device__ __noinline__ void trim_box_gauss_newton(const double (&H)[TRIM_N][TRIM_N], const double (&g)[TRIM_N], const double* dl, const double* du,
-                                                   double ridge, double* d) {
+// The active-set solve inside the box. Every array index below is a compile-time constant after unrolling — the free set is a MASK, not
+// a compacted index list, rows are exchanged by selects — so the 7 x 8 system, H, g and the step live in registers (round 3's form
+// indexed them dynamically: 3.8 KB of scratch per lane, and the solver, not the ~140 residual evaluations, was where k_trim's time
+// went: a dependent scratch round trip per matrix element). The ARITHMETIC is the compacted algorithm's, operation by operation and in
+// its order (free variables in index order; partial pivoting over the free rows below, first maximum; elimination over the free columns
+// from the pivot's on; back-substitution from the last free variable), which is also the oracle's (oracle/fo_trim.hpp): same bits.
+__device__ __forceinline__ void trim_box_gauss_newton(const double (&H)[TRIM_N][TRIM_N], const double (&g)[TRIM_N], const double (&dl)[TRIM_N], const double (&du)[TRIM_N],
+                                                      double ridge, double (&d)[TRIM_N]) {
     constexpr int N = TRIM_N;
     int fixed[N];
+#pragma unroll
     for (int k = 0; k < N; k++) { d[k] = 0; fixed[k] = 0; }
 #pragma unroll 1
     for (int pass = 0; pass < 4 * N; pass++) {
-        int idx[N], nf = 0;
-        for (int k = 0; k < N; k++) if (!fixed[k]) idx[nf++] = k;
-        double A[N][N + 1];
-        for (int a = 0; a < nf; a++) {   // H_FF d_F = -(g_F + H_FB d_B)
-            double rhs = -g[idx[a]];
-            for (int k = 0; k < N; k++) if (fixed[k]) rhs -= H[idx[a]][k] * d[k];
-            for (int b = 0; b < nf; b++) A[a][b] = H[idx[a]][idx[b]] + (a == b ? ridge : 0.0);
-            A[a][nf] = rhs;
+        double A[N][N + 1];   // rows / columns of fixed variables are never read
+#pragma unroll
+        for (int a = 0; a < N; a++) {   // H_FF d_F = -(g_F + H_FB d_B)
+            double rhs = -g[a];
+#pragma unroll
+            for (int k = 0; k < N; k++) rhs = fixed[k] ? rhs - H[a][k] * d[k] : rhs;
+#pragma unroll
+            for (int b = 0; b < N; b++) A[a][b] = H[a][b] + (a == b ? ridge : 0.0);
+            A[a][N] = rhs;
         }
-#pragma unroll 1
-        for (int c = 0; c < nf; c++) {   // Gaussian elimination, partial pivoting
+#pragma unroll
+        for (int c = 0; c < N; c++) {   // Gaussian elimination over the free variables, partial pivoting among the free rows at and below c
+            if (fixed[c]) continue;
             int pv = c;
-            for (int q = c + 1; q < nf; q++) if (fabs(A[q][c]) > fabs(A[pv][c])) pv = q;
-            if (pv != c) for (int q = 0; q <= nf; q++) { const double t = A[pv][q]; A[pv][q] = A[c][q]; A[c][q] = t; }
+            double best = fabs(A[c][c]);
+#pragma unroll
+            for (int q = c + 1; q < N; q++) {
+                const double v = fabs(A[q][c]);
+                const bool take = !fixed[q] && v > best;
+                pv = take ? q : pv; best = take ? v : best;
+            }
+#pragma unroll
+            for (int q = c + 1; q < N; q++) {
+                if (q == pv) {   // (per lane; a wave without such a lane skips it)
+#pragma unroll
+                    for (int w = 0; w <= N; w++) { const double t = A[q][w]; A[q][w] = A[c][w]; A[c][w] = t; }
+                }
+            }
             const double piv = A[c][c] != 0 ? A[c][c] : 1e-300;
-            for (int q = c + 1; q < nf; q++) {
+#pragma unroll
+            for (int q = c + 1; q < N; q++) {
+                if (fixed[q]) continue;
                 const double f = A[q][c] / piv;
-                for (int w = c; w <= nf; w++) A[q][w] -= f * A[c][w];
+#pragma unroll
+                for (int w = c; w < N; w++) A[q][w] = fixed[w] ? A[q][w] : A[q][w] - f * A[c][w];
+                A[q][N] -= f * A[c][N];
             }
         }
         double sol[N];
-        for (int q = nf - 1; q >= 0; q--) {
-            double sum = A[q][nf];
-            for (int w = q + 1; w < nf; w++) sum -= A[q][w] * sol[w];
-            sol[q] = sum / (A[q][q] != 0 ? A[q][q] : 1e-300);
+#pragma unroll
+        for (int q = N - 1; q >= 0; q--) {
+            double sum = A[q][N];
+#pragma unroll
+            for (int w = q + 1; w < N; w++) sum = fixed[w] ? sum : sum - A[q][w] * sol[w];
+            sol[q] = fixed[q] ? 0.0 : sum / (A[q][q] != 0 ? A[q][q] : 1e-300);
         }
         double t = 1.0;   // longest feasible fraction of the move towards the free minimum
         int hit = -1, side = 0;
-        for (int a = 0; a < nf; a++) {
-            const int k = idx[a];
-            const double delta = sol[a] - d[k];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (fixed[k]) continue;
+            const double delta = sol[k] - d[k];
             if (delta > 0 && d[k] + delta > du[k]) { const double tt = (du[k] - d[k]) / delta; if (tt < t) { t = tt; hit = k; side = 1; } }
             if (delta < 0 && d[k] + delta < dl[k]) { const double tt = (dl[k] - d[k]) / delta; if (tt < t) { t = tt; hit = k; side = -1; } }
         }
-        for (int a = 0; a < nf; a++) { const int k = idx[a]; d[k] += t * (sol[a] - d[k]); }
-        if (hit >= 0) { fixed[hit] = side; d[hit] = side > 0 ? du[hit] : dl[hit]; continue; }
+#pragma unroll
+        for (int k = 0; k < N; k++) d[k] = fixed[k] ? d[k] : d[k] + t * (sol[k] - d[k]);
+        if (hit >= 0) {
+#pragma unroll
+            for (int k = 0; k < N; k++) if (k == hit) { fixed[k] = side; d[k] = side > 0 ? du[k] : dl[k]; }
+            continue;
+        }
         int rel = -1;
-        double best = 0;
-        for (int k = 0; k < N; k++) if (fixed[k]) {
+        double best = 0, g_rel = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (!fixed[k]) continue;
             double gm = g[k];
+#pragma unroll
             for (int b = 0; b < N; b++) gm += H[k][b] * d[b];
             const double inward = fixed[k] > 0 ? gm : -gm;   // at the upper face a positive gradient wants to come back
-            if (inward > best) { best = inward; rel = k; }
+            if (inward > best) { best = inward; rel = k; g_rel = g[k]; }
         }
-        if (rel < 0 || best <= 1e-14 * (fabs(g[rel]) + 1e-300)) break;
-        fixed[rel] = 0;
+        if (rel < 0 || best <= 1e-14 * (fabs(g_rel) + 1e-300)) break;
+#pragma unroll
+        for (int k = 0; k < N; k++) if (k == rel) fixed[k] = 0;
     }
 }
 // minimises |r(z)|² inside [lo, hi]; returns the final cost, z updated in place
-__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double* lo, const double* hi, double* z, int max_iter) {
+// (every loop over the seven unknowns is unrolled, so that the Jacobians, H, g and the step are indexed by constants: registers / AGPRs
+// instead of 3.8 KB of dynamically indexed scratch; what is passed to the out-of-line trim_resid by pointer — the 7-vectors — stays in
+// memory at fixed offsets)
+__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], double (&z)[TRIM_N], int max_iter) {
     constexpr int N = TRIM_N;
     const double fd = 1e-6, cost_floor = 1e-27;
     double r[N];
+#pragma unroll
     for (int k = 0; k < N; k++) z[k] = fmin(fmax(z[k], lo[k]), hi[k]);
     trim_resid(p, z, env, T, r);
     double cost = 0;
+#pragma unroll
     for (int k = 0; k < N; k++) cost += r[k] * r[k];
     double D = 0.05;   // the reference's initial_step (c172.jl:919)
 #pragma unroll 1
     for (int it = 0; it < max_iter && cost > cost_floor && D > 1e-13; it++) {
         double Jc[N][N], Jf[N][N], Jb[N][N];
         bool kink[N], any_kink = false;
-#pragma unroll 1
+#pragma unroll
         for (int j = 0; j < N; j++) {
             double zz[N], rp[N], rm[N];
+#pragma unroll
             for (int k = 0; k < N; k++) zz[k] = z[k];
             const double zp = fmin(z[j] + fd, hi[j]), zm = fmax(z[j] - fd, lo[j]);
             zz[j] = zp; trim_resid(p, zz, env, T, rp);
@@ -1956,6 +2001,7 @@ __device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, 
             const double ic = 1.0 / (zp - zm);
             const double ifw = zp > z[j] ? 1.0 / (zp - z[j]) : 0.0, ibw = z[j] > zm ? 1.0 / (z[j] - zm) : 0.0;
             double dmax = 0, cmax = 0;
+#pragma unroll
             for (int i = 0; i < N; i++) {
                 Jc[i][j] = (rp[i] - rm[i]) * ic;
                 Jf[i][j] = ifw != 0 ? (rp[i] - r[i]) * ifw : Jc[i][j];
@@ -1967,34 +2013,51 @@ __device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, 
             if (kink[j]) {
                 any_kink = true;
                 double r2[N];
-                if (zp + fd <= hi[j]) { zz[j] = zp + fd; trim_resid(p, zz, env, T, r2); for (int i = 0; i < N; i++) Jf[i][j] = (r2[i] - rp[i]) / (zp + fd - zp); }
-                if (zm - fd >= lo[j]) { zz[j] = zm - fd; trim_resid(p, zz, env, T, r2); for (int i = 0; i < N; i++) Jb[i][j] = (rm[i] - r2[i]) / (zm - (zm - fd)); }
+                if (zp + fd <= hi[j]) {
+                    zz[j] = zp + fd; trim_resid(p, zz, env, T, r2);
+#pragma unroll
+                    for (int i = 0; i < N; i++) Jf[i][j] = (r2[i] - rp[i]) / (zp + fd - zp);
+                }
+                if (zm - fd >= lo[j]) {
+                    zz[j] = zm - fd; trim_resid(p, zz, env, T, r2);
+#pragma unroll
+                    for (int i = 0; i < N; i++) Jb[i][j] = (rm[i] - r2[i]) / (zm - (zm - fd));
+                }
             }
         }
         bool accepted = false;
 #pragma unroll 1
         for (int attempt = 0; attempt < 40 && !accepted && D > 1e-13; attempt++) {
             double dl[N], du[N];
+#pragma unroll
             for (int k = 0; k < N; k++) { dl[k] = fmax(lo[k] - z[k], -D); du[k] = fmin(hi[k] - z[k], D); }
             double best_cn = 0, best_pred = 0, best_dinf = 0, best_zn[N], best_rn[N];
             bool have = false;
             int side0[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) side0[j] = 0;
 #pragma unroll 1
             for (int cand = 0; cand < (any_kink ? 2 : 1); cand++) {
                 double J[N][N], H[N][N], g[N], d[N];
                 int side[N];
+#pragma unroll
                 for (int j = 0; j < N; j++) {
                     side[j] = cand == 0 ? 0 : (kink[j] ? (side0[j] > 0 ? -1 : 1) : 0);
+#pragma unroll
                     for (int i = 0; i < N; i++) J[i][j] = side[j] == 0 ? Jc[i][j] : side[j] > 0 ? Jf[i][j] : Jb[i][j];
                 }
 #pragma unroll 1
                 for (int round = 0; round < (cand == 0 ? 3 : 1); round++) {
                     double tr = 0;
+#pragma unroll
                     for (int a = 0; a < N; a++) {
                         g[a] = 0;
+#pragma unroll
                         for (int i = 0; i < N; i++) g[a] += J[i][a] * r[i];
+#pragma unroll
                         for (int b = 0; b < N; b++) {
                             double sum = 0;
+#pragma unroll
                             for (int i = 0; i < N; i++) sum += J[i][a] * J[i][b];
                             H[a][b] = sum;
                         }
@@ -2003,37 +2066,48 @@ __device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, 
                     trim_box_gauss_newton(H, g, dl, du, 1e-14 * tr + 1e-300, d);
                     if (cand != 0) break;
                     bool changed = false;
+#pragma unroll
                     for (int j = 0; j < N; j++) if (kink[j]) {
                         const int want = d[j] > 0 ? 1 : d[j] < 0 ? -1 : (side[j] != 0 ? side[j] : 1);
                         if (want != side[j]) {
                             side[j] = want; changed = true;
+#pragma unroll
                             for (int i = 0; i < N; i++) J[i][j] = want > 0 ? Jf[i][j] : Jb[i][j];
                         }
                     }
                     if (!changed) break;
                 }
-                if (cand == 0) for (int j = 0; j < N; j++) side0[j] = side[j];
+                if (cand == 0) {
+#pragma unroll
+                    for (int j = 0; j < N; j++) side0[j] = side[j];
+                }
                 double pred = 0, dinf = 0;
+#pragma unroll
                 for (int a = 0; a < N; a++) {
                     double Hd = 0;
+#pragma unroll
                     for (int b = 0; b < N; b++) Hd += H[a][b] * d[b];
                     pred -= d[a] * (2 * g[a] + Hd);
                     dinf = fmax(dinf, fabs(d[a]));
                 }
                 if (!(pred > 0) || dinf == 0) continue;
                 double zn[N], rn[N];
+#pragma unroll
                 for (int k = 0; k < N; k++) zn[k] = fmin(fmax(z[k] + d[k], lo[k]), hi[k]);
                 trim_resid(p, zn, env, T, rn);
                 double cn = 0;
+#pragma unroll
                 for (int k = 0; k < N; k++) cn += rn[k] * rn[k];
                 if (!have || cn < best_cn) {
                     have = true; best_cn = cn; best_pred = pred; best_dinf = dinf;
+#pragma unroll
                     for (int k = 0; k < N; k++) { best_zn[k] = zn[k]; best_rn[k] = rn[k]; }
                 }
             }
             if (!have) { D *= 0.25; continue; }
             const double rho = (cost - best_cn) / best_pred;
             if (best_cn < cost) {
+#pragma unroll
                 for (int k = 0; k < N; k++) { z[k] = best_zn[k]; r[k] = best_rn[k]; }
                 cost = best_cn;
                 accepted = true;

@@ -10,7 +10,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "flight.jl_amd"))
 import flightbatch as fb  # noqa: E402
 
-n = 1 << 19
+n = int(os.environ.get("FB_BENCH_N", 1 << 19))
 for ratio in ([int(a) for a in sys.argv[1:]] or [1, 2, 5, 10, 50]):
     w = fb.Cessna172Xv2World(n)
     w.set_params(wind_ned=(1.0, 0.5, 0.0))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): PMC passes (own runs, kernel-trace only) of the Cessna172Xv2 airborne stepper
-# k_step_air<0, true, false> on bench.py's extra.x2 configuration -> gpurun_out/prof_x2_$TAG/${TAG}_x2_counters.json
+# (k_step_duo<0, true>; with FLIGHTBATCH_DUO=0: k_step_air<0, true, false>) on bench.py's extra.x2 configuration -> gpurun_out/prof_x2_$TAG/${TAG}_x2_counters.json
 # (copied into profiles/ by hand; bench.py quotes extra.x2.roofline_valu from it when its source hash matches the tree).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_x2_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -23,11 +23,12 @@ N, INNER = 1 << 19, 50
 c = collections.defaultdict(list); dur = []
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_step_air<0, true, false>" in r["Kernel_Name"]:
+        if "k_step_duo<0, true>" in r["Kernel_Name"] or "k_step_air<0, true, false>" in r["Kernel_Name"]:
+            kname = r["Kernel_Name"]
             c[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 m = {k: sum(v) / len(v) for k, v in c.items()}
-res = {"kernel": "k_step_air<0, true, false>", "n": N, "inner": INNER, "ctl_ratio": 2, "tag": "$TAG", "source_hash": ge.source_hash(), "counters_mean_per_launch": m}
+res = {"kernel": kname, "n": N, "inner": INNER, "ctl_ratio": 2, "tag": "$TAG", "source_hash": ge.source_hash(), "counters_mean_per_launch": m}
 flops = 64 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2 * m["SQ_INSTS_VALU_FMA_F64"] + m["SQ_INSTS_VALU_TRANS_F64"])
 res["fp64_flops_per_launch"] = flops
 res["fp64_flops_per_aircraft_step"] = flops / (N * INNER)
