@@ -280,7 +280,6 @@ DUO_MARK(1, 6);   // engine head done
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
-        [[maybe_unused]] double ac_raw[12];
         if constexpr (!X) in.fetch_aero(ac);   // (launch constants; Cessna172Xv2: this evaluation's, behind role P's point R below)
         double alpha = 0, beta = 0, cos_al = 1, sin_al = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
@@ -301,20 +300,26 @@ DUO_MARK(1, 6);   // engine head done
         const double i2V = 1 / (2 * V);
         const double ad_nd = clampd(afd * c * i2V, -0.04, 0.04);
         const double al = clampd(alpha, -0.1, 0.36), be = clampd(beta, -0.2, 0.2);
-        if constexpr (X) {
-            // Cessna172Xv2: role P has formed this evaluation's deflection-only sums ahead of its point R (which releases global memory there):
-            // the fetch is in flight while the knots are located
-            emit.xwait(DUO_PT_R);
-            in.fetch_aero_raw(ac_raw);
-            __builtin_amdgcn_sched_barrier(0);   // (the loads above are issued before the knot scans, their first use stands behind them)
-        }
+        if constexpr (X) emit.xwait(DUO_PT_R);   // Cessna172Xv2: role P has put this evaluation's deflection-only sums into the panel ahead of its point R
         const loc l_al26 = grid_locate<26, true, AUX_AL26>(A + AT_CD_ALPHA_K, RA + AT_CD_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CD_ALPHA_K), T.gk);
         const loc l_al17 = grid_locate<17, true, AUX_AL17>(A + AT_CL_ALPHA_K, RA + AT_CL_ALPHA_K, al, true, true, gkp(LDS_AERO + AT_CL_ALPHA_K), T.gk);
         const loc l_al2 = grid_locate<2, true>(A + AT_ALPHA2_K, RA + AT_ALPHA2_K, al, true, true, gkp(LDS_AERO + AT_ALPHA2_K));
         const loc l_be3 = grid_locate<3, true>(A + AT_CY_BETA_K, RA + AT_CY_BETA_K, be, true, true, gkp(LDS_AERO + AT_CY_BETA_K));
         const loc l_bu = grid_locate<3, true>(A + AT_UNIT3_K, RA + AT_UNIT3_K, be, true, true, gkp(LDS_AERO + AT_UNIT3_K));
         DUO_MARK(2, 3);   // knot locations
-        if constexpr (X) { __builtin_amdgcn_sched_barrier(0); In::aero_from_raw(ac_raw, ac); }
+        if constexpr (X) {
+            // the evaluation's sums from the panel; the four that are linear in the deflections formed here (InputsAgg::sum_aero's expressions)
+            lds_cptr sp = in.pld_l;
+            auto S0_ = [&](int k) -> double { return T.gk[LDS_AERO + AT_SCALARS + k]; };
+            const double de = sp[4 * 256], da = sp[5 * 256], dr = sp[6 * 256];
+            const uint64_t iw = __builtin_bit_cast(uint64_t, sp[9 * 256]);
+            ac.cd_in = sp[0]; ac.cd_df = sp[1 * 256]; ac.cl_df = sp[2 * 256]; ac.cm_in = sp[3 * 256];
+            ac.cy_in = S0_(AS_CY_DR) * dr + S0_(AS_CY_DA) * da;
+            ac.cl_in = S0_(AS_CL_DE) * de;
+            ac.croll_in = S0_(AS_Cl_DA) * da + S0_(AS_Cl_DR) * dr;
+            ac.cn_in = S0_(AS_CN_DR) * dr + S0_(AS_CN_DA) * da;
+            ac.l_df4 = {(int)(uint32_t)iw, sp[7 * 256]}; ac.l_df2 = {(int)(uint32_t)(iw >> 32), sp[8 * 256]};
+        }
         const loc l_stall = {0, stall ? 1.0 : 0.0};
         const loc l_df4 = ac.l_df4, l_df2 = ac.l_df2;
         // the lookups on those axes alone
@@ -327,6 +332,7 @@ DUO_MARK(1, 6);   // engine head done
         if constexpr (!X) emit.xwait(DUO_PT_R);   // ----- role P's point R: it has read q_ew, h_e (the kinematics rows may be rewritten) and finished its previous
                                 // evaluation (the fuel row, which it emits last of all, is there; it will not emit it again before this wave's X) -----
         const double x_fuel = x[FB_X_FUEL];
+        if constexpr (X) in.fetch_pld_raw(const_cast<double(&)[10]>(in.pldv));   // (the payload's sums: in flight behind the kinematics block, consumed by the mass properties)
         DUO_MARK(2, 5);   // past R
 
         // ----- kinematics derivatives (kinematics.jl:181-242; geodesy.jl:125-129) -----

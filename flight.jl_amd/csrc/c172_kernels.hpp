@@ -1067,6 +1067,13 @@ struct InputsDuoD {
     __device__ __forceinline__ double get_pld_M() const { return pld_l[0]; }
     __device__ __forceinline__ double get_pld_Mr(int k) const { return pld_l[(1 + k) * DUO_B]; }
     __device__ __forceinline__ double get_pld_J(int k) const { return pld_l[(4 + k) * DUO_B]; }
+    // Cessna172Xv2 (the two uses of panel and memory rows are exchanged there: the payload's ten sums — launch constants — come from the rows
+    // of KArgs::duo_pld, like the Sv0 instance's aerodynamic constants, and the LDS panel carries the evaluation's aerodynamic sums from role P):
+    static constexpr int SUMS_ROWS = 10;   // cd_in cd_df cl_df cm_in | de da dr | w_df4 w_df2 | the two table intervals in one word
+    __device__ __forceinline__ void fetch_pld_raw(double (&v)[10]) const {
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = aero_g[(int64_t)k * n];
+    }
     __device__ __forceinline__ void fetch_aero(AeroC& c) const {
         double v[DUO_NCONST];
         fetch_aero_raw(v);
@@ -1081,6 +1088,14 @@ struct InputsDuoD {
         c.cd_in = v[0]; c.cd_df = v[1]; c.cy_in = v[2]; c.cl_in = v[3]; c.cl_df = v[4]; c.croll_in = v[5]; c.cm_in = v[6]; c.cn_in = v[7];
         c.l_df4 = {(int)v[8], v[9]}; c.l_df2 = {(int)v[10], v[11]};
     }
+};
+// role D's inputs in the Cessna172Xv2 instance: InputsDuoD with the payload's sums in registers (fetched from memory ahead of the kinematics
+// block, consumed by the mass properties behind it)
+struct InputsDuoDX : InputsDuoD {
+    double pldv[10];
+    __device__ __forceinline__ double get_pld_M() const { return pldv[0]; }
+    __device__ __forceinline__ double get_pld_Mr(int k) const { return pldv[1 + k]; }
+    __device__ __forceinline__ double get_pld_J(int k) const { return pldv[4 + k]; }
 };
 // How the two waves of a PAIR of the wave-specialised stepper (role P: wave w, role D: wave w + 4, the same 64 aircraft) keep in step.
 // Nothing crosses pairs, so they do not meet at workgroup barriers — behind s_barrier a pair also waited for the three pairs on the other
@@ -1242,7 +1257,8 @@ struct DuoEmit {
     }
     __device__ __forceinline__ void xput(int k, double v) const { if (k < 6) xov_l[k * DUO_B + t] = v; else xch_l[(k - 6) * DUO_B + t] = v; }
     __device__ __forceinline__ double xget(int k) const { return k < 6 ? xov_l[k * DUO_B + t] : xch_l[(k - 6) * DUO_B + t]; }
-    __device__ __forceinline__ void xpub(int k) const { duo_publish<X>(*sync, k); }
+    // (Cessna172Xv2: a tapped evaluation hands values over through global memory too — role P's tap rows are released at its point W)
+    __device__ __forceinline__ void xpub(int k) const { if (X && tap && ROLE == 1) duo_publish<true>(*sync, k); else duo_publish<false>(*sync, k); }
     __device__ __forceinline__ void xwait(int k) const { duo_wait(*sync, k); }
 };
 // every state row of an airborne aircraft belongs to exactly one role, and a role's rows fill its stage-sum slots exactly once
@@ -1388,7 +1404,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
         [[maybe_unused]] const double z0 = dt / ACT_TAU;
         // Cessna172Xv2: the deflection-only aerodynamic sums (InputsAgg::sum_aero) of the surface actuators' positions at stage `stg_for`, for
-        // role D, through the rows of KArgs::duo_pld (role D fetches them behind this role's point R, which releases global memory too). Formed
+        // role D, through the LDS panel that carries the payload's sums in the Sv0 instance (role D reads them behind this role's point R). Formed
         // for every lane, running or not, from the lane's own actuator registers — so what is in memory is valid for the whole wave — and
         // formed AHEAD: at the end of an iteration for the stage that normally follows, while role D finishes its evaluation and keeps the
         // book; at the head of an evaluation only when that guess was wrong (a re-evaluation of k1, or new commands from a control update).
@@ -1405,15 +1421,14 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             InputsAgg ia;
             ia.de = ix.get_de(); ia.da = ix.get_da(); ia.dr = ix.get_dr(); ia.df = ix.get_df();
             ia.sum_aero((lds_cptr)lds + LDS_AERO + lds_off, (lds_cptr)rk + LDS_AERO + lds_off);
-            const double ac[DUO_NCONST] = {ia.cd_in, ia.cd_df, ia.cy_in, ia.cl_in, ia.cl_df, ia.croll_in, ia.cm_in, ia.cn_in,
-                                           (double)ia.l_df4.i, ia.l_df4.w, (double)ia.l_df2.i, ia.l_df2.w};
-            if (valid) {
-                int64_t il = i;
-                asm volatile("" : "+v"(il));   // (opaque: the row addresses are formed here — hoisted, they are spilled and reloaded)
-                double* const g = a.duo_pld + il;
+            // ten rows of the panel: the sums that need a table (cd_in, cd_df, cl_df, cm_in), the three deflections the linear ones are formed from
+            // by role D (cy_in, cl_in, croll_in, cn_in: seven multiply-adds with scalar-loaded derivatives — InputsAgg::sum_aero's expressions),
+            // the flap-axis weights and, in one word, the two intervals
+            const uint64_t iw = (uint64_t)(uint32_t)ia.l_df4.i | ((uint64_t)(uint32_t)ia.l_df2.i << 32);
+            const double sv[InputsDuoD::SUMS_ROWS] = {ia.cd_in, ia.cd_df, ia.cl_df, ia.cm_in, ia.de, ia.da, ia.dr, ia.l_df4.w, ia.l_df2.w, __builtin_bit_cast(double, iw)};
+            lds_ptr sp = (lds_ptr)pld_l + t + lds_off;
 #pragma unroll
-                for (int k = 0; k < DUO_NCONST; k++) g[(int64_t)k * a.n] = ac[k];
-            }
+            for (int k = 0; k < InputsDuoD::SUMS_ROWS; k++) sp[k * B] = sv[k];
             sums_for = stg_for;
         };
 #pragma unroll 1
@@ -1493,7 +1508,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                         }
                     }
                 }
-            } else duo_publish<X>(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
+            } else duo_publish(sy, DUO_PT_W);   // (an evaluation nobody runs: role D must not wait for it)
             if constexpr (X) {
                 if (tap) {
                     // f_periodic!(avionics, vehicle), the longitudinal half: role D has run f_step! on x_{n+1} and written the flags (DUO_F_CTL: the
@@ -1563,11 +1578,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 InputsXAgg in0;
                 in0.xa = nullptr; in0.u_glob = a.u + i; in0.n = a.n; in0.ui = a.ui[i];
                 sum_payload_of(in0);
-                pld_l[t] = in0.pld_M;
+                {   // the payload's sums: launch constants, to the rows role D fetches them from at every evaluation (the panel is role P's here)
+                    const double pv[10] = {in0.pld_M, in0.pld_Mr[0], in0.pld_Mr[1], in0.pld_Mr[2], in0.pld_J[0], in0.pld_J[1], in0.pld_J[2], in0.pld_J[3], in0.pld_J[4], in0.pld_J[5]};
 #pragma unroll
-                for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
-#pragma unroll
-                for (int k = 0; k < 6; k++) pld_l[(4 + k) * B + t] = in0.pld_J[k];
+                    for (int k = 0; k < 10; k++) a.duo_pld[(int64_t)k * a.n + i] = pv[k];
+                }
                 in.ui = in0.ui;
                 if (a.k1) a.k1_valid[i] = 0;   // (nothing is carried across launches here; the ground-capable pass evaluates its own k1)
                 if (a.ctl_ratio > 0 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
@@ -1600,11 +1615,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     bool pending_cb = false, redoing = false, exit_ = __builtin_amdgcn_ballot_w64(dst_l[t] & D_ALIVE) == 0;
     [[maybe_unused]] bool tap_now = false, cmd_put = false;   // Cessna172Xv2: this evaluation is tapped / the update before it has put new lateral commands
     if ((threadIdx.x & 63) == 0) ctrl_l[pair] = exit_ ? DUO_C_EXIT : 0;
-    if constexpr (!X) __threadfence();   // (this lane's aerodynamic constants are read back from memory by this lane)
+    __threadfence();   // (this lane's launch constants — Sv0: aerodynamic, Xv2: payload — are read back from memory by this lane)
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
-        duo_publish<X>(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
+        duo_publish(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
         DUO_MARK(2, 0);
         if (exit_) break;
         const StageK sk = stage_k(stage);
@@ -1618,15 +1633,15 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         if (__builtin_amdgcn_ballot_w64(run) != 0) {
             if (run) {
                 const int d0 = dst_l[t];
-                InputsDuoD inl = in;
+                typename std::conditional<X, InputsDuoDX, InputsDuoD>::type inl;
+                static_cast<InputsDuoD&>(inl) = in;
                 inl.aero_g = in.aero_g + lds_off; inl.pld_l = in.pld_l + lds_off;
                 if constexpr (X) {
-                    // base and stride of the sums' rows, read from the kernel's arguments HERE, at the head of the evaluation (scalar loads that
-                    // complete long before the fetch behind point R: held in SGPRs across the whole loop they are spilled, and re-read in
-                    // front of the fetch they are two exposed round trips)
+                    // base and stride of the payload rows, read from the kernel's arguments HERE, at the head of the evaluation (scalar loads that
+                    // complete long before the fetch: held in SGPRs across the whole loop they are spilled)
                     const kargs_cptr ka = kernarg();
                     int64_t il = i;
-                    asm volatile("" : "+v"(il));   // (see role P)
+                    asm volatile("" : "+v"(il));   // (opaque: the row addresses are formed here — hoisted, they are spilled and reloaded)
                     inl.aero_g = ka->duo_pld + il;
                     inl.n = ka->n;
                 }
@@ -1642,7 +1657,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
 #endif
             }
-        } else duo_publish<X>(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
+        } else duo_publish(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
         // (f_step!, below, modifies x_{n+1} in place at the end of a step's last evaluation: role P has read what it reads of it — its
         // point R, which this wave has waited for in the evaluation)
         int d = dst_l[t];

@@ -169,8 +169,11 @@ def test_x2_duo_and_air_steppers_agree(fb, n, spl, kin):
     a, b = out[False], out[True]
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["s"], b["s"])
     live = a["ok"] & (a["status"] == 0)
-    he = {"WA": 20, "ECEF": 19, "NED": 17}[kin]
-    perm_he = he if he < K["FB_X2_ACT"] else he   # (the altitude row sits below the actuator block in the C ABI's order too)
+    # C ABI row (reference order: the actuators behind the power plant, the mechanisation's unused rows dropped) of the device's altitude row
+    perm = [k if k < K["FB_X2_ACT"] else (27 + k - K["FB_X2_ACT"] if k < K["FB_X2_KIN"] else k - K["FB_NACT"]) for k in range(34)]
+    perm = [r for r in perm if r not in {"WA": (), "ECEF": (20,), "NED": (18, 19, 20)}[kin]]
+    perm_he = perm.index({"WA": 20, "ECEF": 19, "NED": 17}[kin])
+    assert a["x"].shape[0] == len(perm)
     landed = live & (a["x"][perm_he] - h_trn < 8.0)
     flying = live & ~landed
     assert flying.sum() > 0.4 * n and (~cruise & live).sum() > 0.1 * n
