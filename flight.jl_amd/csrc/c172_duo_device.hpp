@@ -280,6 +280,7 @@ DUO_MARK(1, 6);   // engine head done
         const double TAS = norm(v_wb_b);
         // ----- aerodynamics, the part that needs no atmosphere: airflow angles, filters, table locations (c172.jl:307-340) -----
         AeroC ac;
+        [[maybe_unused]] double x2_de = 0, x2_da = 0, x2_dr = 0;
         if constexpr (!X) in.fetch_aero(ac);   // (launch constants; Cessna172Xv2: this evaluation's, behind role P's point R below)
         double alpha = 0, beta = 0, cos_al = 1, sin_al = 0;
         if (TAS > 0.1) {  // also covers get_airflow_angles' own ‖v‖ < 0.1 guard (atmosphere.jl:329-337)
@@ -310,14 +311,9 @@ DUO_MARK(1, 6);   // engine head done
         if constexpr (X) {
             // the evaluation's sums from the panel; the four that are linear in the deflections formed here (InputsAgg::sum_aero's expressions)
             lds_cptr sp = in.pld_l;
-            auto S0_ = [&](int k) -> double { return T.gk[LDS_AERO + AT_SCALARS + k]; };
-            const double de = sp[4 * 256], da = sp[5 * 256], dr = sp[6 * 256];
+            x2_de = sp[4 * 256]; x2_da = sp[5 * 256]; x2_dr = sp[6 * 256];   // (the four linear sums are formed where the scalar derivatives are loaded, behind A)
             const uint64_t iw = __builtin_bit_cast(uint64_t, sp[9 * 256]);
             ac.cd_in = sp[0]; ac.cd_df = sp[1 * 256]; ac.cl_df = sp[2 * 256]; ac.cm_in = sp[3 * 256];
-            ac.cy_in = S0_(AS_CY_DR) * dr + S0_(AS_CY_DA) * da;
-            ac.cl_in = S0_(AS_CL_DE) * de;
-            ac.croll_in = S0_(AS_Cl_DA) * da + S0_(AS_Cl_DR) * dr;
-            ac.cn_in = S0_(AS_CN_DR) * dr + S0_(AS_CN_DA) * da;
             ac.l_df4 = {(int)(uint32_t)iw, sp[7 * 256]}; ac.l_df2 = {(int)(uint32_t)(iw >> 32), sp[8 * 256]};
         }
         const loc l_stall = {0, stall ? 1.0 : 0.0};
@@ -426,6 +422,12 @@ DUO_MARK(1, 6);   // engine head done
         const double dh_nd = (h_o - env.h_trn) / b;
         const loc l_ge = grid_locate<13, true, AUX_GE>(A + AT_GE_K, RA + AT_GE_K, dh_nd, true, true, gkp(LDS_AERO + AT_GE_K), T.gk);
         auto S_ = [&](int k) -> double { return FB_SCALAR_DERIVS ? T.gk[LDS_AERO + AT_SCALARS + k] : A[AT_SCALARS + k]; };
+        if constexpr (X) {   // InputsAgg::sum_aero's expressions for the sums that are linear in the deflections
+            ac.cy_in = S_(AS_CY_DR) * x2_dr + S_(AS_CY_DA) * x2_da;
+            ac.cl_in = S_(AS_CL_DE) * x2_de;
+            ac.croll_in = S_(AS_Cl_DA) * x2_da + S_(AS_Cl_DR) * x2_dr;
+            ac.cn_in = S_(AS_CN_DR) * x2_dr + S_(AS_CN_DA) * x2_da;
+        }
         const double C_D = ac.cd_in + lerp1(A + AT_CD_GE_V, l_ge) * cd_al + cd_be;
         const double C_Y = ac.cy_in + cy_be + cy_p * p_nd + cy_r * r_nd;
         const double C_L = lerp1(A + AT_CL_GE_V, l_ge) * cl_al + ac.cl_in + S_(AS_CL_Q) * q_nd + S_(AS_CL_ALPHA_DOT) * ad_nd;
