@@ -329,7 +329,7 @@ def test_x2_ecef_and_ned_mechanisations(fb, oracle, gains, kin):
     with the same mechanisation: f_init! (trim, actuators, control laws), f_ode!, ten seconds of closed-loop flight with every aircraft
     in its own pair of modes, and — for the ground-capable instance of that mechanisation — steep autopilot descents onto a runway:
     hard landings that end in GroundCrash and softer ones that roll out, status word, step and place of every termination included;
-    the descent is run twice and must repeat bit for bit (what a spill-placement fault of the compiler would break: DESIGN.md §4)."""
+    the descent is run twice and must repeat bit for bit (what a spill-placement fault of the compiler would break: docs/design/k_step_air.md)."""
     K = fb.K
     perm = abi_to_dev_rows(K, kin)
     nx = 34 - {"WA": 0, "ECEF": 1, "NED": 3}[kin]

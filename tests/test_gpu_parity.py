@@ -684,7 +684,7 @@ def test_takeoff_ground_to_air_handover(fb, oracle):
 @pytest.mark.parametrize("eps, tol", [(0.0, 2e-12), (1e-8, 2e-12), (1e-6, 2e-9)])
 def test_gravity_at_com_with_off_norm_states(fb, oracle, eps, tol):
     """The kernels get the gravity vector at the centre of mass from a first-order expansion about the body origin instead of the
-    reference's ECEF->geodetic conversion and local-level quaternion, carrying the state quaternions' norm errors
+    reference's ECEF->geodetic conversion and local-level quaternion (docs/design/k_step_air.md), carrying the state quaternions' norm errors
     (~1e-8 at RK stages) to first order: g_c and the accelerations must match the oracle to rounding at eps = 1e-8, and to
     O(eps^2 g) at a norm error a hundred times larger than any that occurs."""
     n = 16384

@@ -1,5 +1,5 @@
 """tools/check_isa_spills.py — the build-time guard against spill code placed before the exec restore of a control-flow join block
-("A compiler bug the build now guards against") — on hand-written assembly fragments: the patterns the two observed
+(docs/design/k_step_air.md, "A compiler bug the build now guards against") — on hand-written assembly fragments: the patterns the two observed
 miscompiles had must be reported, the harmless look-alikes must not."""
 import importlib.util
 import os
