@@ -1408,7 +1408,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         // for every lane, running or not, from the lane's own actuator registers — so what is in memory is valid for the whole wave — and
         // formed AHEAD: at the end of an iteration for the stage that normally follows, while role D finishes its evaluation and keeps the
         // book; at the head of an evaluation only when that guess was wrong (a re-evaluation of k1, or new commands from a control update).
-        [[maybe_unused]] int sums_for = -1;   // wave-uniform: the stage whose sums are in memory (-1: none)
+        [[maybe_unused]] int sums_for = -1;   // wave-uniform: the stage whose sums are in the panel (-1: none)
+        [[maybe_unused]] double df_last = __builtin_nan(""), cm_df = 0;   // per lane: the flap deflection the flap-dependent rows were formed for; its C_m term
         [[maybe_unused]] auto form_sums = [&](int stg_for, int lds_off) {
             double z = z0;
             asm volatile("" : "+v"(z));
@@ -1418,17 +1419,30 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
             xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
             const InputsX ix = {xa_s, nullptr, a.n, in.ui};
-            InputsAgg ia;
-            ia.de = ix.get_de(); ia.da = ix.get_da(); ia.dr = ix.get_dr(); ia.df = ix.get_df();
-            ia.sum_aero((lds_cptr)lds + LDS_AERO + lds_off, (lds_cptr)rk + LDS_AERO + lds_off);
-            // ten rows of the panel: the sums that need a table (cd_in, cd_df, cl_df, cm_in), the three deflections the linear ones are formed from
-            // by role D (cy_in, cl_in, croll_in, cn_in: seven multiply-adds with scalar-loaded derivatives — InputsAgg::sum_aero's expressions),
-            // the flap-axis weights and, in one word, the two intervals
-            const uint64_t iw = (uint64_t)(uint32_t)ia.l_df4.i | ((uint64_t)(uint32_t)ia.l_df2.i << 32);
-            const double sv[InputsDuoD::SUMS_ROWS] = {ia.cd_in, ia.cd_df, ia.cl_df, ia.cm_in, ia.de, ia.da, ia.dr, ia.l_df4.w, ia.l_df2.w, __builtin_bit_cast(double, iw)};
+            // InputsAgg::sum_aero's expressions, term by term; the flap-dependent ones (two table locations, three lookups, five of the ten
+            // rows) only when a lane's flap position has changed since they were formed — flaps move in seconds, a stage follows a stage in
+            // microseconds
+            const double de = ix.get_de(), da = ix.get_da(), dr = ix.get_dr(), df = ix.get_df();
+            lds_cptr A = (lds_cptr)lds + LDS_AERO + lds_off, RA = (lds_cptr)rk + LDS_AERO + lds_off;
+            auto S_ = [&](int k) -> double { return A[AT_SCALARS + k]; };
             lds_ptr sp = (lds_ptr)pld_l + t + lds_off;
-#pragma unroll
-            for (int k = 0; k < InputsDuoD::SUMS_ROWS; k++) sp[k * B] = sv[k];
+            if (__builtin_amdgcn_ballot_w64(!(df == df_last)) != 0) {
+                const loc l_df4 = grid_locate<4>(A + AT_DF4_K, RA + AT_DF4_K, df, true, true);
+                const loc l_df2 = grid_locate<2>(A + AT_DF2_K, RA + AT_DF2_K, df, true, true);
+                cm_df = lerp1(A + AT_CM_DF_V, l_df4);
+                const uint64_t iw = (uint64_t)(uint32_t)l_df4.i | ((uint64_t)(uint32_t)l_df2.i << 32);
+                sp[1 * B] = lerp1(A + AT_CD_DF_V, l_df4); sp[2 * B] = lerp1(A + AT_CL_DF_V, l_df4);
+                sp[7 * B] = l_df4.w; sp[8 * B] = l_df2.w; sp[9 * B] = __builtin_bit_cast(double, iw);
+                df_last = df;
+            }
+            const loc l_de = grid_locate<3>(A + AT_UNIT3_K, RA + AT_UNIT3_K, de, true, true);
+            // ten rows of the panel: the sums that need a table (0 cd_in, 1 cd_df, 2 cl_df, 3 cm_in), the three deflections the linear ones are formed
+            // from by role D (4-6: cy_in, cl_in, croll_in, cn_in are seven multiply-adds with scalar-loaded derivatives there), the flap-axis
+            // weights (7, 8) and, in one word, the two intervals (9)
+            sp[0] = S_(AS_CD_ZERO) + lerp1(A + AT_CD_DE_V, l_de);
+            sp[3 * B] = S_(AS_CM_ZERO) + S_(AS_CM_DE) * de + cm_df;
+            sp[4 * B] = de; sp[5 * B] = da; sp[6 * B] = dr;
+            static_assert(InputsDuoD::SUMS_ROWS == 10, "panel rows");
             sums_for = stg_for;
         };
 #pragma unroll 1

@@ -163,7 +163,11 @@ def test_x2_duo_and_air_steppers_agree(fb, n, spl, kin):
         cu[K["FB_CU_EAS_REF"]] += 2.0; cu[K["FB_CU_PHI_REF"]] += 0.2; cu[K["FB_CU_H_REF"]] += 30.0
         w.cu = cu
         fb._lib.check(fb.lib.fb_set_status(w._h, st0.ctypes.data_as(fb._lib.C.POINTER(fb._lib.C.c_int32))))
-        fb.step(sim, 4.0); w.sync()
+        fb.step(sim, 2.0)
+        uu = w.u                                            # flaps on the move for half of the cruising aircraft (the flap actuator follows its command
+        uu[K["FB_U_FLAPS"]] = np.where(cruise & (np.arange(n) % 2 == 0), 0.5, uu[K["FB_U_FLAPS"]])   # with a 50 ms lag: role P re-forms the flap-dependent sums every stage)
+        w.u = uu
+        fb.step(sim, 2.0); w.sync()
         out[duo] = dict(x=w.x, cs=w.cs, s=w.s, status=w.status, ok=ok)
         w.close()
     a, b = out[False], out[True]
