@@ -121,6 +121,7 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
             }
         }
         emit.xpub(DUO_PT_R);   // ----- point R: state rows read (role D may rewrite the kinematics rows; this wave's previous evaluation is complete) -----
+        if constexpr (X) __builtin_amdgcn_s_setprio(0);   // (Cessna172Xv2: this role ran ahead of role D from the top of its loop to here, see k_step_duo)
         double lat, lon;
         const double N_geoid = geoid_height<true>(T, n_e, lat, lon);
         const double h_o = h_e - N_geoid;

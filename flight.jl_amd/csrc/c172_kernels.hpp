@@ -1327,6 +1327,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #ifndef FB_X2_LON_PRIO
 #define FB_X2_LON_PRIO 3   // Cessna172Xv2: role P's wave during its half of a control update (see there)
 #endif
+#ifndef FB_X2_HEAD_PRIO
+#define FB_X2_HEAD_PRIO 3  // ... and from the top of its loop to its point R
+#endif
+#ifndef FB_X2_SPEC_PRIO
+#define FB_X2_SPEC_PRIO 3  // ... and while it forms the next stage's aerodynamic sums at the end of an iteration
+#endif
     if (role == 2) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_D);
 #ifdef FB_DUO_PRIO_P
     if (role == 1) __builtin_amdgcn_s_setprio(FB_DUO_PRIO_P);
@@ -1450,6 +1456,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             DUO_MARK(1, 15);  // (arrival at the top of the loop, counted from the previous evaluation's start)
             duo_wait(sy, DUO_PT_T);   // role D's control and flag words of this evaluation are written, every row of the previous one emitted
             DUO_MARK(1, 0);
+            if constexpr (X) __builtin_amdgcn_s_setprio(FB_X2_HEAD_PRIO);   // (until its point R: role D reads the evaluation's sums behind it, early in its own evaluation)
             const int c = __builtin_amdgcn_readfirstlane(ctrl_l[pair]);
             const int f = flags_l[t];
             if constexpr (X) {
@@ -1551,7 +1558,13 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 // update has just run: role D's two new commands arrive with the next control word, and the sums are formed then, once
 #ifndef FB_X2_NO_SPECULATION
                 if (tap) sums_for = -1;
-                else form_sums((stg + 1) & 3, lds_off);
+                else {
+                    // (ahead of role D in issue priority: this wave must be back at the top, and through its state reads, before role D needs
+                    // point R — at priority 0 it got there late: stepping alone 8.52 -> 8.33 ms, profiles/r04_x2_update_ab.txt)
+                    __builtin_amdgcn_s_setprio(FB_X2_SPEC_PRIO);
+                    form_sums((stg + 1) & 3, lds_off);
+                    __builtin_amdgcn_s_setprio(0);
+                }
 #endif
             }
             sy.base += NPT;
