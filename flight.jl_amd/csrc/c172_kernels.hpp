@@ -972,8 +972,14 @@ template <int HALF> __device__ __forceinline__ void half_stamp(int k) {
 #define FB_HALF_STAMP(HALF, k) do { } while (0)
 #endif
 // xs: &x_n panel[lane] of the calling workgroup (rows of DUO_B lanes, the airborne row numbering); h_e: the mechanisation's altitude state
+// Inlined into k_step_duo<KIN,true>: as an out-of-line callee each half saved and restored the callee-saved VGPR groups it used through scratch
+// (~170 stores + 170 loads per pair-update, ~9 GB each way per launch); inlined the kernel holds 249 registers and has no scratch frame at all.
+// Same-box alternating A/B (profiles/r04_x2_inline_ab.txt): ratio 2 10.90 -> 10.37 ms, ratio 1 13.9 -> 12.5 ms, ratio 50 8.25 -> 8.35 ms.
+#ifndef FB_X2_HALF_ATTR
+#define FB_X2_HALF_ATTR __forceinline__
+#endif
 template <int HALF>
-__device__ __noinline__ Ctl2 x2_periodic_half(const double* a_cu, double* a_cs, const double* a_gains, const double* a_tap, int64_t a_n, double a_dT, uint32_t o01,
+__device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_cs, const double* a_gains, const double* a_tap, int64_t a_n, double a_dT, uint32_t o01,
                                               uint32_t o23, uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, double h_e, lds_cptr xs) {
     constexpr int B = 256;   // (= DUO_B, defined below)
     using SV = StateLds<B, false>;
