@@ -2019,23 +2019,35 @@ __device__ __forceinline__ void trim_box_gauss_newton(const double (&H)[TRIM_N][
         for (int k = 0; k < N; k++) if (k == rel) fixed[k] = 0;
     }
 }
-// minimises |r(z)|² inside [lo, hi]; returns the final cost, z updated in place
+// The descent that minimises |r(z)|² inside [lo, hi].
 // (every loop over the seven unknowns is unrolled, so that the Jacobians, H, g and the step are indexed by constants: registers / AGPRs
 // instead of 3.8 KB of dynamically indexed scratch; what is passed to the out-of-line trim_resid by pointer — the 7-vectors — stays in
 // memory at fixed offsets)
-__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], double (&z)[TRIM_N], int max_iter) {
+// One aircraft's descent between iterations: what trim_tr_minimize's loop carries (k_trim keeps one per lane, so that a lane whose aircraft
+// has converged takes the next aircraft while its neighbours go on iterating)
+struct TrimLane { double z[TRIM_N], r[TRIM_N], cost, D; int it; };
+constexpr double TRIM_COST_FLOOR = 1e-27;
+__device__ __forceinline__ bool trim_tr_goes_on(const TrimLane& S, int max_iter) { return S.it < max_iter && S.cost > TRIM_COST_FLOOR && S.D > 1e-13; }
+__device__ __noinline__ void trim_tr_begin(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], TrimLane& S) {
     constexpr int N = TRIM_N;
-    const double fd = 1e-6, cost_floor = 1e-27;
-    double r[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) z[k] = fmin(fmax(z[k], lo[k]), hi[k]);
-    trim_resid(p, z, env, T, r);
+    for (int k = 0; k < N; k++) S.z[k] = fmin(fmax(S.z[k], lo[k]), hi[k]);
+    trim_resid(p, S.z, env, T, S.r);
     double cost = 0;
 #pragma unroll
-    for (int k = 0; k < N; k++) cost += r[k] * r[k];
-    double D = 0.05;   // the reference's initial_step (c172.jl:919)
-#pragma unroll 1
-    for (int it = 0; it < max_iter && cost > cost_floor && D > 1e-13; it++) {
+    for (int k = 0; k < N; k++) cost += S.r[k] * S.r[k];
+    S.cost = cost;
+    S.D = 0.05;   // the reference's initial_step (c172.jl:919)
+    S.it = 0;
+}
+// one iteration (Jacobian, trial steps until one is accepted): false when no step was accepted — the descent has ended
+__device__ __noinline__ bool trim_tr_iterate(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], TrimLane& S) {
+    constexpr int N = TRIM_N;
+    const double fd = 1e-6;
+    double (&z)[N] = S.z;
+    double (&r)[N] = S.r;
+    double cost = S.cost, D = S.D;
+    {
         double Jc[N][N], Jf[N][N], Jb[N][N];
         bool kink[N], any_kink = false;
 #pragma unroll
@@ -2165,31 +2177,128 @@ __device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, 
                 D = 0.25 * fmin(D, best_dinf);
             }
         }
-        if (!accepted) break;
+        S.cost = cost; S.D = D;
+        return accepted;
     }
-    return cost;
 }
-// One lane trims one aircraft: f_init!(vehicle, TrimParameters) (c172.jl:883-942).
-__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out) {
-    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
-    __shared__ double rk[LDS_RK_DOUBLES];
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
-    const int64_t n = a.n;
-    TrimP p;
+// minimises |r(z)|² inside [lo, hi]; returns the final cost, z updated in place
+__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], double (&z)[TRIM_N], int max_iter) {
+    TrimLane S;
+#pragma unroll
+    for (int k = 0; k < TRIM_N; k++) S.z[k] = z[k];
+    trim_tr_begin(p, env, T, lo, hi, S);
+#pragma unroll 1
+    for (; trim_tr_goes_on(S, max_iter); S.it++)
+        if (!trim_tr_iterate(p, env, T, lo, hi, S)) break;
+#pragma unroll
+    for (int k = 0; k < TRIM_N; k++) z[k] = S.z[k];
+    return S.cost;
+}
+// f_init!(vehicle, TrimParameters) (c172.jl:883-942), one lane per aircraft at a time.
+__device__ __forceinline__ void trim_load_params(TrimP& p, const double* tp, int64_t n, int64_t i) {
     p.n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
     p.h_e = tp[(int64_t)FB_TP_H_E * n + i]; p.psi_nb = tp[(int64_t)FB_TP_PSI_NB * n + i]; p.EAS = tp[(int64_t)FB_TP_EAS * n + i];
     p.gamma_wb_n = tp[(int64_t)FB_TP_GAMMA_WB_N * n + i]; p.psi_wb_dot = tp[(int64_t)FB_TP_PSI_WB_DOT * n + i];
     p.theta_wb_dot = tp[(int64_t)FB_TP_THETA_WB_DOT * n + i]; p.beta_a = tp[(int64_t)FB_TP_BETA_A * n + i];
     p.fuel_load = tp[(int64_t)FB_TP_FUEL_LOAD * n + i]; p.mixture = tp[(int64_t)FB_TP_MIXTURE * n + i]; p.flaps = tp[(int64_t)FB_TP_FLAPS * n + i];
     for (int k = 0; k < 5; k++) p.payload[k] = tp[(int64_t)(FB_TP_PAYLOAD + k) * n + i];
-    const double lo[7] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                 // c172.jl:901-908
-    const double hi[7] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
+}
+// assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s, the trim state in ts
+__device__ __noinline__ void trim_leave(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
+    const int64_t n = a.n;
+    double x[FB_NX], uraw[FB_NU];
+    Inputs in;
+    trim_assign(p, z, a.env, T, x, in, uraw);
+    for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * n + i] = x[k];
+    double* uw = const_cast<double*>(a.u);
+    for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = uraw[k];
+    const_cast<int32_t*>(a.ui)[i] = in.ui;
+    a.s[i] = 0;        // stall = false
+    a.s[n + i] = 2;    // EngineState.running
+    for (int k = 0; k < TRIM_N; k++) ts[(int64_t)k * n + i] = z[k];
+    if (success) success[i] = cost <= 1e-16;   // the reference's criterion: STOPVAL_REACHED, stopval = 1e-16 (c172.jl:926,934)
+    if (cost_out) cost_out[i] = cost;
+}
+constexpr double TRIM_LO[TRIM_N] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                 // c172.jl:901-908
+constexpr double TRIM_HI[TRIM_N] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
+constexpr int TRIM_MAX_ITER = 500;
+#ifndef FB_TRIM_REFILL_MIN
+#define FB_TRIM_REFILL_MIN 8
+#endif
+// The descent from the given trim state, for every aircraft. The aircraft differ in how many iterations they take (bench lattice: 64 to 606
+// residual evaluations, mean 144 — a wave that trimmed 64 aircraft side by side waited for its slowest, ~420), so the kernel is PERSISTENT:
+// a wave takes aircraft from a queue (`next`, zeroed by the host), every lane iterates on its own aircraft, and when FB_TRIM_REFILL_MIN lanes
+// have finished theirs they are served together: results written, the next aircraft taken and begun (one residual evaluation). What a lane
+// computes for an aircraft is trim_tr_minimize's sequence exactly (trim_tr_begin, then trim_tr_iterate while trim_tr_goes_on): the
+// result does not depend on which lane or wave took the aircraft. An aircraft whose descent ends above stopval is left to k_trim_cont
+// (`pending[i]` = 1, nothing else written).
+__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, int32_t* pending) {
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
+    __shared__ double rk[LDS_RK_DOUBLES];
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const int64_t n = a.n;
+    const int lane = threadIdx.x;
+    const double lo[7] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
+    const double hi[7] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
+    TrimP p;
+    TrimLane S;
+    int64_t i = -1;        // the lane's aircraft; with !active: finished, results not yet written
+    bool active = false;
+    bool more = true;      // (wave-uniform) the queue may still hold aircraft
+#pragma unroll 1
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+        const int n_idle = __builtin_popcountll(idle);
+        if (n_idle == 64 || (more && n_idle >= FB_TRIM_REFILL_MIN)) {
+            if (!active && i >= 0) {
+                if (S.cost <= 1e-16) { trim_leave(a, p, S.z, T, ts, success, cost_out, S.cost, i); pending[i] = 0; }
+                else pending[i] = 1;
+                i = -1;
+            }
+            if (more) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(next, (unsigned long long)n_idle);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+                more = base + (unsigned long long)n_idle < (unsigned long long)n;
+                if (!active) {
+                    const int64_t mine = (int64_t)base + __builtin_popcountll(idle & ((1ull << lane) - 1));
+                    if (mine < n) {
+                        i = mine;
+                        trim_load_params(p, tp, n, i);
+                        for (int k = 0; k < TRIM_N; k++) S.z[k] = ts[(int64_t)k * n + i];
+                        trim_tr_begin(p, a.env, T, lo, hi, S);
+                        active = true;
+                    }
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        }
+        if (active) {
+            bool go = trim_tr_goes_on(S, TRIM_MAX_ITER);
+            if (go) { go = trim_tr_iterate(p, a.env, T, lo, hi, S); S.it++; }
+            active = go && trim_tr_goes_on(S, TRIM_MAX_ITER);
+        }
+    }
+}
+// The aircraft k_trim left pending: the descent from TrimState() again (same result), then the continuation in the trim parameters.
+__global__ __launch_bounds__(64) void k_trim_cont(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, const int32_t* pending) {
+    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
+    __shared__ double rk[LDS_RK_DOUBLES];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = i < a.n && pending[i] != 0;
+    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;   // (one wave per block)
+    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+    if (!mine) return;
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const int64_t n = a.n;
+    TrimP p;
+    trim_load_params(p, tp, n, i);
+    const double lo[7] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
+    const double hi[7] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
     double z0[7], z[7];
     for (int k = 0; k < 7; k++) { z0[k] = ts[(int64_t)k * n + i]; z[k] = z0[k]; }
-    double cost = trim_tr_minimize(p, a.env, T, lo, hi, z, 500);
+    double cost = trim_tr_minimize(p, a.env, T, lo, hi, z, TRIM_MAX_ITER);
     if (cost > 1e-16) {
         // continuation from TrimParameters() (c172.jl:806-818); location and heading as requested (the trim barely depends on them)
         const double d0[15] = {1050.0, 50.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 75.0, 75.0, 0.0, 0.0, 50.0, 0.0};
@@ -2220,19 +2329,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
         }
         if (good && c < cost) { cost = c; for (int k = 0; k < 7; k++) z[k] = zc[k]; }
     }
-    // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s
-    double x[FB_NX], uraw[FB_NU];
-    Inputs in;
-    trim_assign(p, z, a.env, T, x, in, uraw);
-    for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * n + i] = x[k];
-    double* uw = const_cast<double*>(a.u);
-    for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = uraw[k];
-    const_cast<int32_t*>(a.ui)[i] = in.ui;
-    a.s[i] = 0;        // stall = false
-    a.s[n + i] = 2;    // EngineState.running
-    for (int k = 0; k < 7; k++) ts[(int64_t)k * n + i] = z[k];
-    if (success) success[i] = cost <= 1e-16;   // the reference's criterion: STOPVAL_REACHED, stopval = 1e-16 (c172.jl:926,934)
-    if (cost_out) cost_out[i] = cost;
+    trim_leave(a, p, z, T, ts, success, cost_out, cost, i);
 }
 
 // f_init!(kinematics::ECEF / ::NED, ic) (kinematics.jl:255-280, 336-364) applied to the WA initial condition k_trim leaves
