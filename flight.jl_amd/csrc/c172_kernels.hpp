@@ -1827,13 +1827,31 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 }
 
 // ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------
+// Diagnostic builds (-DFB_STAMP -DFB_TRIM_STAMP, tools/stamp_trim.py): where the first wave of k_trim spends its cycles — the time since the
+// previous mark goes to bucket 24 + k (0 other, 1 residual evaluations, 2 the active-set solver, 3 serving finished lanes)
+#if defined(FB_STAMP) && defined(FB_TRIM_STAMP)
+__device__ unsigned long long g_trim_last;
+__device__ __forceinline__ void trim_mark(int k) {
+    if (blockIdx.x == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        const int lane = threadIdx.x;
+        if (__builtin_amdgcn_readfirstlane(lane) == lane) {
+            const unsigned long long old = atomicExch(&g_trim_last, t);
+            if (old != 0) { atomicAdd(&g_stamp_acc[24 + k], t - old); atomicAdd(&g_stamp_cnt[24 + k], 1ull); }
+        }
+    }
+}
+#define TRIM_MARK(k) trim_mark(k)
+#else
+#define TRIM_MARK(k) do { } while (0)
+#endif
 struct TrimP {
     v3 n_e;
     double h_e, psi_nb, EAS, gamma_wb_n, psi_wb_dot, theta_wb_dot, beta_a, fuel_load, mixture, flaps, payload[5];
 };
 // assign!(vehicle, params, state): trim unknowns -> (x, u, s)   (c172s.jl:227-263,168-220; c172.jl:825-854;
 // aircraftbase.jl:76-86,110-118; kinematics.jl:155-178)
-__device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const Env& env, const Tables& T, double (&x)[FB_NX], Inputs& in, double (&uraw)[FB_NU]) {
+__device__ __forceinline__ void trim_assign(const TrimP& p, const double* z, const Env& env, const Tables& T, double (&x)[FB_NX], Inputs& in, double (&uraw)[FB_NU]) {
     using namespace c172;
     const double alpha_a = z[FB_TS_ALPHA_A], phi = z[FB_TS_PHI_NB];
     // atmosphere at Ob (ellipsoidal -> orthometric -> geopotential)
@@ -1897,6 +1915,7 @@ __device__ __noinline__ void trim_assign(const TrimP& p, const double* z, const 
 }
 // residuals whose squared sum is the reference's cost (c172.jl:857-867)
 __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) {
+    TRIM_MARK(0);
     double x[FB_NX], xd[FB_NX];
     Inputs in;
     double uraw[FB_NU];
@@ -1907,6 +1926,7 @@ __device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const E
     r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
     r[6] = xd[FB_X_ENG_OMEGA] / c172::w_rated;
+    TRIM_MARK(1);
 }
 // ---- the trim solver ---------------------------------------------------------------------------------------------
 // The reference minimises cost = Σ r² with NLopt's :LN_BOBYQA inside box bounds, initial_step 0.05, stopval 1e-16,
@@ -2123,7 +2143,9 @@ __device__ __noinline__ bool trim_tr_iterate(const TrimP& p, const Env& env, con
                         }
                         tr += H[a][a];
                     }
+                    TRIM_MARK(0);
                     trim_box_gauss_newton(H, g, dl, du, 1e-14 * tr + 1e-300, d);
+                    TRIM_MARK(2);
                     if (cand != 0) break;
                     bool changed = false;
 #pragma unroll
@@ -2251,6 +2273,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
         const int n_idle = __builtin_popcountll(idle);
         if (n_idle == 64 || (more && n_idle >= FB_TRIM_REFILL_MIN)) {
+            TRIM_MARK(0);
             if (!active && i >= 0) {
                 if (S.cost <= 1e-16) { trim_leave(a, p, S.z, T, ts, success, cost_out, S.cost, i); pending[i] = 0; }
                 else pending[i] = 1;
@@ -2272,6 +2295,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                     }
                 }
             }
+            TRIM_MARK(3);
             if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         }
         if (active) {
