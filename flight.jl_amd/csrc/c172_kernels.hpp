@@ -1827,9 +1827,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 }
 
 // ---- trim: f_init!(vehicle, TrimParameters) (FlightApps/src/c172/c172.jl:796-942) --------------
-// Diagnostic builds (-DFB_STAMP -DFB_TRIM_STAMP, tools/stamp_trim.py): where the first wave of k_trim spends its cycles — the time since the
+// Diagnostic builds (-DFB_TRIM_STAMP, tools/stamp_trim.py): where the first wave of k_trim spends its cycles — the time since the
 // previous mark goes to bucket 24 + k (0 other, 1 residual evaluations, 2 the active-set solver, 3 serving finished lanes)
-#if defined(FB_STAMP) && defined(FB_TRIM_STAMP)
+#if defined(FB_TRIM_STAMP)
 __device__ unsigned long long g_trim_last;
 __device__ __forceinline__ void trim_mark(int k) {
     if (blockIdx.x == 0) {
@@ -1914,20 +1914,30 @@ __device__ __forceinline__ void trim_assign(const TrimP& p, const double* z, con
     in.n = 0;
 }
 // residuals whose squared sum is the reference's cost (c172.jl:857-867)
-__device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) {
+// (FB_TRIM_FAST_RHS: the evaluation in the stepping kernels' form — their atan2 / log / sincos, knot scans through scalar loads — instead of
+// the single-call verbs' form with the library's: a third of the instructions, and the trimmed state is the zero of the very arithmetic
+// that steps it. The trim state moves by ~1e-13 against the library form.)
+#ifndef FB_TRIM_FAST_RHS
+#define FB_TRIM_FAST_RHS true
+#endif
+// GROUND = false: the airborne-only evaluation (388 registers against 504); answers FB_ST_INTERNAL_REDO where a wheel could reach the ground
+template <bool GROUND = true>
+__device__ __forceinline__ int32_t trim_resid_body(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) {
     TRIM_MARK(0);
     double x[FB_NX], xd[FB_NX];
     Inputs in;
     double uraw[FB_NU];
     trim_assign(p, z, env, T, x, in, uraw);
     StepAux aux;
-    rhs<FB_KIN_WA>(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, NoSink{});
+    const int32_t st = rhs<FB_KIN_WA, GROUND, FB_TRIM_FAST_RHS>(x, 0, 2, in, env, T, [&](int j, double v) { xd[j] = v; }, aux, NoSink{});
     const double nv = sqrt(x[FB_X_V_EB_B] * x[FB_X_V_EB_B] + x[FB_X_V_EB_B + 1] * x[FB_X_V_EB_B + 1] + x[FB_X_V_EB_B + 2] * x[FB_X_V_EB_B + 2]);
     r[0] = xd[FB_X_V_EB_B] / nv; r[1] = xd[FB_X_V_EB_B + 1] / nv; r[2] = xd[FB_X_V_EB_B + 2] / nv;
     r[3] = xd[FB_X_OMEGA_EB_B]; r[4] = xd[FB_X_OMEGA_EB_B + 1]; r[5] = xd[FB_X_OMEGA_EB_B + 2];
     r[6] = xd[FB_X_ENG_OMEGA] / c172::w_rated;
     TRIM_MARK(1);
+    return st;
 }
+__device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) { trim_resid_body<true>(p, z, env, T, r); }
 // ---- the trim solver ---------------------------------------------------------------------------------------------
 // The reference minimises cost = Σ r² with NLopt's :LN_BOBYQA inside box bounds, initial_step 0.05, stopval 1e-16,
 // maxeval 1e5 (c172.jl:883-942). NLopt is a third-party optimiser; what is kept of it is its behaviour on this
@@ -2226,7 +2236,7 @@ __device__ __forceinline__ void trim_load_params(TrimP& p, const double* tp, int
     for (int k = 0; k < 5; k++) p.payload[k] = tp[(int64_t)(FB_TP_PAYLOAD + k) * n + i];
 }
 // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s, the trim state in ts
-__device__ __noinline__ void trim_leave(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
+__device__ __forceinline__ void trim_leave_body(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
     const int64_t n = a.n;
     double x[FB_NX], uraw[FB_NU];
     Inputs in;
@@ -2241,32 +2251,60 @@ __device__ __noinline__ void trim_leave(const KArgs& a, const TrimP& p, const do
     if (success) success[i] = cost <= 1e-16;   // the reference's criterion: STOPVAL_REACHED, stopval = 1e-16 (c172.jl:926,934)
     if (cost_out) cost_out[i] = cost;
 }
+__device__ __noinline__ void trim_leave(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
+    trim_leave_body(a, p, z, T, ts, success, cost_out, cost, i);
+}
 constexpr double TRIM_LO[TRIM_N] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                 // c172.jl:901-908
 constexpr double TRIM_HI[TRIM_N] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
 constexpr int TRIM_MAX_ITER = 500;
+#ifndef FB_TRIM_GROUND
+#define FB_TRIM_GROUND true   // k_trim's residual with the ground-contact branch compiled in (false: airborne only, aircraft within reach of the ground go to k_trim_cont — measured no faster)
+#endif
 #ifndef FB_TRIM_REFILL_MIN
 #define FB_TRIM_REFILL_MIN 8
 #endif
-// The descent from the given trim state, for every aircraft. The aircraft differ in how many iterations they take (bench lattice: 64 to 606
-// residual evaluations, mean 144 — a wave that trimmed 64 aircraft side by side waited for its slowest, ~420), so the kernel is PERSISTENT:
-// a wave takes aircraft from a queue (`next`, zeroed by the host), every lane iterates on its own aircraft, and when FB_TRIM_REFILL_MIN lanes
-// have finished theirs they are served together: results written, the next aircraft taken and begun (one residual evaluation). What a lane
-// computes for an aircraft is trim_tr_minimize's sequence exactly (trim_tr_begin, then trim_tr_iterate while trim_tr_goes_on): the
-// result does not depend on which lane or wave took the aircraft. An aircraft whose descent ends above stopval is left to k_trim_cont
-// (`pending[i]` = 1, nothing else written).
-__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, int32_t* pending) {
+// The descent from the given trim state, for every aircraft.
+//  * PERSISTENT: the aircraft differ in how many iterations they take (bench lattice: 64 to 606 residual evaluations, mean 144 — a wave that
+//    trimmed 64 aircraft side by side waited for its slowest, ~420). One wave per SIMD; a wave takes aircraft from a queue (`next`, zeroed by the
+//    host), every lane descends on its own aircraft, and when FB_TRIM_REFILL_MIN lanes have finished theirs they are served together: results
+//    written, the next aircraft taken.
+//  * ONE loop around ONE inlined residual evaluation, no call: with the residual out of line (an `f_ode!`: ~7.6 k instructions, every VGPR) each
+//    call saved and restored the callee-saved registers and the caller's arrays through scratch — 800 scratch accesses per evaluation, a scratch
+//    frame of 3.5 KB per lane whose 230 MB did not fit the L2: 138 k cycles per evaluation, 280 GB of HBM traffic per launch
+//    (tools/stamp_trim.py, tools/pmc_trim.sh). Here trim_tr_iterate's two parts are phases of a single loop — phase 0, the Jacobian: every
+//    lane asks for the residual at its next difference point (its own column, its own kink probes; all lanes evaluate together, each at its
+//    own point); phase 1, the trial steps: every lane forms its candidate step (the active-set solver) and asks for the residual there —
+//    and a lane that has just taken an aircraft asks for the residual at the initial state first. The three Jacobians (central, forward,
+//    backward: 147 values per lane, indexed by the lane's column) live in a workspace in memory, [row][lane]: written once per column, read once
+//    per candidate. The arithmetic is trim_tr_begin's / trim_tr_iterate's, statement by statement, which k_trim_cont still runs as they stand.
+//  * An aircraft whose descent ends above stopval is left to k_trim_cont (`pending[i]` = 1, nothing else written).
+constexpr int TRIM_WS_J = FB_NTP, TRIM_WS_ROWS = FB_NTP + 3 * TRIM_N * TRIM_N;   // workspace rows per lane: its aircraft's TrimParameters, Jc | Jf | Jb
+template <class A7>
+__device__ __forceinline__ double pick7(const A7& v, int k) {   // v[k] for a lane-dependent k: a select chain (a dynamic register index would be scratch)
+    double x = v[0];
+#pragma unroll
+    for (int m = 1; m < TRIM_N; m++) x = (k == m) ? v[m] : x;
+    return x;
+}
+__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, int32_t* pending, double* ws) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     stage_tables<PR_NC_STEP>(lds, rk, a.tables);
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk, (gk_cptr)a.tables};
+    constexpr int N = TRIM_N;
     const int64_t n = a.n;
     const int lane = threadIdx.x;
-    const double lo[7] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
-    const double hi[7] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
-    TrimP p;
+    const int64_t W = (int64_t)gridDim.x * 64, slot = (int64_t)blockIdx.x * 64 + lane;
+    double* const wsl = ws + slot;
+    auto Jrow = [&](int m, int i, int j) -> double& { return wsl[(int64_t)(TRIM_WS_J + (m * N + i) * N + j) * W]; };
+    const double lo[N] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
+    const double hi[N] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
+    const double fd = 1e-6;
     TrimLane S;
     int64_t i = -1;        // the lane's aircraft; with !active: finished, results not yet written
     bool active = false;
+    bool fresh = false;    // the aircraft has just been taken: its residual at the initial state is not there yet
+    bool redo = false;     // an evaluation of the aircraft came within reach of the ground: this kernel's airborne-only residual does not cover it
     bool more = true;      // (wave-uniform) the queue may still hold aircraft
 #pragma unroll 1
     for (;;) {
@@ -2275,9 +2313,13 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
         if (n_idle == 64 || (more && n_idle >= FB_TRIM_REFILL_MIN)) {
             TRIM_MARK(0);
             if (!active && i >= 0) {
-                if (S.cost <= 1e-16) { trim_leave(a, p, S.z, T, ts, success, cost_out, S.cost, i); pending[i] = 0; }
-                else pending[i] = 1;
-                i = -1;
+                if (S.cost <= 1e-16 && !redo) {
+                    TrimP p;
+                    trim_load_params(p, ws, W, slot);
+                    trim_leave_body(a, p, S.z, T, ts, success, cost_out, S.cost, i);
+                    pending[i] = 0;
+                } else pending[i] = 1;
+                i = -1; redo = false;
             }
             if (more) {
                 unsigned long long base = 0;
@@ -2288,20 +2330,214 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                     const int64_t mine = (int64_t)base + __builtin_popcountll(idle & ((1ull << lane) - 1));
                     if (mine < n) {
                         i = mine;
-                        trim_load_params(p, tp, n, i);
-                        for (int k = 0; k < TRIM_N; k++) S.z[k] = ts[(int64_t)k * n + i];
-                        trim_tr_begin(p, a.env, T, lo, hi, S);
-                        active = true;
+                        for (int k = 0; k < FB_NTP; k++) wsl[(int64_t)k * W] = tp[(int64_t)k * n + i];
+#pragma unroll
+                        for (int k = 0; k < N; k++) S.z[k] = ts[(int64_t)k * n + i];
+                        active = true; fresh = true;
                     }
                 }
             }
             TRIM_MARK(3);
             if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         }
+        // ---- one iteration of every active lane's descent (trim_tr_iterate; for a fresh lane trim_tr_begin first) ----
+        bool it_on = active && (fresh || trim_tr_goes_on(S, TRIM_MAX_ITER));
+        int phase = 0;                                   // (wave-uniform) 0: the Jacobian, 1: the trial steps
+        // phase 0, per lane: the column, and which of its points is asked for next (0: z + fd, 1: z - fd, 2 / 3: the kink probes one step further out)
+        int col = fresh ? -1 : 0, sub = 0;               // (col -1: the residual at the initial state)
+        uint32_t kink = 0;                               // bit j: the forward and backward slopes of column j disagree
+        double rp[N], rm[N], zp = 0, zm = 0;
+        // phase 1, per lane
+        bool accepted = false, tdone = true, have = false;
+        int attempt = 0, cand = 0;
+        uint32_t side0p = 0;                             // bit j: candidate 0 ended on the forward side of kink column j
+        double best_cn = 0, best_pred = 0, best_dinf = 0, best_zn[N], best_rn[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) { rp[k] = 0; rm[k] = 0; best_zn[k] = 0; best_rn[k] = 0; }
+#pragma unroll 1
+        for (;;) {
+            // ---- which point does the lane want the residual at?
+            bool need = false;
+            double zq[N], pred = 0, dinf = 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) zq[k] = S.z[k];
+            if (phase == 0) {
+                need = it_on && col < N;
+                if (need && col < 0) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) { S.z[k] = fmin(fmax(S.z[k], lo[k]), hi[k]); zq[k] = S.z[k]; }   // (trim_tr_begin)
+                }
+                if (need && col >= 0) {
+                    if (sub == 0) { const double zj = pick7(S.z, col); zp = fmin(zj + fd, pick7(hi, col)); zm = fmax(zj - fd, pick7(lo, col)); }
+                    const double tgt = sub == 0 ? zp : sub == 1 ? zm : sub == 2 ? zp + fd : zm - fd;
+#pragma unroll
+                    for (int k = 0; k < N; k++) zq[k] = (k == col) ? tgt : zq[k];
+                }
+                if (__builtin_amdgcn_ballot_w64(need) == 0) {   // every column of every lane is there: on to the trial steps
+                    phase = 1;
+                    tdone = !it_on;
+                    continue;
+                }
+            } else {
+                if (__builtin_amdgcn_ballot_w64(!tdone) == 0) break;
+                if (!tdone) {
+                    double dl[N], du[N];
+#pragma unroll
+                    for (int k = 0; k < N; k++) { dl[k] = fmax(lo[k] - S.z[k], -S.D); du[k] = fmin(hi[k] - S.z[k], S.D); }
+                    double J[N][N], H[N][N], g[N], d[N];
+                    int side[N];
+#pragma unroll
+                    for (int j = 0; j < N; j++) {
+                        side[j] = cand == 0 ? 0 : ((kink >> j) & 1 ? ((side0p >> j) & 1 ? -1 : 1) : 0);
+#pragma unroll
+                        for (int r_ = 0; r_ < N; r_++) J[r_][j] = Jrow(side[j] == 0 ? 0 : side[j] > 0 ? 1 : 2, r_, j);
+                    }
+#pragma unroll 1
+                    for (int round = 0; round < (cand == 0 ? 3 : 1); round++) {
+                        double tr = 0;
+#pragma unroll
+                        for (int c = 0; c < N; c++) {
+                            g[c] = 0;
+#pragma unroll
+                            for (int r_ = 0; r_ < N; r_++) g[c] += J[r_][c] * S.r[r_];
+#pragma unroll
+                            for (int b = 0; b < N; b++) {
+                                double sum = 0;
+#pragma unroll
+                                for (int r_ = 0; r_ < N; r_++) sum += J[r_][c] * J[r_][b];
+                                H[c][b] = sum;
+                            }
+                            tr += H[c][c];
+                        }
+                        TRIM_MARK(0);
+                        trim_box_gauss_newton(H, g, dl, du, 1e-14 * tr + 1e-300, d);
+                        TRIM_MARK(2);
+                        if (cand != 0) break;
+                        bool changed = false;
+#pragma unroll
+                        for (int j = 0; j < N; j++) if ((kink >> j) & 1) {
+                            const int want = d[j] > 0 ? 1 : d[j] < 0 ? -1 : (side[j] != 0 ? side[j] : 1);
+                            if (want != side[j]) {
+                                side[j] = want; changed = true;
+#pragma unroll
+                                for (int r_ = 0; r_ < N; r_++) J[r_][j] = Jrow(want > 0 ? 1 : 2, r_, j);
+                            }
+                        }
+                        if (!changed) break;
+                    }
+                    if (cand == 0) {
+                        side0p = 0;
+#pragma unroll
+                        for (int j = 0; j < N; j++) side0p |= side[j] > 0 ? 1u << j : 0u;
+                    }
+#pragma unroll
+                    for (int c = 0; c < N; c++) {
+                        double Hd = 0;
+#pragma unroll
+                        for (int b = 0; b < N; b++) Hd += H[c][b] * d[b];
+                        pred -= d[c] * (2 * g[c] + Hd);
+                        dinf = fmax(dinf, fabs(d[c]));
+                    }
+                    if (pred > 0 && dinf != 0) {
+                        need = true;
+#pragma unroll
+                        for (int k = 0; k < N; k++) zq[k] = fmin(fmax(S.z[k] + d[k], lo[k]), hi[k]);
+                    }
+                }
+            }
+            // ---- the residuals, every lane at its own point
+            double rq[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) rq[k] = 0;
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                if (need) {
+                    TrimP p;
+                    trim_load_params(p, ws, W, slot);
+                    const int32_t st = trim_resid_body<FB_TRIM_GROUND>(p, zq, a.env, T, rq);
+                    if (st & FB_ST_INTERNAL_REDO) { redo = true; need = false; it_on = false; tdone = true; }   // within reach of the ground: k_trim_cont's
+                }
+            }
+            // ---- what the lane does with them
+            if (phase == 0) {
+                if (need) {
+                    if (col < 0) {   // trim_tr_begin
+                        double c0 = 0;
+#pragma unroll
+                        for (int k = 0; k < N; k++) { S.r[k] = rq[k]; c0 += rq[k] * rq[k]; }
+                        S.cost = c0; S.D = 0.05; S.it = 0;   // (0.05: the reference's initial_step, c172.jl:919)
+                        fresh = false;
+                        it_on = trim_tr_goes_on(S, TRIM_MAX_ITER);
+                        col = 0;
+                    } else if (sub == 0) {
+#pragma unroll
+                        for (int k = 0; k < N; k++) rp[k] = rq[k];
+                        sub = 1;
+                    } else if (sub == 1) {
+#pragma unroll
+                        for (int k = 0; k < N; k++) rm[k] = rq[k];
+                        const double zj = pick7(S.z, col);
+                        const double ic = 1.0 / (zp - zm);
+                        const double ifw = zp > zj ? 1.0 / (zp - zj) : 0.0, ibw = zj > zm ? 1.0 / (zj - zm) : 0.0;
+                        double dmax = 0, cmax = 0;
+#pragma unroll
+                        for (int r_ = 0; r_ < N; r_++) {
+                            const double jc = (rp[r_] - rm[r_]) * ic;
+                            const double jf = ifw != 0 ? (rp[r_] - S.r[r_]) * ifw : jc;
+                            const double jb = ibw != 0 ? (S.r[r_] - rm[r_]) * ibw : jc;
+                            dmax = fmax(dmax, fabs(jf - jb));
+                            cmax = fmax(cmax, fabs(jc));
+                            Jrow(0, r_, col) = jc; Jrow(1, r_, col) = jf; Jrow(2, r_, col) = jb;
+                        }
+                        const bool kk = dmax > 1e-3 * cmax;   // smooth: |Jf - Jb| ~ fd |r''| ~ 1e-6 of the column
+                        if (kk) kink |= 1u << col;
+                        if (kk && zp + fd <= pick7(hi, col)) sub = 2;
+                        else if (kk && zm - fd >= pick7(lo, col)) sub = 3;
+                        else { col++; sub = 0; }
+                    } else if (sub == 2) {
+#pragma unroll
+                        for (int r_ = 0; r_ < N; r_++) Jrow(1, r_, col) = (rq[r_] - rp[r_]) / (zp + fd - zp);
+                        if (zm - fd >= pick7(lo, col)) sub = 3;
+                        else { col++; sub = 0; }
+                    } else {
+#pragma unroll
+                        for (int r_ = 0; r_ < N; r_++) Jrow(2, r_, col) = (rm[r_] - rq[r_]) / (zm - (zm - fd));
+                        col++; sub = 0;
+                    }
+                }
+            } else if (!tdone) {
+                if (need) {
+                    double cn = 0;
+#pragma unroll
+                    for (int k = 0; k < N; k++) cn += rq[k] * rq[k];
+                    if (!have || cn < best_cn) {
+                        have = true; best_cn = cn; best_pred = pred; best_dinf = dinf;
+#pragma unroll
+                        for (int k = 0; k < N; k++) { best_zn[k] = zq[k]; best_rn[k] = rq[k]; }
+                    }
+                }
+                cand++;
+                if (cand >= (kink != 0 ? 2 : 1)) {   // the attempt's candidates are through
+                    if (have) {
+                        const double rho = (S.cost - best_cn) / best_pred;
+                        if (best_cn < S.cost) {
+#pragma unroll
+                            for (int k = 0; k < N; k++) { S.z[k] = best_zn[k]; S.r[k] = best_rn[k]; }
+                            S.cost = best_cn;
+                            accepted = true;
+                            if (rho > 0.75 && best_dinf > 0.9 * S.D) S.D = fmin(2 * S.D, 1.0);
+                            else if (rho < 0.25) S.D = fmax(0.5 * best_dinf, 1e-14);
+                        } else {
+                            S.D = 0.25 * fmin(S.D, best_dinf);
+                        }
+                    } else S.D *= 0.25;
+                    attempt++; cand = 0; have = false; side0p = 0;
+                    tdone = accepted || attempt >= 40 || !(S.D > 1e-13);
+                }
+            }
+        }
         if (active) {
-            bool go = trim_tr_goes_on(S, TRIM_MAX_ITER);
-            if (go) { go = trim_tr_iterate(p, a.env, T, lo, hi, S); S.it++; }
-            active = go && trim_tr_goes_on(S, TRIM_MAX_ITER);
+            if (it_on) { S.it++; active = accepted && trim_tr_goes_on(S, TRIM_MAX_ITER); }
+            else active = false;
         }
     }
 }
@@ -2314,7 +2550,7 @@ __global__ __launch_bounds__(64) void k_trim_cont(KArgs a, const double* tp, dou
     if (__builtin_amdgcn_ballot_w64(mine) == 0) return;   // (one wave per block)
     stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     if (!mine) return;
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk, (gk_cptr)a.tables};
     const int64_t n = a.n;
     TrimP p;
     trim_load_params(p, tp, n, i);

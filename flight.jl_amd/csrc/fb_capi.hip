@@ -52,6 +52,7 @@ struct fb_handle_s {
     float* egm96 = nullptr;
     double* trim_buf = nullptr;  // tp | ts | cost
     int32_t* trim_ok = nullptr;
+    double* trim_ws = nullptr;   // k_trim's workspace: TRIM_WS_ROWS rows per resident lane (freed when fb_trim returns)
     bool have_table[4] = {false, false, false, false};
     fb_params params;
     int32_t steps_per_launch = 1;
@@ -323,7 +324,7 @@ int32_t fb_destroy(fb_handle h) {
     log_free(h);
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->term_step); hipFree(h->term_where); hipFree(h->y); hipFree(h->xdot);
-    hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok);
+    hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok); hipFree(h->trim_ws);
     hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->duo_tap); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
@@ -547,7 +548,8 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     const int64_t trim_waves = std::min<int64_t>((n + 63) / 64, (int64_t)prop.multiProcessorCount * 4);
-    hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, d_pending);
+    if (!h->trim_ws) HIPCHK(hipMalloc(&h->trim_ws, sizeof(double) * fbd::TRIM_WS_ROWS * 64 * std::min<int64_t>((n + 63) / 64, (int64_t)prop.multiProcessorCount * 4)));
+    hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, d_pending, h->trim_ws);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_trim_cont, grid_for(n, 64), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, (const int32_t*)d_pending);
     HIPCHK(hipGetLastError());
@@ -846,7 +848,7 @@ int32_t fb_set_termination(fb_handle h, const int64_t* step, const int32_t* wher
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
-#ifdef FB_STAMP
+#if defined(FB_STAMP) || defined(FB_TRIM_STAMP)
 // diagnostic builds only (tools/stamp_profile.py): the per-phase cycle accumulators of c172_device_impl.inc
 int32_t fb_debug_stamps(unsigned long long* acc, unsigned long long* cnt, int32_t reset) {
     if (acc) HIPCHK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(fbd::g_stamp_acc), sizeof(unsigned long long) * 32));

@@ -1,5 +1,5 @@
 """Where k_trim's first wave spends its cycles (diagnostic build):
-    python __graft_entry__.py --diagnostic-variant trimstamp -DFB_STAMP -DFB_TRIM_STAMP
+    python __graft_entry__.py --diagnostic-variant trimstamp -DFB_TRIM_STAMP
     FLIGHTBATCH_LIB=flight.jl_amd/libflightbatch_trimstamp.so python tools/stamp_trim.py"""
 import ctypes as C, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,5 +17,5 @@ fb.lib.fb_debug_stamps(acc, cnt, 0)
 names = ["other (Jacobian columns, candidate, bookkeeping)", "residual evaluations", "active-set solver", "serving finished lanes (results, next aircraft, first residual)"]
 tot = sum(acc[24 + k] for k in range(4))
 for k in range(4):
-    print("%-62s %12d cycles (100 MHz ticks) %5.1f %%   %7d intervals" % (names[k], acc[24 + k], 100.0 * acc[24 + k] / max(tot, 1), cnt[24 + k]))
+    print("%-62s %12d cycles %5.1f %%   %7d intervals" % (names[k], acc[24 + k], 100.0 * acc[24 + k] / max(tot, 1), cnt[24 + k]))
 print("success %.6f" % w.trim_success.mean())
