@@ -1055,6 +1055,15 @@ __device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_c
 constexpr int DUO_B = 256;
 constexpr int DUO_NP = 4, DUO_ND = 17;   // state rows per role
 constexpr int DUO_NPL = 3;   // how many of role P's four stage sums live in LDS (what is left of the 160 KB)
+// how many of role D's seventeen live in LDS; the rest — from the end: the angular / linear velocity rows, whose emit closes the evaluation
+// behind role P's point W, on the critical path of the pair — in registers (a ds_read + ds_write less per row and evaluation)
+// (the WA Cessna172Sv0 instance: 13 in LDS, four in registers, 248 registers: 14.36 -> 14.26 ms per launch, profiles/r04_ab_acc_regs.txt; the
+// other instances sit at 249-256 registers and would spill: all seventeen in LDS)
+#ifndef FB_DUO_NDL
+#define FB_DUO_NDL 13
+#endif
+template <int KIN, bool X> constexpr int duo_ndl() { return (KIN == FB_KIN_WA && !X) ? FB_DUO_NDL : DUO_ND; }
+static_assert(FB_DUO_NDL >= 1 && FB_DUO_NDL <= DUO_ND, "");
 // Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation. Role D reads the payload's
 // ten mass-property sums from an LDS panel at the point of use and fetches its aerodynamic sums from global memory at the start of
 // the evaluation (one batch of loads, consumed after the table locations).
@@ -1196,7 +1205,7 @@ FBD void duo_wait(DuoSync& sy, int k) {
 #endif
 }
 
-template <int ROLE, bool X = false>
+template <int ROLE, bool X = false, int NDL = DUO_ND>   // NDL: how many of role D's stage sums live in LDS (duo_ndl())
 struct DuoEmit {
     static constexpr int role = ROLE;
     static constexpr bool x2 = X;   // the Cessna172Xv2 instance: role D fetches the evaluation's aerodynamic sums behind role P's point R, every publication
@@ -1206,7 +1215,7 @@ struct DuoEmit {
     lds_cptr xs_l;     // x_n panel
     lds_ptr xwr_l;     // the panel this stage writes
     lds_ptr acc_l;     // this role's stage sums in LDS: D's seventeen [17][DUO_B], the first DUO_NPL of P's four
-    double* acc_r;     // role P: the rest of its stage sums (registers)
+    double* acc_r;     // the rest of the role's stage sums (registers)
     lds_ptr xch_l;     // exchange rows 6.. [XD_ROWS - 6][DUO_B]
     lds_ptr xov_l;     // exchange rows 0-5: the angular / linear velocity rows of the evaluation panel (see c172_duo_device.hpp)
     double eb, ee, em;
@@ -1233,10 +1242,12 @@ struct DuoEmit {
     __device__ __forceinline__ static constexpr int slot(int r) { return ROLE == 1 ? r - 2 : (r < 2 ? r : r - 4); }
     __device__ __forceinline__ double aget(int r) const {
         if (ROLE == 1 && slot(r) >= DUO_NPL) return acc_r[slot(r) - DUO_NPL];
+        if (ROLE == 2 && slot(r) >= NDL) return acc_r[slot(r) - NDL];
         return acc_l[slot(r) * DUO_B + t];
     }
     __device__ __forceinline__ void aset(int r, double v) const {
         if (ROLE == 1 && slot(r) >= DUO_NPL) acc_r[slot(r) - DUO_NPL] = v;
+        else if (ROLE == 2 && slot(r) >= NDL) acc_r[slot(r) - NDL] = v;
         else acc_l[slot(r) * DUO_B + t] = v;
     }
     __device__ __forceinline__ void operator()(int j, double kj) const {
@@ -1311,7 +1322,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __shared__ double rk[LDS_RK_DOUBLES];
     __shared__ double xs_l[NR * B];    // x_n
     __shared__ double xc_l[NR * B];    // the state being evaluated, updated in place by the emits
-    __shared__ double accd_l[ND * B];  // role D's stage sums
+    constexpr int DUO_NDL = duo_ndl<KIN, X>();
+    __shared__ double accd_l[DUO_NDL * B];  // role D's stage sums, as far as they live in LDS (duo_ndl())
     __shared__ double accp_l[DUO_NPL * B];   // role P's, as far as the LDS goes
     __shared__ double pld_l[10 * B];   // role D: the payload's mass-property sums
     __shared__ double xch_l[(XD_ROWS - 6) * B];
@@ -1595,6 +1607,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     // spills around the evaluation, and the reloads land in the divergent bookkeeping code (tools/check_isa_spills.py).
     InputsDuoD in;
     in.pld_l = (lds_cptr)pld_l + t; in.aero_g = a.duo_pld + (valid ? i : 0); in.n = a.n; in.ui = 0;
+    double accd_r[ND > DUO_NDL ? ND - DUO_NDL : 1];   // the stage sums that do not live in LDS (DUO_NDL)
+#pragma unroll
+    for (int k = 0; k < (ND > DUO_NDL ? ND - DUO_NDL : 1); k++) accd_r[k] = 0.0;
     {
         int stall = 0, eng = 0;
         bool to_ground = false;
@@ -1638,7 +1653,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;
+        for (int k = 0; k < DUO_NDL; k++) accd_l[k * B + t] = 0.0;
         const bool active = valid && !to_ground;   // this launch owns the lane's state
         dst_l[t] = (active ? (D_ALIVE | D_ACTIVE) : 0) | (stall ? D_STALL : 0) | (eng << D_ENG_SHIFT);
         flags_l[t] = (active ? DUO_F_RUN : 0) | (eng << DUO_F_ENG_SHIFT);
@@ -1678,7 +1693,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     inl.aero_g = ka->duo_pld + il;
                     inl.n = ka->n;
                 }
-                const DuoEmit<2, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, nullptr, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
+                const DuoEmit<2, X, DUO_NDL> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accd_l, accd_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
                                             tap_now, i};
                 const SV xv = {sk.xrd_l + t + lds_off};
 #if defined(FB_DUO_ONLY) && FB_DUO_ONLY == 1
@@ -1737,7 +1752,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             else if (__builtin_amdgcn_ballot_w64(mod) != 0) {   // k1 must be re-evaluated on the modified x_{n+1}
                 if (mod) {
 #pragma unroll
-                    for (int k = 0; k < ND; k++) accd_l[k * B + t] = 0.0;   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
+                    for (int k = 0; k < DUO_NDL; k++) accd_l[k * B + t] = 0.0;   // (acc held the discarded k1; stage 0 reads x_n from xs_l itself)
+#pragma unroll
+                    for (int k = 0; k < (ND > DUO_NDL ? ND - DUO_NDL : 1); k++) accd_r[k] = 0.0;
                 }
                 zero_acc = mod; run = mod; redoing = true; advance = false;
             }
