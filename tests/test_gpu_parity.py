@@ -88,6 +88,35 @@ def test_trim_bench_lattice_all_succeed(fb, oracle):
     w.close()
 
 
+def test_trim_does_not_depend_on_which_lane_takes_an_aircraft(fb):
+    """k_trim is persistent: a lane takes the next aircraft from a queue whenever its own has converged, so which lane and wave trims
+    an aircraft, and beside whom, depends on the batch order and on timing. What it computes for an aircraft must not: the same
+    aircraft in another order (and in a batch of another size, through k_trim_cont's aircraft as well — the wide envelope has
+    points without a trim) give the same trim state, cost and initial condition BIT FOR BIT."""
+    n = 8192
+    rng = np.random.default_rng(5)
+    lat = rng.uniform(-1.2, 1.2, n); lon = rng.uniform(-np.pi, np.pi, n)
+    f = dict(n_e=np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)]), h_e=rng.uniform(100.0, 4500.0, n),
+             EAS=rng.uniform(24.0, 62.0, n), ψ_nb=rng.uniform(-np.pi, np.pi, n), γ_wb_n=rng.uniform(-0.05, 0.05, n),
+             ψ_wb_dot=rng.uniform(-0.03, 0.03, n), flaps=rng.choice([0.0, 0.33, 1.0], n), fuel_load=rng.uniform(0.1, 1.0, n))
+    def run(idx):
+        w = fb.BatchedWorld(len(idx))
+        fb.f_init(w, fb.TrimParameters(**{k: (v[:, idx] if v.ndim == 2 else v[idx]) for k, v in f.items()}))
+        out = (w.trim_state.copy(), w.trim_cost.copy(), w.trim_success.copy(), w.x.copy(), w.u.copy())
+        w.close()
+        return out
+    ident = np.arange(n)
+    perm = rng.permutation(n)
+    part = np.sort(rng.choice(n, 1000, replace=False))
+    a = run(ident); b = run(perm); c = run(part)
+    assert 0.02 < 1 - a[2].mean() < 0.6, "the envelope should hold aircraft without a trim (k_trim_cont's path) and with one"
+    for x, y, z in zip(a, b, c):
+        xa = x[..., perm] if x.ndim == 2 else x[perm]
+        assert np.array_equal(xa, y, equal_nan=True)
+        xp = x[..., part] if x.ndim == 2 else x[part]
+        assert np.array_equal(xp, z, equal_nan=True)
+
+
 def test_trim_wide_envelope_and_hard_cases(fb, oracle):
     """An envelope wider than the aircraft can fly (28 % of the points have no trim: below the stall speed, beyond the power
     available) plus the five knot-trapped cases of tests/golden/trim_hard_cases.npz: same success set as the oracle, same
