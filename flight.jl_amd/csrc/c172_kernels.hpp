@@ -335,7 +335,13 @@ template <class P> FBD P* uni(P* p) { return (P*)(uintptr_t)uni((int64_t)(uintpt
 // to a word (the blob is at most CTL_GAINS_MAX = 6144 doubles), `tsg` = total | same_grid << 16.
 // Returns the four commands it leaves in cs — in registers: re-reading the rows just written waits for the stores to land first.
 struct CtlOut { double cmd[4]; };   // throttle, aileron, elevator, rudder, as x2_command() would read them back
-__device__ __noinline__ CtlOut x2_periodic(const double* a_cu, double* a_cs, const double* a_gains, int64_t a_n, double a_dT, uint32_t o01, uint32_t o23,
+// Inlined into k_step_air<KIN, true, GROUND> since round 4: out of line (rounds 2-3, "the call costs 4.9 k cycles") it was a callee that saved and
+// restored the callee-saved registers it used through scratch; inlined, the one-wave airborne pass runs 14.05 -> 12.8 ms per launch of 524 288
+// (profiles/r04_x2_inline_ab.txt, second table). -DFB_X2_PERIODIC_ATTR=__noinline__ builds the old form.
+#ifndef FB_X2_PERIODIC_ATTR
+#define FB_X2_PERIODIC_ATTR __forceinline__
+#endif
+__device__ FB_X2_PERIODIC_ATTR CtlOut x2_periodic(const double* a_cu, double* a_cs, const double* a_gains, int64_t a_n, double a_dT, uint32_t o01, uint32_t o23,
                                            uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, const CtlIn& v) {
     FB_X2_STAMP(21);
     const double* cu = uni(a_cu); double* cs = uni(a_cs); const double* gains = uni(a_gains);
