@@ -383,6 +383,12 @@ __device__ FB_X2_PERIODIC_ATTR CtlOut x2_periodic(const double* a_cu, double* a_
     return {{clampd(M.S(FB_CS_THROTTLE_CMD), 0, 1), clampd(M.S(FB_CS_AILERON_CMD), -1, 1), clampd(M.S(FB_CS_ELEVATOR_CMD), -1, 1), clampd(M.S(FB_CS_RUDDER_CMD), -1, 1)}};
 }
 
+// FB_VERB_FAST: the single-call verbs with f_ode! in the stepping kernels' form (their atan2 / log / sincos, knot scans through scalar loads) instead
+// of the form with the library's functions. Measured, no gain (k_f_ode 0.404 against 0.405-0.413 ms per 1 048 576 aircraft: it is bound by its
+// 1.4 KB of output per aircraft, 3.6 TB/s of stores), so the verbs keep the library form.
+#ifndef FB_VERB_FAST
+#define FB_VERB_FAST false
+#endif
 // f_ode!(world): xdot (optional) and the output record y
 template <bool X, int KIN>
 __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y) {
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     stage_tables<PR_NC>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk, (gk_cptr)a.tables};
     double x[NXT], xd[NXT];
 #pragma unroll
     for (int k = 0; k < NXT; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -401,13 +407,13 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs<KIN>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
 #pragma unroll
         for (int k = 0; k < FB_NACT; k++) xd[X2_ACT + k] = 1 / ACT_TAU * (x2_command(a, i, k) - x[X2_ACT + k]);   // Actuator1.f_ode!, c172x.jl:39-52
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs<KIN>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
     }
     if (xdot) {
 #pragma unroll
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     stage_tables<PR_NC_STEP>(lds, rk, a.tables);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk};
+    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk, (gk_cptr)a.tables};
     double x[NXT], xd[NXT];
 #pragma unroll
     for (int k = 0; k < NXT; k++) x[k] = a.x[(int64_t)k * a.n + i];
@@ -436,12 +442,12 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs<KIN>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
         f_step<KIN>(x, stall, eng, in, aux, st);
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs<KIN>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
         f_step<KIN>(x, stall, eng, in, aux, st);
     }
 #pragma unroll
