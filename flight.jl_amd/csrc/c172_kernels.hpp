@@ -1966,7 +1966,6 @@ __device__ __forceinline__ int32_t trim_resid_body(const TrimP& p, const double*
     TRIM_MARK(1);
     return st;
 }
-__device__ __noinline__ void trim_resid(const TrimP& p, const double* z, const Env& env, const Tables& T, double* r) { trim_resid_body<true>(p, z, env, T, r); }
 // ---- the trim solver ---------------------------------------------------------------------------------------------
 // The reference minimises cost = Σ r² with NLopt's :LN_BOBYQA inside box bounds, initial_step 0.05, stopval 1e-16,
 // maxeval 1e5 (c172.jl:883-942). NLopt is a third-party optimiser; what is kept of it is its behaviour on this
@@ -2078,183 +2077,12 @@ __device__ __forceinline__ void trim_box_gauss_newton(const double (&H)[TRIM_N][
         for (int k = 0; k < N; k++) if (k == rel) fixed[k] = 0;
     }
 }
-// The descent that minimises |r(z)|² inside [lo, hi].
-// (every loop over the seven unknowns is unrolled, so that the Jacobians, H, g and the step are indexed by constants: registers / AGPRs
-// instead of 3.8 KB of dynamically indexed scratch; what is passed to the out-of-line trim_resid by pointer — the 7-vectors — stays in
-// memory at fixed offsets)
-// One aircraft's descent between iterations: what trim_tr_minimize's loop carries (k_trim keeps one per lane, so that a lane whose aircraft
-// has converged takes the next aircraft while its neighbours go on iterating)
+// One aircraft's descent between iterations (k_trim keeps one per lane, so that a lane whose aircraft has converged takes the next aircraft while
+// its neighbours go on iterating). Every loop over the seven unknowns in k_trim is unrolled, so that H, g and the step are indexed by constants
+// (registers), and a lane-dependent index (the lane's Jacobian column) is a select chain or an address in the kernel's workspace.
 struct TrimLane { double z[TRIM_N], r[TRIM_N], cost, D; int it; };
 constexpr double TRIM_COST_FLOOR = 1e-27;
 __device__ __forceinline__ bool trim_tr_goes_on(const TrimLane& S, int max_iter) { return S.it < max_iter && S.cost > TRIM_COST_FLOOR && S.D > 1e-13; }
-__device__ __noinline__ void trim_tr_begin(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], TrimLane& S) {
-    constexpr int N = TRIM_N;
-#pragma unroll
-    for (int k = 0; k < N; k++) S.z[k] = fmin(fmax(S.z[k], lo[k]), hi[k]);
-    trim_resid(p, S.z, env, T, S.r);
-    double cost = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) cost += S.r[k] * S.r[k];
-    S.cost = cost;
-    S.D = 0.05;   // the reference's initial_step (c172.jl:919)
-    S.it = 0;
-}
-// one iteration (Jacobian, trial steps until one is accepted): false when no step was accepted — the descent has ended
-__device__ __noinline__ bool trim_tr_iterate(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], TrimLane& S) {
-    constexpr int N = TRIM_N;
-    const double fd = 1e-6;
-    double (&z)[N] = S.z;
-    double (&r)[N] = S.r;
-    double cost = S.cost, D = S.D;
-    {
-        double Jc[N][N], Jf[N][N], Jb[N][N];
-        bool kink[N], any_kink = false;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            double zz[N], rp[N], rm[N];
-#pragma unroll
-            for (int k = 0; k < N; k++) zz[k] = z[k];
-            const double zp = fmin(z[j] + fd, hi[j]), zm = fmax(z[j] - fd, lo[j]);
-            zz[j] = zp; trim_resid(p, zz, env, T, rp);
-            zz[j] = zm; trim_resid(p, zz, env, T, rm);
-            const double ic = 1.0 / (zp - zm);
-            const double ifw = zp > z[j] ? 1.0 / (zp - z[j]) : 0.0, ibw = z[j] > zm ? 1.0 / (z[j] - zm) : 0.0;
-            double dmax = 0, cmax = 0;
-#pragma unroll
-            for (int i = 0; i < N; i++) {
-                Jc[i][j] = (rp[i] - rm[i]) * ic;
-                Jf[i][j] = ifw != 0 ? (rp[i] - r[i]) * ifw : Jc[i][j];
-                Jb[i][j] = ibw != 0 ? (r[i] - rm[i]) * ibw : Jc[i][j];
-                dmax = fmax(dmax, fabs(Jf[i][j] - Jb[i][j]));
-                cmax = fmax(cmax, fabs(Jc[i][j]));
-            }
-            kink[j] = dmax > 1e-3 * cmax;   // smooth: |Jf - Jb| ~ fd |r''| ~ 1e-6 of the column
-            if (kink[j]) {
-                any_kink = true;
-                double r2[N];
-                if (zp + fd <= hi[j]) {
-                    zz[j] = zp + fd; trim_resid(p, zz, env, T, r2);
-#pragma unroll
-                    for (int i = 0; i < N; i++) Jf[i][j] = (r2[i] - rp[i]) / (zp + fd - zp);
-                }
-                if (zm - fd >= lo[j]) {
-                    zz[j] = zm - fd; trim_resid(p, zz, env, T, r2);
-#pragma unroll
-                    for (int i = 0; i < N; i++) Jb[i][j] = (rm[i] - r2[i]) / (zm - (zm - fd));
-                }
-            }
-        }
-        bool accepted = false;
-#pragma unroll 1
-        for (int attempt = 0; attempt < 40 && !accepted && D > 1e-13; attempt++) {
-            double dl[N], du[N];
-#pragma unroll
-            for (int k = 0; k < N; k++) { dl[k] = fmax(lo[k] - z[k], -D); du[k] = fmin(hi[k] - z[k], D); }
-            double best_cn = 0, best_pred = 0, best_dinf = 0, best_zn[N], best_rn[N];
-            bool have = false;
-            int side0[N];
-#pragma unroll
-            for (int j = 0; j < N; j++) side0[j] = 0;
-#pragma unroll 1
-            for (int cand = 0; cand < (any_kink ? 2 : 1); cand++) {
-                double J[N][N], H[N][N], g[N], d[N];
-                int side[N];
-#pragma unroll
-                for (int j = 0; j < N; j++) {
-                    side[j] = cand == 0 ? 0 : (kink[j] ? (side0[j] > 0 ? -1 : 1) : 0);
-#pragma unroll
-                    for (int i = 0; i < N; i++) J[i][j] = side[j] == 0 ? Jc[i][j] : side[j] > 0 ? Jf[i][j] : Jb[i][j];
-                }
-#pragma unroll 1
-                for (int round = 0; round < (cand == 0 ? 3 : 1); round++) {
-                    double tr = 0;
-#pragma unroll
-                    for (int a = 0; a < N; a++) {
-                        g[a] = 0;
-#pragma unroll
-                        for (int i = 0; i < N; i++) g[a] += J[i][a] * r[i];
-#pragma unroll
-                        for (int b = 0; b < N; b++) {
-                            double sum = 0;
-#pragma unroll
-                            for (int i = 0; i < N; i++) sum += J[i][a] * J[i][b];
-                            H[a][b] = sum;
-                        }
-                        tr += H[a][a];
-                    }
-                    TRIM_MARK(0);
-                    trim_box_gauss_newton(H, g, dl, du, 1e-14 * tr + 1e-300, d);
-                    TRIM_MARK(2);
-                    if (cand != 0) break;
-                    bool changed = false;
-#pragma unroll
-                    for (int j = 0; j < N; j++) if (kink[j]) {
-                        const int want = d[j] > 0 ? 1 : d[j] < 0 ? -1 : (side[j] != 0 ? side[j] : 1);
-                        if (want != side[j]) {
-                            side[j] = want; changed = true;
-#pragma unroll
-                            for (int i = 0; i < N; i++) J[i][j] = want > 0 ? Jf[i][j] : Jb[i][j];
-                        }
-                    }
-                    if (!changed) break;
-                }
-                if (cand == 0) {
-#pragma unroll
-                    for (int j = 0; j < N; j++) side0[j] = side[j];
-                }
-                double pred = 0, dinf = 0;
-#pragma unroll
-                for (int a = 0; a < N; a++) {
-                    double Hd = 0;
-#pragma unroll
-                    for (int b = 0; b < N; b++) Hd += H[a][b] * d[b];
-                    pred -= d[a] * (2 * g[a] + Hd);
-                    dinf = fmax(dinf, fabs(d[a]));
-                }
-                if (!(pred > 0) || dinf == 0) continue;
-                double zn[N], rn[N];
-#pragma unroll
-                for (int k = 0; k < N; k++) zn[k] = fmin(fmax(z[k] + d[k], lo[k]), hi[k]);
-                trim_resid(p, zn, env, T, rn);
-                double cn = 0;
-#pragma unroll
-                for (int k = 0; k < N; k++) cn += rn[k] * rn[k];
-                if (!have || cn < best_cn) {
-                    have = true; best_cn = cn; best_pred = pred; best_dinf = dinf;
-#pragma unroll
-                    for (int k = 0; k < N; k++) { best_zn[k] = zn[k]; best_rn[k] = rn[k]; }
-                }
-            }
-            if (!have) { D *= 0.25; continue; }
-            const double rho = (cost - best_cn) / best_pred;
-            if (best_cn < cost) {
-#pragma unroll
-                for (int k = 0; k < N; k++) { z[k] = best_zn[k]; r[k] = best_rn[k]; }
-                cost = best_cn;
-                accepted = true;
-                if (rho > 0.75 && best_dinf > 0.9 * D) D = fmin(2 * D, 1.0);
-                else if (rho < 0.25) D = fmax(0.5 * best_dinf, 1e-14);
-            } else {
-                D = 0.25 * fmin(D, best_dinf);
-            }
-        }
-        S.cost = cost; S.D = D;
-        return accepted;
-    }
-}
-// minimises |r(z)|² inside [lo, hi]; returns the final cost, z updated in place
-__device__ __noinline__ double trim_tr_minimize(const TrimP& p, const Env& env, const Tables& T, const double (&lo)[TRIM_N], const double (&hi)[TRIM_N], double (&z)[TRIM_N], int max_iter) {
-    TrimLane S;
-#pragma unroll
-    for (int k = 0; k < TRIM_N; k++) S.z[k] = z[k];
-    trim_tr_begin(p, env, T, lo, hi, S);
-#pragma unroll 1
-    for (; trim_tr_goes_on(S, max_iter); S.it++)
-        if (!trim_tr_iterate(p, env, T, lo, hi, S)) break;
-#pragma unroll
-    for (int k = 0; k < TRIM_N; k++) z[k] = S.z[k];
-    return S.cost;
-}
 // f_init!(vehicle, TrimParameters) (c172.jl:883-942), one lane per aircraft at a time.
 __device__ __forceinline__ void trim_load_params(TrimP& p, const double* tp, int64_t n, int64_t i) {
     p.n_e = {tp[(int64_t)FB_TP_N_E * n + i], tp[(int64_t)(FB_TP_N_E + 1) * n + i], tp[(int64_t)(FB_TP_N_E + 2) * n + i]};
@@ -2280,15 +2108,9 @@ __device__ __forceinline__ void trim_leave_body(const KArgs& a, const TrimP& p, 
     if (success) success[i] = cost <= 1e-16;   // the reference's criterion: STOPVAL_REACHED, stopval = 1e-16 (c172.jl:926,934)
     if (cost_out) cost_out[i] = cost;
 }
-__device__ __noinline__ void trim_leave(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
-    trim_leave_body(a, p, z, T, ts, success, cost_out, cost, i);
-}
 constexpr double TRIM_LO[TRIM_N] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};                 // c172.jl:901-908
 constexpr double TRIM_HI[TRIM_N] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
 constexpr int TRIM_MAX_ITER = 500;
-#ifndef FB_TRIM_GROUND
-#define FB_TRIM_GROUND true   // k_trim's residual with the ground-contact branch compiled in (false: airborne only, aircraft within reach of the ground go to k_trim_cont — measured no faster)
-#endif
 #ifndef FB_TRIM_REFILL_MIN
 #define FB_TRIM_REFILL_MIN 8
 #endif
@@ -2300,14 +2122,18 @@ constexpr int TRIM_MAX_ITER = 500;
 //  * ONE loop around ONE inlined residual evaluation, no call: with the residual out of line (an `f_ode!`: ~7.6 k instructions, every VGPR) each
 //    call saved and restored the callee-saved registers and the caller's arrays through scratch — 800 scratch accesses per evaluation, a scratch
 //    frame of 3.5 KB per lane whose 230 MB did not fit the L2: 138 k cycles per evaluation, 280 GB of HBM traffic per launch
-//    (tools/stamp_trim.py, tools/pmc_trim.sh). Here trim_tr_iterate's two parts are phases of a single loop — phase 0, the Jacobian: every
+//    (tools/stamp_trim.py, tools/pmc_trim.sh). Here an iteration's two parts are phases of a single loop — phase 0, the Jacobian: every
 //    lane asks for the residual at its next difference point (its own column, its own kink probes; all lanes evaluate together, each at its
 //    own point); phase 1, the trial steps: every lane forms its candidate step (the active-set solver) and asks for the residual there —
-//    and a lane that has just taken an aircraft asks for the residual at the initial state first. The three Jacobians (central, forward,
+//    and a lane that has just begun a descent asks for the residual at the initial state first. The three Jacobians (central, forward,
 //    backward: 147 values per lane, indexed by the lane's column) live in a workspace in memory, [row][lane]: written once per column, read once
-//    per candidate. The arithmetic is trim_tr_begin's / trim_tr_iterate's, statement by statement, which k_trim_cont still runs as they stand.
-//  * An aircraft whose descent ends above stopval is left to k_trim_cont (`pending[i]` = 1, nothing else written).
-constexpr int TRIM_WS_J = FB_NTP, TRIM_WS_ROWS = FB_NTP + 3 * TRIM_N * TRIM_N;   // workspace rows per lane: its aircraft's TrimParameters, Jc | Jf | Jb
+//    per candidate. The algorithm, statement by statement, is oracle/fo_trim.hpp's.
+//  * THE CONTINUATION FALLBACK is a sequence of descents of the same lane: when the descent from the given state ends above stopval, the lane
+//    restarts from the given state with the parameters blended towards TrimParameters() (c172.jl:806-818; location and heading as requested)
+//    and walks the blend back to the requested ones in steps that halve on failure and double on success.
+// workspace rows per lane: the TrimParameters of the descent in progress; Jc | Jf | Jb; three trim states of the continuation (the given one, the
+// first descent's result, the last good continuation point)
+constexpr int TRIM_WS_J = FB_NTP, TRIM_WS_Z = TRIM_WS_J + 3 * TRIM_N * TRIM_N, TRIM_WS_ROWS = TRIM_WS_Z + 3 * TRIM_N;
 template <class A7>
 __device__ __forceinline__ double pick7(const A7& v, int k) {   // v[k] for a lane-dependent k: a select chain (a dynamic register index would be scratch)
     double x = v[0];
@@ -2315,7 +2141,7 @@ __device__ __forceinline__ double pick7(const A7& v, int k) {   // v[k] for a la
     for (int m = 1; m < TRIM_N; m++) x = (k == m) ? v[m] : x;
     return x;
 }
-__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, int32_t* pending, double* ws) {
+__global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, double* ws) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
     stage_tables<PR_NC_STEP>(lds, rk, a.tables);
@@ -2326,14 +2152,17 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     const int64_t W = (int64_t)gridDim.x * 64, slot = (int64_t)blockIdx.x * 64 + lane;
     double* const wsl = ws + slot;
     auto Jrow = [&](int m, int i, int j) -> double& { return wsl[(int64_t)(TRIM_WS_J + (m * N + i) * N + j) * W]; };
+    auto Zrow = [&](int v, int k) -> double& { return wsl[(int64_t)(TRIM_WS_Z + v * N + k) * W]; };   // v: 0 the given state, 1 the first descent's result, 2 the last good continuation point
     const double lo[N] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
     const double hi[N] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
     const double fd = 1e-6;
     TrimLane S;
     int64_t i = -1;        // the lane's aircraft; with !active: finished, results not yet written
     bool active = false;
-    bool fresh = false;    // the aircraft has just been taken: its residual at the initial state is not there yet
-    bool redo = false;     // an evaluation of the aircraft came within reach of the ground: this kernel's airborne-only residual does not cover it
+    bool fresh = false;    // a descent has just begun: its residual at the initial state is not there yet
+    int maxit = TRIM_MAX_ITER;             // the descent's iteration limit (c172.jl's maxeval is never reached)
+    int mode = 0;                          // 0: the descent from the given state; 1: the continuation's first descent (blend 0); 2: its later ones
+    double ct = 0, cdt = 0, tn_last = 0, cost_main = 0;   // continuation: the blend reached, its step, the blend of the descent in progress, the first descent's cost
     bool more = true;      // (wave-uniform) the queue may still hold aircraft
 #pragma unroll 1
     for (;;) {
@@ -2341,14 +2170,11 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
         const int n_idle = __builtin_popcountll(idle);
         if (n_idle == 64 || (more && n_idle >= FB_TRIM_REFILL_MIN)) {
             TRIM_MARK(0);
-            if (!active && i >= 0) {
-                if (S.cost <= 1e-16 && !redo) {
-                    TrimP p;
-                    trim_load_params(p, ws, W, slot);
-                    trim_leave_body(a, p, S.z, T, ts, success, cost_out, S.cost, i);
-                    pending[i] = 0;
-                } else pending[i] = 1;
-                i = -1; redo = false;
+            if (!active && i >= 0) {   // assign!(vehicle, params, state_opt) with the REQUESTED parameters
+                TrimP p;
+                trim_load_params(p, tp, n, i);
+                trim_leave_body(a, p, S.z, T, ts, success, cost_out, S.cost, i);
+                i = -1;
             }
             if (more) {
                 unsigned long long base = 0;
@@ -2361,16 +2187,16 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                         i = mine;
                         for (int k = 0; k < FB_NTP; k++) wsl[(int64_t)k * W] = tp[(int64_t)k * n + i];
 #pragma unroll
-                        for (int k = 0; k < N; k++) S.z[k] = ts[(int64_t)k * n + i];
-                        active = true; fresh = true;
+                        for (int k = 0; k < N; k++) { S.z[k] = ts[(int64_t)k * n + i]; Zrow(0, k) = S.z[k]; }
+                        active = true; fresh = true; mode = 0; maxit = TRIM_MAX_ITER;
                     }
                 }
             }
             TRIM_MARK(3);
             if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         }
-        // ---- one iteration of every active lane's descent (trim_tr_iterate; for a fresh lane trim_tr_begin first) ----
-        bool it_on = active && (fresh || trim_tr_goes_on(S, TRIM_MAX_ITER));
+        // ---- one iteration of every active lane's descent (oracle/fo_trim.hpp: trim_tr_minimize's loop body; for a lane that has just begun a descent its first residual before) ----
+        bool it_on = active && (fresh || trim_tr_goes_on(S, maxit));
         int phase = 0;                                   // (wave-uniform) 0: the Jacobian, 1: the trial steps
         // phase 0, per lane: the column, and which of its points is asked for next (0: z + fd, 1: z - fd, 2 / 3: the kink probes one step further out)
         int col = fresh ? -1 : 0, sub = 0;               // (col -1: the residual at the initial state)
@@ -2394,7 +2220,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                 need = it_on && col < N;
                 if (need && col < 0) {
 #pragma unroll
-                    for (int k = 0; k < N; k++) { S.z[k] = fmin(fmax(S.z[k], lo[k]), hi[k]); zq[k] = S.z[k]; }   // (trim_tr_begin)
+                    for (int k = 0; k < N; k++) { S.z[k] = fmin(fmax(S.z[k], lo[k]), hi[k]); zq[k] = S.z[k]; }   // (the descent begins inside the box)
                 }
                 if (need && col >= 0) {
                     if (sub == 0) { const double zj = pick7(S.z, col); zp = fmin(zj + fd, pick7(hi, col)); zm = fmax(zj - fd, pick7(lo, col)); }
@@ -2482,20 +2308,19 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                 if (need) {
                     TrimP p;
                     trim_load_params(p, ws, W, slot);
-                    const int32_t st = trim_resid_body<FB_TRIM_GROUND>(p, zq, a.env, T, rq);
-                    if (st & FB_ST_INTERNAL_REDO) { redo = true; need = false; it_on = false; tdone = true; }   // within reach of the ground: k_trim_cont's
+                    trim_resid_body<true>(p, zq, a.env, T, rq);
                 }
             }
             // ---- what the lane does with them
             if (phase == 0) {
                 if (need) {
-                    if (col < 0) {   // trim_tr_begin
+                    if (col < 0) {   // the descent's first residual
                         double c0 = 0;
 #pragma unroll
                         for (int k = 0; k < N; k++) { S.r[k] = rq[k]; c0 += rq[k] * rq[k]; }
                         S.cost = c0; S.D = 0.05; S.it = 0;   // (0.05: the reference's initial_step, c172.jl:919)
                         fresh = false;
-                        it_on = trim_tr_goes_on(S, TRIM_MAX_ITER);
+                        it_on = trim_tr_goes_on(S, maxit);
                         col = 0;
                     } else if (sub == 0) {
 #pragma unroll
@@ -2565,62 +2390,57 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
             }
         }
         if (active) {
-            if (it_on) { S.it++; active = accepted && trim_tr_goes_on(S, TRIM_MAX_ITER); }
-            else active = false;
+            bool ended = true;
+            if (it_on) { S.it++; ended = !(accepted && trim_tr_goes_on(S, maxit)); }
+            if (ended) {   // the descent is over: S.z, S.cost. Done, or the next descent of the continuation
+                const double d0[14] = {1050.0, 50.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 75.0, 75.0, 0.0, 0.0, 50.0};   // TrimParameters(), c172.jl:806-818
+                bool again = false;
+                double tn = 0;
+                if (mode == 0) {
+                    if (S.cost > 1e-16) {   // from TrimParameters() towards the requested ones, beginning at blend 0 from the given state
+                        cost_main = S.cost;
+#pragma unroll
+                        for (int k = 0; k < N; k++) { Zrow(1, k) = S.z[k]; S.z[k] = Zrow(0, k); }
+                        ct = 0; cdt = 0.125; tn = 0; maxit = 200; mode = 1; again = true;
+                    }
+                } else {
+                    bool good;
+                    if (mode == 1) {
+                        good = S.cost <= 1e-16; mode = 2;
+                        if (good) {
+#pragma unroll
+                            for (int k = 0; k < N; k++) Zrow(2, k) = S.z[k];
+                        }
+                    } else if (S.cost <= 1e-16) {
+                        good = true; ct = tn_last; cdt = fmin(2 * cdt, 0.25);
+#pragma unroll
+                        for (int k = 0; k < N; k++) Zrow(2, k) = S.z[k];
+                    } else { cdt *= 0.5; good = !(cdt < 1.0 / 1024); }
+                    if (good && ct < 1.0) {
+                        tn = fmin(1.0, ct + cdt); maxit = 60; again = true;
+#pragma unroll
+                        for (int k = 0; k < N; k++) S.z[k] = Zrow(2, k);
+                    } else if (good && S.cost < cost_main) {   // the requested parameters reached (the last descent, at blend 1, ended below stopval)
+#pragma unroll
+                        for (int k = 0; k < N; k++) S.z[k] = Zrow(2, k);
+                    } else {   // no path: the first descent's result stands
+#pragma unroll
+                        for (int k = 0; k < N; k++) S.z[k] = Zrow(1, k);
+                        S.cost = cost_main;
+                    }
+                }
+                if (again) {
+                    tn_last = tn;
+                    constexpr int row[14] = {FB_TP_H_E, FB_TP_EAS, FB_TP_GAMMA_WB_N, FB_TP_PSI_WB_DOT, FB_TP_THETA_WB_DOT, FB_TP_BETA_A, FB_TP_FUEL_LOAD, FB_TP_MIXTURE,
+                                             FB_TP_FLAPS, FB_TP_PAYLOAD, FB_TP_PAYLOAD + 1, FB_TP_PAYLOAD + 2, FB_TP_PAYLOAD + 3, FB_TP_PAYLOAD + 4};
+#pragma unroll
+                    for (int k = 0; k < 14; k++) wsl[(int64_t)row[k] * W] = d0[k] + tn * (tp[(int64_t)row[k] * n + i] - d0[k]);
+                    fresh = true;
+                } else active = false;
+            }
         }
     }
 }
-// The aircraft k_trim left pending: the descent from TrimState() again (same result), then the continuation in the trim parameters.
-__global__ __launch_bounds__(64) void k_trim_cont(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, const int32_t* pending) {
-    __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
-    __shared__ double rk[LDS_RK_DOUBLES];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = i < a.n && pending[i] != 0;
-    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;   // (one wave per block)
-    stage_tables<PR_NC_STEP>(lds, rk, a.tables);
-    if (!mine) return;
-    const Tables T = {(lds_cptr)lds, a.egm96, (lds_cptr)rk, (gk_cptr)a.tables};
-    const int64_t n = a.n;
-    TrimP p;
-    trim_load_params(p, tp, n, i);
-    const double lo[7] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
-    const double hi[7] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
-    double z0[7], z[7];
-    for (int k = 0; k < 7; k++) { z0[k] = ts[(int64_t)k * n + i]; z[k] = z0[k]; }
-    double cost = trim_tr_minimize(p, a.env, T, lo, hi, z, TRIM_MAX_ITER);
-    if (cost > 1e-16) {
-        // continuation from TrimParameters() (c172.jl:806-818); location and heading as requested (the trim barely depends on them)
-        const double d0[15] = {1050.0, 50.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.0, 75.0, 75.0, 0.0, 0.0, 50.0, 0.0};
-        auto blend = [&](double t) {
-            TrimP q = p;
-            q.h_e = d0[0] + t * (p.h_e - d0[0]); q.EAS = d0[1] + t * (p.EAS - d0[1]); q.gamma_wb_n = d0[2] + t * (p.gamma_wb_n - d0[2]);
-            q.psi_wb_dot = d0[3] + t * (p.psi_wb_dot - d0[3]); q.theta_wb_dot = d0[4] + t * (p.theta_wb_dot - d0[4]);
-            q.beta_a = d0[5] + t * (p.beta_a - d0[5]); q.fuel_load = d0[6] + t * (p.fuel_load - d0[6]); q.mixture = d0[7] + t * (p.mixture - d0[7]);
-            q.flaps = d0[8] + t * (p.flaps - d0[8]);
-            for (int k = 0; k < 5; k++) q.payload[k] = d0[9 + k] + t * (p.payload[k] - d0[9 + k]);
-            return q;
-        };
-        double zc[7];
-        for (int k = 0; k < 7; k++) zc[k] = z0[k];
-        double t = 0, dt = 0.125;
-        TrimP q = blend(0.0);
-        double c = trim_tr_minimize(q, a.env, T, lo, hi, zc, 200);
-        bool good = c <= 1e-16;
-#pragma unroll 1
-        while (good && t < 1.0) {
-            const double tn = fmin(1.0, t + dt);
-            double zt[7];
-            for (int k = 0; k < 7; k++) zt[k] = zc[k];
-            q = blend(tn);
-            c = trim_tr_minimize(q, a.env, T, lo, hi, zt, 60);
-            if (c <= 1e-16) { t = tn; for (int k = 0; k < 7; k++) zc[k] = zt[k]; dt = fmin(2 * dt, 0.25); }
-            else { dt *= 0.5; if (dt < 1.0 / 1024) good = false; }
-        }
-        if (good && c < cost) { cost = c; for (int k = 0; k < 7; k++) z[k] = zc[k]; }
-    }
-    trim_leave(a, p, z, T, ts, success, cost_out, cost, i);
-}
-
 // f_init!(kinematics::ECEF / ::NED, ic) (kinematics.jl:255-280, 336-364) applied to the WA initial condition k_trim leaves
 // (ψ_nw = 0 there, so q_wb = q_nb and q_ew = ltf(n_e) exactly): rows FB_X_Q_WB.. are rewritten in the mechanisation's states.
 template <int KIN>

@@ -533,25 +533,21 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     const int64_t n = h->n;
     if (!h->trim_buf) {
         HIPCHK(hipMalloc(&h->trim_buf, sizeof(double) * ((FB_NTP + FB_NTS + 1) * n + 1)));   // (+ k_trim's queue position)
-        HIPCHK(hipMalloc(&h->trim_ok, sizeof(int32_t) * 2 * n));                              // (+ which aircraft k_trim left to k_trim_cont)
+        HIPCHK(hipMalloc(&h->trim_ok, sizeof(int32_t) * n));
     }
     double* d_tp = h->trim_buf;
     double* d_ts = d_tp + (int64_t)FB_NTP * n;
     double* d_cost = d_ts + (int64_t)FB_NTS * n;
     HIPCHK(hipMemcpyAsync(d_tp, trim_params, sizeof(double) * FB_NTP * n, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d_ts, trim_state, sizeof(double) * FB_NTS * n, hipMemcpyHostToDevice, h->stream));
-    // the descent from the given trim state in a persistent kernel — one wave per SIMD (k_trim holds the whole register file), aircraft taken
-    // from a queue — then the continuation fallback for the aircraft it left pending
+    // a persistent kernel: one wave per SIMD (k_trim holds the whole register file), aircraft taken from a queue
     unsigned long long* d_next = reinterpret_cast<unsigned long long*>(d_cost + n);
-    int32_t* d_pending = h->trim_ok + n;
     HIPCHK(hipMemsetAsync(d_next, 0, sizeof(unsigned long long), h->stream));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     const int64_t trim_waves = std::min<int64_t>((n + 63) / 64, (int64_t)prop.multiProcessorCount * 4);
-    if (!h->trim_ws) HIPCHK(hipMalloc(&h->trim_ws, sizeof(double) * fbd::TRIM_WS_ROWS * 64 * std::min<int64_t>((n + 63) / 64, (int64_t)prop.multiProcessorCount * 4)));
-    hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, d_pending, h->trim_ws);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_trim_cont, grid_for(n, 64), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, (const int32_t*)d_pending);
+    if (!h->trim_ws) HIPCHK(hipMalloc(&h->trim_ws, sizeof(double) * fbd::TRIM_WS_ROWS * 64 * trim_waves));
+    hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, h->trim_ws);
     HIPCHK(hipGetLastError());
     if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL(k_kin_convert<FB_KIN_ECEF>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
     if (h->kin == FB_KIN_NED) hipLaunchKernelGGL(k_kin_convert<FB_KIN_NED>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);

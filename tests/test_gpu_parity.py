@@ -91,7 +91,7 @@ def test_trim_bench_lattice_all_succeed(fb, oracle):
 def test_trim_does_not_depend_on_which_lane_takes_an_aircraft(fb):
     """k_trim is persistent: a lane takes the next aircraft from a queue whenever its own has converged, so which lane and wave trims
     an aircraft, and beside whom, depends on the batch order and on timing. What it computes for an aircraft must not: the same
-    aircraft in another order (and in a batch of another size, through k_trim_cont's aircraft as well — the wide envelope has
+    aircraft in another order (and in a batch of another size, through the continuation fallback as well — the wide envelope has
     points without a trim) give the same trim state, cost and initial condition BIT FOR BIT."""
     n = 8192
     rng = np.random.default_rng(5)
@@ -109,7 +109,7 @@ def test_trim_does_not_depend_on_which_lane_takes_an_aircraft(fb):
     perm = rng.permutation(n)
     part = np.sort(rng.choice(n, 1000, replace=False))
     a = run(ident); b = run(perm); c = run(part)
-    assert 0.02 < 1 - a[2].mean() < 0.6, "the envelope should hold aircraft without a trim (k_trim_cont's path) and with one"
+    assert 0.02 < 1 - a[2].mean() < 0.6, "the envelope should hold aircraft without a trim (the continuation's path) and with one"
     for x, y, z in zip(a, b, c):
         xa = x[..., perm] if x.ndim == 2 else x[perm]
         assert np.array_equal(xa, y, equal_nan=True)

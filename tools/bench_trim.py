@@ -1,6 +1,6 @@
 """Time of fb_trim on the bench lattice (1,048,576 aircraft, neighbouring lanes in different (EAS, h) cells) and on a smooth ramp.
     python tools/bench_trim.py            wall times (host copies of 26 doubles per aircraft included)
-    rocprofv3 --kernel-trace --stats -d gpurun_out/trim -- python3 tools/bench_trim.py      the kernels' own times (k_trim, k_trim_cont)"""
+    rocprofv3 --kernel-trace --stats -d gpurun_out/trim -- python3 tools/bench_trim.py      the kernel's own time (k_trim)"""
 import os, sys, time, numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "flight.jl_amd")); sys.path.insert(0, R)
