@@ -1324,6 +1324,13 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
 //     stepped here, the ground-capable pass evaluates its own.
 constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
+// Diagnostic builds (-DFB_STAMP -DFB_DUO_PHASES, tools/duo_phases.py): the shader clock when role D's first wave of workgroup 0 passes the
+// phases of a launch (g_stamp_acc[8 + k]: 0 entry, 1 tables staged, 2 state loaded and launch constants formed, 3 last evaluation done, 4 exit)
+#if defined(FB_STAMP) && defined(FB_DUO_PHASES)
+#define DUO_PHASE(k) do { if (blockIdx.x == 0 && threadIdx.x == 256) { __builtin_amdgcn_s_waitcnt(0); g_stamp_acc[8 + (k)] = __builtin_amdgcn_s_memtime(); g_stamp_cnt[8 + (k)] += 1; } } while (0)
+#else
+#define DUO_PHASE(k) do { } while (0)
+#endif
 template <int KIN, bool X = false>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
@@ -1370,12 +1377,14 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     const int t = threadIdx.x & (B - 1);
     const int pair = __builtin_amdgcn_readfirstlane(t >> 6);
     const int64_t i = (int64_t)blockIdx.x * B + t;
+    DUO_PHASE(0);
     for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = a.tables[k];
     __syncthreads();
     for (int k = threadIdx.x; k < LDS_RK_KNOTS; k += blockDim.x) rk[k] = 1.0 / (lds[k + 1] - lds[k]);
     for (int k = threadIdx.x; k < ATAN_N; k += blockDim.x) rk[LDS_ATAN + k] = atan(k * (1.0 / 32));
     if (threadIdx.x < 8) sync_l[threadIdx.x] = 0;
     __syncthreads();
+    DUO_PHASE(1);
     DuoSync sy = {(volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? pair : 4 + pair)),
                   (volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? 4 + pair : pair)), 0, 0};
     const bool valid = i < a.n && a.status[i] == 0;
@@ -1634,6 +1643,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             }
             if (to_ground) a.redo[i] = 1;
             stall = a.s[i]; eng = a.s[a.n + i];
+            DUO_PHASE(5);
             if constexpr (X) {
                 InputsXAgg in0;
                 in0.xa = nullptr; in0.u_glob = a.u + i; in0.n = a.n; in0.ui = a.ui[i];
@@ -1651,7 +1661,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 }
             } else {
                 InputsAgg in0;
-                load_inputs(a, i, in0); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO); in0.sum_payload();
+                load_inputs(a, i, in0); DUO_PHASE(6); in0.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO); in0.sum_payload();
+                DUO_PHASE(7);
                 pld_l[t] = in0.pld_M;
 #pragma unroll
                 for (int k = 0; k < 3; k++) pld_l[(1 + k) * B + t] = in0.pld_Mr[k];
@@ -1670,18 +1681,25 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         dst_l[t] = (active ? (D_ALIVE | D_ACTIVE) : 0) | (stall ? D_STALL : 0) | (eng << D_ENG_SHIFT);
         flags_l[t] = (active ? DUO_F_RUN : 0) | (eng << DUO_F_ENG_SHIFT);
     }
+    DUO_PHASE(2);
     // the wave-uniform stage machine (k_step_air's)
     int stage = 0, step = 0;
     bool pending_cb = false, redoing = false, exit_ = __builtin_amdgcn_ballot_w64(dst_l[t] & D_ALIVE) == 0;
     [[maybe_unused]] bool tap_now = false, cmd_put = false;   // Cessna172Xv2: this evaluation is tapped / the update before it has put new lateral commands
     if ((threadIdx.x & 63) == 0) ctrl_l[pair] = exit_ ? DUO_C_EXIT : 0;
-    __threadfence();   // (this lane's launch constants — Sv0: aerodynamic, Xv2: payload — are read back from memory by this lane)
+    // (this lane's launch constants — Sv0: aerodynamic, Xv2: payload — are read back from memory by THIS lane: program order is all that needs,
+    // no fence. The device-scope __threadfence() that stood here wrote the L2 back — buffer_wbl2 — in every wave of every workgroup.)
+#ifdef FB_DUO_START_FENCE
+    __threadfence();
+#elif !defined(FB_DUO_START_NOWAIT)
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the stores have been performed at this XCD's L2, which every later load of this workgroup goes to
+#endif
 #pragma unroll 1
     while (true) {
         DUO_MARK(2, 15);
         duo_publish(sy, DUO_PT_T);   // the control and flag words of this evaluation are written, every row of the previous one emitted
         DUO_MARK(2, 0);
-        if (exit_) break;
+        if (exit_) { DUO_PHASE(3); break; }
         const StageK sk = stage_k(stage);
         int lds_off = 0;
         asm volatile("" : "+s"(lds_off));
@@ -1851,6 +1869,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         }
     }
     if (bad || __builtin_amdgcn_ballot_w64(sy.failed != 0) != 0) atomicOr(&a.status[i], (int32_t)FB_ST_NAN);   // (sy.failed: a synchronisation wait ran into its bound — the partner wave never arrived)
+    DUO_PHASE(4);
     a.s[i] = (d & D_STALL) ? 1 : 0;
     a.s[a.n + i] = (d >> D_ENG_SHIFT) & 3;
 }
