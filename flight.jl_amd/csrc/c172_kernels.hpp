@@ -1324,6 +1324,20 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
 //     stepped here, the ground-capable pass evaluates its own.
 constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
+// dst[k n + i] = src[k n + i], k < ROWS, G rows at a time: G loads in flight, then G stores. (Row by row — a load, a wait, a store, the next
+// load behind the store it may alias — the launch-start copy of the control-law record was 94 dependent memory round trips per workgroup.)
+template <int ROWS, int G>
+__device__ __forceinline__ void copy_rows_batched(double* dst, const double* src, int64_t n, int64_t i) {
+    static_assert(ROWS % G == 0, "");
+#pragma unroll 1
+    for (int k0 = 0; k0 < ROWS; k0 += G) {
+        double v[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) v[g] = src[(int64_t)(k0 + g) * n + i];
+#pragma unroll
+        for (int g = 0; g < G; g++) dst[(int64_t)(k0 + g) * n + i] = v[g];
+    }
+}
 // Diagnostic builds (-DFB_STAMP -DFB_DUO_PHASES, tools/duo_phases.py): the shader clock when role D's first wave of workgroup 0 passes the
 // phases of a launch (g_stamp_acc[8 + k]: 0 entry, 1 tables staged, 2 state loaded and launch constants formed, 3 last evaluation done, 4 exit)
 #if defined(FB_STAMP) && defined(FB_DUO_PHASES)
@@ -1433,8 +1447,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 in.mixture = clampd(a.u[(int64_t)FB_U_MIXTURE * a.n + i], 0, 1);
                 in.ui = a.ui[i];
                 if (a.ctl_ratio > 0) {   // its half of the launch-start copy of the control-law record (role D copies cu)
-#pragma unroll 1
-                    for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
+                    static_assert(FB_NCS % 11 == 0 && FB_NCU % 14 == 0, "batch sizes of the record copies");
+                    copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
                 }
             }
         } else if (valid) {
@@ -1656,8 +1670,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 in.ui = in0.ui;
                 if (a.k1) a.k1_valid[i] = 0;   // (nothing is carried across launches here; the ground-capable pass evaluates its own k1)
                 if (a.ctl_ratio > 0 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
-#pragma unroll 1
-                    for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+                    copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
                 }
             } else {
                 InputsAgg in0;

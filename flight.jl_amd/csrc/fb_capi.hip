@@ -543,9 +543,9 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     // a persistent kernel: one wave per SIMD (k_trim holds the whole register file), aircraft taken from a queue
     unsigned long long* d_next = reinterpret_cast<unsigned long long*>(d_cost + n);
     HIPCHK(hipMemsetAsync(d_next, 0, sizeof(unsigned long long), h->stream));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, h->device));
-    const int64_t trim_waves = std::min<int64_t>((n + 63) / 64, (int64_t)prop.multiProcessorCount * 4);
+    int n_cu = 0;
+    HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int64_t trim_waves = std::min<int64_t>((n + 63) / 64, (int64_t)n_cu * 4);
     if (!h->trim_ws) HIPCHK(hipMalloc(&h->trim_ws, sizeof(double) * fbd::TRIM_WS_ROWS * 64 * trim_waves));
     hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, h->trim_ws);
     HIPCHK(hipGetLastError());
