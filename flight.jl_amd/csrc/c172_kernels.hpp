@@ -293,6 +293,20 @@ FBD double x2_command(const KArgs& a, int64_t i, int k) {
         default: return clampd(a.u[(int64_t)FB_U_BRAKE_RIGHT * n + i], 0, 1);
     }
 }
+// dst[k n + i] = src[k n + i], k < ROWS, G rows at a time: G loads in flight, then G stores. (Row by row — a load, a wait, a store, the next
+// load behind the store it may alias — the launch-start copy of the control-law record was 94 dependent memory round trips per workgroup.)
+template <int ROWS, int G>
+__device__ __forceinline__ void copy_rows_batched(double* dst, const double* src, int64_t n, int64_t i) {
+    static_assert(ROWS % G == 0, "");
+#pragma unroll 1
+    for (int k0 = 0; k0 < ROWS; k0 += G) {
+        double v[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) v[g] = src[(int64_t)(k0 + g) * n + i];
+#pragma unroll
+        for (int g = 0; g < G; g++) dst[(int64_t)(k0 + g) * n + i] = v[g];
+    }
+}
 template <bool X> struct Dims { static constexpr int NXT = X ? (int)FB_X2_NX : (int)FB_NX; };
 
 // vehicle.y as the control laws see it, from the state x (device row order): one RHS evaluation with a partial sink — everything
@@ -631,15 +645,11 @@ restart:
         // a second time up to the evaluation that threw, must find them as they were at launch start
         if (a.ctl_ratio > 0 && mine) {
             if (!replaying) {
-#pragma unroll 1
-                for (int k = 0; k < FB_NCS; k++) a.ctl_bak[(int64_t)k * a.n + i] = a.cs[(int64_t)k * a.n + i];
-#pragma unroll 1
-                for (int k = 0; k < FB_NCU; k++) a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i] = a.cu[(int64_t)k * a.n + i];
+                copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
+                copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
             } else {
-#pragma unroll 1
-                for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
-#pragma unroll 1
-                for (int k = 0; k < FB_NCU; k++) const_cast<double*>(a.cu)[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)(FB_NCS + k) * a.n + i];
+                copy_rows_batched<FB_NCS, 11>(a.cs, a.ctl_bak, a.n, i);
+                copy_rows_batched<FB_NCU, 14>(const_cast<double*>(a.cu), a.ctl_bak + (int64_t)FB_NCS * a.n, a.n, i);
             }
         }
     }
@@ -1324,20 +1334,6 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
 //     stepped here, the ground-capable pass evaluates its own.
 constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
-// dst[k n + i] = src[k n + i], k < ROWS, G rows at a time: G loads in flight, then G stores. (Row by row — a load, a wait, a store, the next
-// load behind the store it may alias — the launch-start copy of the control-law record was 94 dependent memory round trips per workgroup.)
-template <int ROWS, int G>
-__device__ __forceinline__ void copy_rows_batched(double* dst, const double* src, int64_t n, int64_t i) {
-    static_assert(ROWS % G == 0, "");
-#pragma unroll 1
-    for (int k0 = 0; k0 < ROWS; k0 += G) {
-        double v[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) v[g] = src[(int64_t)(k0 + g) * n + i];
-#pragma unroll
-        for (int g = 0; g < G; g++) dst[(int64_t)(k0 + g) * n + i] = v[g];
-    }
-}
 // Diagnostic builds (-DFB_STAMP -DFB_DUO_PHASES, tools/duo_phases.py): the shader clock when role D's first wave of workgroup 0 passes the
 // phases of a launch (g_stamp_acc[8 + k]: 0 entry, 1 tables staged, 2 state loaded and launch constants formed, 3 last evaluation done, 4 exit)
 #if defined(FB_STAMP) && defined(FB_DUO_PHASES)
