@@ -1080,11 +1080,15 @@ constexpr int DUO_NPL = 3;   // how many of role P's four stage sums live in LDS
 // how many of role D's seventeen live in LDS; the rest — from the end: the angular / linear velocity rows, whose emit closes the evaluation
 // behind role P's point W, on the critical path of the pair — in registers (a ds_read + ds_write less per row and evaluation)
 // (the WA Cessna172Sv0 instance: 13 in LDS, four in registers, 248 registers: 14.36 -> 14.26 ms per launch, profiles/r04_ab_acc_regs.txt; the
-// other instances sit at 249-256 registers and would spill: all seventeen in LDS)
+// ECEF / NED Cessna172Sv0 instances sit at 252-256 registers and would spill: all seventeen in LDS)
 #ifndef FB_DUO_NDL
 #define FB_DUO_NDL 13
 #endif
-template <int KIN, bool X> constexpr int duo_ndl() { return (KIN == FB_KIN_WA && !X) ? FB_DUO_NDL : DUO_ND; }
+// (the Cessna172Xv2 instances, since the update halves are inlined: 14 in LDS, three in registers, no spill: 9.95 -> 9.86 ms per launch)
+#ifndef FB_DUO_NDL_X
+#define FB_DUO_NDL_X 14
+#endif
+template <int KIN, bool X> constexpr int duo_ndl() { return (KIN == FB_KIN_WA && !X) ? FB_DUO_NDL : (X ? FB_DUO_NDL_X : DUO_ND); }
 static_assert(FB_DUO_NDL >= 1 && FB_DUO_NDL <= DUO_ND, "");
 // Per-aircraft launch constants cost a role twenty registers each if they ride through the evaluation. Role D reads the payload's
 // ten mass-property sums from an LDS panel at the point of use and fetches its aerodynamic sums from global memory at the start of
@@ -1376,6 +1380,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #endif
 #ifndef FB_X2_HEAD_PRIO
 #define FB_X2_HEAD_PRIO 3  // ... and from the top of its loop to its point R
+#endif
+#ifndef FB_X2_UPD_PRIO
+#define FB_X2_UPD_PRIO 0   // ... and role D's wave during ITS half (the shorter one): 9.86 -> 9.82 ms per launch
 #endif
 #ifndef FB_X2_SPEC_PRIO
 #define FB_X2_SPEC_PRIO 3  // ... and while it forms the next stage's aerodynamic sums at the end of an iteration
@@ -1812,9 +1819,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 // does not touch). Role P's wave runs the longitudinal half meanwhile.
                 DUO_MARK(2, 12);   // f_step! done, flags written: at U
                 duo_publish<true>(sy, DUO_PT_U);
-#ifdef FB_X2_UPD_PRIO
-                __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO);
-#endif
+                __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO);   // (its half is the shorter one: behind role P's, which runs at FB_X2_LON_PRIO)
 #ifdef FB_X2_SERIAL   // (timing diagnostic: the lateral half only after the longitudinal one has finished)
                 duo_wait(sy, DUO_PT_F);
 #endif
