@@ -1076,7 +1076,15 @@ __device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_c
 // the one-wave stepper and the oracle.
 constexpr int DUO_B = 256;
 constexpr int DUO_NP = 4, DUO_ND = 17;   // state rows per role
-constexpr int DUO_NPL = 3;   // how many of role P's four stage sums live in LDS (what is left of the 160 KB)
+#ifndef FB_DUO_NPL
+#define FB_DUO_NPL 0
+#endif
+// role P's own x_n rows (fuel, engine: nobody else writes them) in registers, refreshed from the panel at every stage 0: its emits — the
+// last thing of its evaluation, behind role D's point X — then start without an LDS round trip (the Cessna172Sv0 instances: the Xv2 ones spill with it)
+#ifndef FB_DUO_P_XN_REGS
+#define FB_DUO_P_XN_REGS 1
+#endif
+constexpr int DUO_NPL = FB_DUO_NPL;   // how many of role P's four stage sums live in LDS (what is left of the 160 KB)
 // how many of role D's seventeen live in LDS; the rest — from the end: the angular / linear velocity rows, whose emit closes the evaluation
 // behind role P's point W, on the critical path of the pair — in registers (a ds_read + ds_write less per row and evaluation)
 // (the WA Cessna172Sv0 instance: 13 in LDS, four in registers, 248 registers: 14.36 -> 14.26 ms per launch, profiles/r04_ab_acc_regs.txt; the
@@ -1250,6 +1258,7 @@ struct DuoEmit {
     DuoSync* sync;     // this wave's side of the pair's synchronisation counters
     bool tap;          // wave-uniform (Cessna172Xv2): this is the step's last f_ode! and a control update follows it
     int64_t ai;        // the lane's aircraft
+    const double* xn_r = nullptr;   // role P (FB_DUO_P_XN_REGS): x_n of its own rows
     // rows k0 .. k0 + N - 1 of KArgs::duo_tap (base and stride re-read from the kernel's arguments: once per control period, see kernarg())
     template <int N>
     __device__ __forceinline__ void tap_rows(int k0, const double (&v)[N]) const {
@@ -1279,7 +1288,7 @@ struct DuoEmit {
     __device__ __forceinline__ void operator()(int j, double kj) const {
         static_assert(ROLE == 1 || ROLE == 2, "");
         const int r = SV::row(j), idx = r * DUO_B + t;
-        const double xs = xs_l[idx];
+        const double xs = (ROLE == 1 && FB_DUO_P_XN_REGS && !X) ? xn_r[slot(r)] : xs_l[idx];
         const double A = __builtin_fma(eb, kj, aget(r));
         aset(r, A * em);
         xwr_l[idx] = __builtin_fma(ee, last ? A : kj, xs);
@@ -1288,7 +1297,7 @@ struct DuoEmit {
     __device__ __forceinline__ void batch(int j0, const double (&k)[NE]) const {
         double xs[NE], A[NE];
 #pragma unroll
-        for (int e = 0; e < NE; e++) { const int r = SV::row(j0 + e); xs[e] = xs_l[r * DUO_B + t]; A[e] = aget(r); }
+        for (int e = 0; e < NE; e++) { const int r = SV::row(j0 + e); xs[e] = (ROLE == 1 && FB_DUO_P_XN_REGS && !X) ? xn_r[slot(r)] : xs_l[r * DUO_B + t]; A[e] = aget(r); }
 #pragma unroll
         for (int e = 0; e < NE; e++) A[e] = __builtin_fma(eb, k[e], A[e]);
 #pragma unroll
@@ -1357,7 +1366,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __shared__ double xc_l[NR * B];    // the state being evaluated, updated in place by the emits
     constexpr int DUO_NDL = duo_ndl<KIN, X>();
     __shared__ double accd_l[DUO_NDL * B];  // role D's stage sums, as far as they live in LDS (duo_ndl())
-    __shared__ double accp_l[DUO_NPL * B];   // role P's, as far as the LDS goes
+    __shared__ double accp_l[(DUO_NPL > 0 ? DUO_NPL : 1) * B];   // role P's, as far as the LDS goes
     __shared__ double pld_l[10 * B];   // role D: the payload's mass-property sums
     __shared__ double xch_l[(XD_ROWS - 6) * B];
     __shared__ int flags_l[B];
@@ -1460,6 +1469,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
             in.throttle = in0.throttle; in.mixture = in0.mixture; in.ui = in0.ui;
         }
         double acc_r[NP - DUO_NPL];
+        double xn_r[NP] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
 #pragma unroll
@@ -1530,6 +1540,10 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 for (int k = 0; k < DUO_NPL; k++) accp_l[k * B + t] = 0.0;
             }
             const int stg = c & 3;
+            if (FB_DUO_P_XN_REGS && !X && stg == 0) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) xn_r[k] = xs_l[(2 + k) * B + t];
+            }
             const StageK sk = stage_k(stg);
             int lds_off = 0;
             asm volatile("" : "+s"(lds_off));   // (see k_step_air: keeps the loop-invariant table / input loads from being hoisted into registers)
@@ -1552,7 +1566,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     DUO_MARK(1, 12);   // (Cessna172Xv2: stage positions and aerodynamic sums formed and stored)
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
                     const DuoEmit<1, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
-                                                tap, i};
+                                                tap, i, xn_r};
                     if constexpr (X) {
                         if (tap) {   // what the control laws read of the actuators: the Ranged positions of the state x_{n+1} (InputsX::pos), and the commands this f_ode! saw
                             static_assert(DUO_TAP_CMD == DUO_TAP_POS + 4, "positions, then commands");
