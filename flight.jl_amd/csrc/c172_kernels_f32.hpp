@@ -38,6 +38,11 @@ FBD constexpr int xsrow(int r) { return r < RP0 ? r : r - XPN; }   // panel row 
 // emit of the fp32 stepper. The stage enters through wave-uniform scalar branches (not through selects as in the fp64 kernel: with
 // two waves per SIMD the SALU work of one wave hides behind the other's VALU, and VALU issue is what bounds this kernel), one
 // branch per BATCH of consecutive rows: all panel reads first, then the updates and writes, so the LDS round trips of a batch overlap.
+// FB_F32_NAL: how many of the 21 stage sums (k1 + 2 k2 + 2 k3) live in LDS; the rest, from the last panel row down, in registers
+#ifndef FB_F32_NAL
+#define FB_F32_NAL 9   // (12 in registers: 7.92 -> 7.66 ms per launch, profiles/r04_ab_acc_regs.txt; 249 registers, the LDS panel 37 KB smaller per CU)
+#endif
+constexpr int F32_NAL = FB_F32_NAL;
 template <int B>
 struct F32Emit {
     typedef void batched_tag;
@@ -46,6 +51,9 @@ struct F32Emit {
     using SV = StateLdsF<B>;
     lf_ptr xs_l; ld_ptr xp_l; lf_ptr acc_l, xc_l;
     float eb, ee; double eed; bool last; int t;
+    float* acc_r;   // the stage sums of panel rows >= F32_NAL
+    __device__ __forceinline__ float aget(int r) const { return r < F32_NAL ? acc_l[r * B + t] : acc_r[r - F32_NAL]; }
+    __device__ __forceinline__ void aset(int r, float v) const { if (r < F32_NAL) acc_l[r * B + t] = v; else acc_r[r - F32_NAL] = v; }
     static __device__ __forceinline__ constexpr bool wide(int j) { return j >= XP0 && j < XP0 + XPN; }   // integrated in fp64
     template <int NE>
     __device__ __forceinline__ void batch(int j0, const float (&k)[NE]) const {   // NE consecutive non-contact rows
@@ -53,14 +61,14 @@ struct F32Emit {
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const int j = j0 + e, r = SV::row(j);
-            ac[e] = acc_l[r * B + t];
+            ac[e] = aget(r);
             if (wide(j)) { xsd[e] = xp_l[(j - XP0) * B + t]; xsf[e] = 0; } else { xsf[e] = xs_l[xsrow(r) * B + t]; xsd[e] = 0; }
         }
         if (last) {
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 const int j = j0 + e, r = SV::row(j), idx = r * B + t;
-                acc_l[idx] = 0.0f;
+                aset(r, 0.0f);
                 if (wide(j)) { const double v = xsd[e] + eed * ((double)ac[e] + (double)eb * (double)k[e]); xc_l[idx] = (float)v; xp_l[(j - XP0) * B + t] = v; }
                 else { const float v = __builtin_fmaf(ee, __builtin_fmaf(eb, k[e], ac[e]), xsf[e]); xc_l[idx] = v; xs_l[xsrow(r) * B + t] = v; }
             }
@@ -68,8 +76,8 @@ struct F32Emit {
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 const int j = j0 + e, r = SV::row(j), idx = r * B + t;
-                if (wide(j)) { acc_l[idx] = (float)((double)ac[e] + (double)eb * (double)k[e]); xc_l[idx] = (float)(xsd[e] + eed * (double)k[e]); }
-                else { acc_l[idx] = __builtin_fmaf(eb, k[e], ac[e]); xc_l[idx] = __builtin_fmaf(ee, k[e], xsf[e]); }
+                if (wide(j)) { aset(r, (float)((double)ac[e] + (double)eb * (double)k[e])); xc_l[idx] = (float)(xsd[e] + eed * (double)k[e]); }
+                else { aset(r, __builtin_fmaf(eb, k[e], ac[e])); xc_l[idx] = __builtin_fmaf(ee, k[e], xsf[e]); }
             }
         }
     }
@@ -91,7 +99,10 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
     __shared__ float rk[LDS_RK_DOUBLES];
     __shared__ float xs_l[(NRF - XPN) * B];   // x_n of the fp32-integrated states
     __shared__ double xp_l[XPN * B];          // x_n of the fp64-integrated states
-    __shared__ float acc_l[NRF * B];          // k1 + 2 k2 + 2 k3
+    __shared__ float acc_l[(F32_NAL > 0 ? F32_NAL : 1) * B];   // k1 + 2 k2 + 2 k3 (the rows that do not live in registers)
+    float acc_r[NRF > F32_NAL ? NRF - F32_NAL : 1];
+#pragma unroll
+    for (int k = 0; k < (NRF > F32_NAL ? NRF - F32_NAL : 1); k++) acc_r[k] = 0.0f;
     __shared__ float xc_l[NRF * B];           // the state being evaluated, updated in place by emit()
     // tables: fp64 blob in global memory -> fp32 in LDS (propeller compacted to four coefficients like the fp64 stepper)
     for (int k = threadIdx.x; k < AT_SIZE + PT_SIZE; k += blockDim.x) lds[k] = a.tables_f32[k];
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
         if (k >= FB_X_LDG_FRC && k < FB_X_LDG_FRC + 6) { to_ground = to_ground || (v != 0.0); continue; }
         const int r = SV::row(k);
         xc_l[r * B + t] = (float)v;
-        acc_l[r * B + t] = 0.0f;
+        if (r < F32_NAL) acc_l[r * B + t] = 0.0f;
         if (k >= XP0 && k < XP0 + XPN) xp_l[(k - XP0) * B + t] = v;
         else xs_l[xsrow(r) * B + t] = (float)v;
     }
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
             InputsAgg inl = in;
             asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
             const F32Emit<B> emit = {(typename F32Emit<B>::lf_ptr)xs_l, (typename F32Emit<B>::ld_ptr)xp_l, (typename F32Emit<B>::lf_ptr)acc_l,
-                                     (typename F32Emit<B>::lf_ptr)xc_l, eb, ee, eed, last, t};
+                                     (typename F32Emit<B>::lf_ptr)xc_l, eb, ee, eed, last, t, acc_r};
             const SV xv = {(lds_cptr)xc_l + t + lds_off};
             bits = rhs<FB_KIN_WA, false, true>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
             // within reach of the ground, or an exception (altitude / ISA range): nothing is committed, the fp64 ground-capable kernel takes
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(fbd::STEP_BLOCK, 2) FB_NO_PK32 void k_step_f32(fbd:
 #pragma unroll
                     for (int r = 0; r < NRF; r++) {
                         xc_l[r * B + t] = (r >= RP0 && r < RP0 + XPN) ? (float)xp_l[(r - RP0) * B + t] : xs_l[xsrow(r) * B + t];
-                        acc_l[r * B + t] = 0.0f;   // (it held the discarded k1)
+                        if (r < F32_NAL) acc_l[r * B + t] = 0.0f; else acc_r[r - F32_NAL] = 0.0f;   // (it held the discarded k1)
                     }
                 }
                 run = mod; redoing = true;
