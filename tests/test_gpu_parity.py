@@ -88,6 +88,21 @@ def test_trim_bench_lattice_all_succeed(fb, oracle):
     w.close()
 
 
+def test_trim_batch_sizes_around_the_wave_size(fb):
+    """k_trim runs one wave per 64 aircraft up to one per SIMD and hands aircraft out from a queue: batches of 1, 2, 63, 64, 65, 127 and 1000
+    copies of TrimParameters() all trim, every copy to the same bits."""
+    ref = None
+    for n in (1, 2, 63, 64, 65, 127, 1000):
+        w = fb.BatchedWorld(n)
+        fb.f_init(w, fb.TrimParameters())
+        ts = w.trim_state.copy()
+        assert w.trim_success.all(), n
+        if ref is None:
+            ref = ts[:, 0].copy()
+        assert np.array_equal(ts, np.tile(ref[:, None], (1, n))), n
+        w.close()
+
+
 def test_trim_does_not_depend_on_which_lane_takes_an_aircraft(fb):
     """k_trim is persistent: a lane takes the next aircraft from a queue whenever its own has converged, so which lane and wave trims
     an aircraft, and beside whom, depends on the batch order and on timing. What it computes for an aircraft must not: the same
