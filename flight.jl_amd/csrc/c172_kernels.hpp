@@ -2159,7 +2159,7 @@ constexpr double TRIM_LO[TRIM_N] = {-PI / 12, -PI / 3, 0.4, 0, -1, -1, -1};     
 constexpr double TRIM_HI[TRIM_N] = {c172::alpha_stall_hi, PI / 3, 1.1, 1, 1, 1, 1};         // c172.jl:910-917
 constexpr int TRIM_MAX_ITER = 500;
 #ifndef FB_TRIM_REFILL_MIN
-#define FB_TRIM_REFILL_MIN 8
+#define FB_TRIM_REFILL_MIN 16   // (4: 77.6 ms, 8: 73.8, 16: 72.0, 24: 74.5 per 1 048 576 aircraft of the bench lattice)
 #endif
 // The descent from the given trim state, for every aircraft.
 //  * PERSISTENT: the aircraft differ in how many iterations they take (bench lattice: 64 to 606 residual evaluations, mean 144 — a wave that
