@@ -1,3 +1,5 @@
+"""The fp32 stepper at 1, 10 and 50 RK4 steps per launch (1,048,576 aircraft on the bench lattice): ms per launch and aircraft-steps/s.
+    python tools/quickbench_f32.py"""
 import sys, time, numpy as np, os
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(R, "flight.jl_amd")); sys.path.insert(0, R)

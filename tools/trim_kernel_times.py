@@ -1,3 +1,4 @@
+"""Per-launch durations of k_trim from a rocprofv3 --kernel-trace directory:   python tools/trim_kernel_times.py gpurun_out/trim"""
 import csv,glob,sys
 f=glob.glob(sys.argv[1]+'/*/*_kernel_trace.csv')[0]
 for r in csv.DictReader(open(f)):
