@@ -348,6 +348,17 @@ int32_t fo_robot2d_f_ode(int64_t n, const double* vp, const double* r, double* x
     }
     return 0;
 }
+// Vehicle.f_ode! with the VehicleY outputs the reference's linearisation reads (robot2d.jl:32-41, 230-247): y = [ω, v, θ, η, u_m, τ_m]
+int32_t fo_robot2d_f_ode_y(int64_t n, const double* vp, const double* r, double* xd /*[4 x n]*/, double* y /*[6 x n]*/) {
+    const R2Vehicle v = r2_vehicle(vp);
+    for (int64_t i = 0; i < n; i++) {
+        double x[4] = {r[0 * n + i], r[1 * n + i], r[2 * n + i], r[3 * n + i]}, d[4], tau_m;
+        r2_f_ode(v, x, r[4 * n + i], d, &tau_m);
+        for (int k = 0; k < 4; k++) { xd[k * n + i] = d[k]; y[k * n + i] = x[k]; }
+        y[4 * n + i] = r[4 * n + i]; y[5 * n + i] = tau_m;
+    }
+    return 0;
+}
 static int32_t robot2d_step_many(int64_t n, const double* vp, const double* gp, double dt, int32_t ratio, int32_t with_controller,
                                  const double* u /*[4 x n]*/, double* r /*[10 x n]*/, int64_t step0, int64_t nsteps, int32_t* status, int64_t* term_step) {
     const R2Vehicle v = r2_vehicle(vp);
