@@ -39,6 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "flight.jl_amd"))
 N_TOTAL = 1 << 20
 DT = 0.01
 BYTES_PER_AIRCRAFT_STEP = 440.0   # 2 * Nx * 8 B + 8 B of flags, C172Sv0 fp64
+BYTES_PER_AIRCRAFT_STEP_F32 = 264.0   # the fp32 stepper: 2 * (27 * 4 B + 5 rows of q_ew / h_e kept in fp64: + 5 * 4 B) + 8 B (extra_fleet's bytes_c)
 BYTES_PER_X2_STEP = 756.0         # Cessna172Xv2
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -255,10 +256,14 @@ def check_valid(m, what):
             raise SystemExit(f"INVALID RUN ({what}): {key} = {m[key]} of {n} aircraft — refusing to report a throughput")
 
 
-def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
+def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
     """BASELINE.json configs[3], one GPU's share per rank: 524 288 Cessna172Xv2, autopilot every 2 steps, README example 2 scenario.
     With `world` ranks this IS configs[3] at world = 8 (4 194 304 aircraft): same barrier + max-over-ranks timing as the headline, and
-    the final-state gather (one RCCL all-gather of the 34-row state panels) timed behind it."""
+    the final-state gather (one RCCL all-gather of the 34-row state panels) timed behind it.
+    divergent: the same number of aircraft on bench.lattice(3)'s randomised trims (as tests/test_gpu_fullsize.py flies them), every aircraft
+    in its OWN pair of control modes with its own references (as extra_x2's parity sample draws them): neighbouring lanes sit in
+    different gain-schedule cells, aerodynamic table cells and control-law branches — configs[3]'s identical-aircraft scenario is the
+    best case of every wave-uniform load and branch in the update, this is the other end."""
     n = N_TOTAL // 2
     w = fb.Cessna172Xv2World(n, device=local_rank)
     x_dev = None
@@ -269,10 +274,22 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
         fb._lib.check(fb.lib.fb_attach_state(w._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(s_dev.data_ptr())))
     w.set_params(wind_ned=(1.0, 0.5, 0.0))
     sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=args.x2_inner)
-    fb.init(sim, fb.TrimParameters())
-    assert w.trim_success.all()
-    w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
-    w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+    if divergent:
+        EAS, h, psi, _ = lattice(3, n)
+        fb.init(sim, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+        assert w.trim_success.all()
+        K = fb.K
+        rng = np.random.default_rng(33)
+        cu = w.cu
+        cu[K["FB_CU_LON_MODE_REQ"]] = rng.integers(0, 9, n); cu[K["FB_CU_LAT_MODE_REQ"]] = rng.integers(0, 5, n)
+        cu[K["FB_CU_EAS_REF"]] += rng.uniform(-3, 3, n); cu[K["FB_CU_CLM_REF"]] += rng.uniform(-1.5, 1.5, n)
+        cu[K["FB_CU_PHI_REF"]] += rng.uniform(-0.3, 0.3, n); cu[K["FB_CU_CHI_REF"]] += rng.uniform(-0.5, 0.5, n)
+        w.cu = cu
+    else:
+        fb.init(sim, fb.TrimParameters())
+        assert w.trim_success.all()
+        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+        w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
 
     def barrier():
         if world > 1:
@@ -310,6 +327,13 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1):
     w.close()
     value = n_total * steps / el
     gbs = BYTES_PER_X2_STEP * value / 1e9
+    if divergent:
+        return {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64",
+                "config": {"workload": f"N={n} Cessna172Xv2 on lattice(3)'s randomised trims (EAS 35-55 m/s x h 200-3000 m x heading), wind as configs[3], every aircraft in its own "
+                                       "(lon, lat) control-mode pair drawn from all 9 x 5 with its own references: the divergent counterpart of extra.x2",
+                           "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
+                "kernel_ms": ms.value / max(nl.value, 1),
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}
     out = {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64", "n_gpus": world,
            "config": {"workload": (f"N={n_total} Cessna172Xv2 over {world} GPUs, {n} per GPU (BASELINE.json configs[3]" + (")" if world == 8 else f" at {world} of its 8 GPUs)")
                                    if world > 1 else f"N={n} Cessna172Xv2 (one GPU's share of configs[3]: 4 194 304 over 8)") +
@@ -525,7 +549,8 @@ def main():
         kernel_ms = head["kernel_ms"]
         value = float(head["n_total"]) * args.inner * args.steps / head["elapsed"]
         units_per_launch = float(n) * args.inner
-        achieved_gbs = BYTES_PER_AIRCRAFT_STEP * units_per_launch / (kernel_ms * 1e-3) / 1e9
+        bytes_per_unit = BYTES_PER_AIRCRAFT_STEP if args.dtype == "f64" else BYTES_PER_AIRCRAFT_STEP_F32
+        achieved_gbs = bytes_per_unit * units_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         valu = None
         counters_note = None
@@ -572,8 +597,8 @@ def main():
                        "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= " + ("1e-8" if args.dtype == "f64" else "5e-7") + " (q_wb, q_ew), all states finite"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": (("fbd::k_step_duo<0, false>" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "fbd::k_step_air<0, false>") if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
-                         "note": "algorithmic bytes = 440 B per aircraft-step (SURVEY §8d) x N x inner steps per launch; the fused "
-                                 "stepper is fp64-VALU-bound, see roofline_valu and DESIGN.md"},
+                         "note": f"algorithmic bytes = {bytes_per_unit:.0f} B per aircraft-step (SURVEY §8d" + ("" if args.dtype == "f64" else ", fp32 rows; q_ew / h_e stay fp64") + ") x N x inner steps per launch; the fused "
+                                 "stepper is " + ("fp64" if args.dtype == "f64" else "fp32") + "-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,
         }
         if counters_note:
@@ -607,6 +632,8 @@ def main():
             head.pop("ic", None)
             line["extra"] = {"x2": extra_x2(fb, C, args, timed=x2_timed)}
             if world == 1:
+                line["extra"]["x2_lattice"] = time_x2(fb, None, None, C, args, divergent=True)
+                line["extra"]["x2_lattice"]["vs_identical_aircraft"] = line["extra"]["x2_lattice"]["kernel_ms"] / line["extra"]["x2"]["kernel_ms"]
                 line["extra"]["fleet"] = extra_fleet(fb, C, args)
         print(json.dumps(line), flush=True)
 

@@ -1463,6 +1463,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
                 }
             }
+            // once per launch: the backup rows have left this wave before its first publication, whichever kind that is — role D restores a
+            // handed-over lane from ctl_bak (D_HANDOFF), and an ordinary publication (duo_publish<false>) waits on lgkmcnt only
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         } else if (valid) {
             Inputs in0;
             load_inputs(a, i, in0);

@@ -52,7 +52,7 @@ struct fb_handle_s {
     float* egm96 = nullptr;
     double* trim_buf = nullptr;  // tp | ts | cost
     int32_t* trim_ok = nullptr;
-    double* trim_ws = nullptr;   // k_trim's workspace: TRIM_WS_ROWS rows per resident lane (freed when fb_trim returns)
+    double* trim_ws = nullptr;   // k_trim's workspace: TRIM_WS_ROWS rows per resident lane, allocated by the first fb_trim and kept until fb_destroy (~100 MB on 256 CUs)
     bool have_table[4] = {false, false, false, false};
     fb_params params;
     int32_t steps_per_launch = 1;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_r2_f_step(R2Args<T> a, long long step0)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     if (fabs((double)a.r[(int64_t)2 * a.n + i]) > 45 * (3.14159265358979323846 / 180)) {
-        if (a.status[i] == 0) { a.term_where[i] = FB_TERM_OUTSIDE_STEP; a.term_step[i] = step0; }   // (the verb, not fb_step: see fb_get_termination)
+        if ((a.status[i] & ~FB_ST_NAN) == 0) { a.term_where[i] = FB_TERM_OUTSIDE_STEP; a.term_step[i] = step0; }   // (the verb, not fb_step: see fb_get_termination)
         a.status[i] |= FB_ST_LOST_BALANCE;
     }
 }

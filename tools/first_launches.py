@@ -1,6 +1,6 @@
 """What the first stepping launches after fb_trim cost (k_step_duo<0> max 16.4 ms against 14.3 in the kernel stats).
 Workload, run under `rocprofv3 --kernel-trace` by tools/first_launches.sh: trim 1 048 576 aircraft, 30 back-to-back 50-step launches,
-one second of idle, 30 more, a second trim (its scratch arena is allocated and released again), 30 more.
+one second of idle, 30 more, a second trim (the trim workspace, ~100 MB, is allocated by the FIRST fb_trim and stays resident until fb_destroy: the second trim allocates nothing), 30 more.
     python tools/first_launches.py run                 the workload
     python tools/first_launches.py report TRACE.csv    the launches in order: start time, duration, what ran before"""
 import csv
