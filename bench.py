@@ -273,10 +273,10 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
         torch.cuda.synchronize()
         fb._lib.check(fb.lib.fb_attach_state(w._h, C.c_void_p(x_dev.data_ptr()), C.c_void_p(s_dev.data_ptr())))
     w.set_params(wind_ned=(1.0, 0.5, 0.0))
-    sim = fb.Simulation(w, dt=DT, Δt=2 * DT, save_on=False, steps_per_launch=args.x2_inner)
-    if divergent:
+    sim = fb.Simulation(w, dt=DT, Δt=getattr(args, "x2_ratio", 2) * DT, save_on=False, steps_per_launch=args.x2_inner)   # (x2_ratio: tools/bench_x2_divergence.py only)
+    if divergent:   # (tools/bench_x2_divergence.py passes "trim" / "modes" to time the two sources of divergence apart)
         EAS, h, psi, _ = lattice(3, n)
-        fb.init(sim, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi))
+        fb.init(sim, fb.TrimParameters(EAS=EAS, h_e=h, ψ_nb=psi) if divergent != "modes" else fb.TrimParameters())
         assert w.trim_success.all()
         K = fb.K
         rng = np.random.default_rng(33)
@@ -284,7 +284,11 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
         cu[K["FB_CU_LON_MODE_REQ"]] = rng.integers(0, 9, n); cu[K["FB_CU_LAT_MODE_REQ"]] = rng.integers(0, 5, n)
         cu[K["FB_CU_EAS_REF"]] += rng.uniform(-3, 3, n); cu[K["FB_CU_CLM_REF"]] += rng.uniform(-1.5, 1.5, n)
         cu[K["FB_CU_PHI_REF"]] += rng.uniform(-0.3, 0.3, n); cu[K["FB_CU_CHI_REF"]] += rng.uniform(-0.5, 0.5, n)
-        w.cu = cu
+        if divergent == "trim":   # randomised trims, but the ONE mode pair of configs[3]
+            w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+            w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+        else:
+            w.cu = cu
     else:
         fb.init(sim, fb.TrimParameters())
         assert w.trim_success.all()

@@ -141,6 +141,69 @@ def test_config3_per_gpu_share_xv2_autopilot(fb, oracle):
     w2.close(); w.close()
 
 
+def test_config3_whole_batch_on_one_gpu_4m_aircraft(fb):
+    """BASELINE.json's LARGEST N on one device: Cessna172Xv2World(4 194 304) — configs[3] whole, what an 8-GPU node splits — 2 launches
+    of 50 steps with the autopilot every 2 steps. The control-law record is 66 rows x 4 194 304 x 8 B = 2.2 GB, its launch-start copy
+    another 2.2 GB, cu 0.94 GB: every row offset of the record paths passes 2^31 BYTES from row 8 on and 2^32 from row 16 on, so a 32-bit
+    offset anywhere in the 66-row / 28-row / 20-row paths shows here before an 8-GPU node finds it. The batch is lattice(3)'s 524 288
+    aircraft eight times over: invariants on ALL aircraft, every copy equal to the first bit for bit (incl. the last, whose rows lie
+    highest), and a 512-aircraft stratified sample of the LAST copy bitwise equal to a 512-aircraft world stepped from the same state
+    (results independent of batch size)."""
+    import bench
+    K = fb.K
+    n1 = bench.N_TOTAL // 2
+    copies = 8
+    n = n1 * copies
+    EAS, h, psi, cell = bench.lattice(3, n1)
+    gains = fb.ctl_gains.ctl_gains_blob()
+    wind = (1.0, 0.5, 0.0)
+    w = fb.Cessna172Xv2World(n, gains=gains)
+    w.set_params(wind_ned=wind)
+    sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    fb.init(sim, fb.TrimParameters(EAS=np.tile(EAS, copies), h_e=np.tile(h, copies), ψ_nb=np.tile(psi, copies)))
+    assert w.trim_success.all()
+    w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 2.0
+    w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = float(np.deg2rad(30.0))
+    sel = bench.stratified_sample(cell, per_cell=1)[::2]
+    assert sel.size == 512
+    last = (copies - 1) * n1 + sel
+    x0 = w.x
+    assert np.array_equal(x0.reshape(-1, copies, n1), np.broadcast_to(x0[:, None, :n1], (x0.shape[0], copies, n1)))
+    fuel_row = K["FB_X_FUEL"]           # rows 0-11 of the C ABI's Xv2 state are the Sv0 rows
+    fuel0 = x0[fuel_row].copy()
+    small = dict(x=np.ascontiguousarray(x0[:, last]), s=np.ascontiguousarray(w.s[:, last]), u=np.ascontiguousarray(w.u[:, last]),
+                 ui=np.ascontiguousarray(w.ui[last]))
+    cu0 = w.cu; small["cu"] = np.ascontiguousarray(cu0[:, last]); del cu0
+    cs0 = w.cs; small["cs"] = np.ascontiguousarray(cs0[:, last]); del cs0
+    del x0
+    for _ in range(2):
+        fb.step(sim, 0.5)
+    w.sync()
+    st = w.status
+    assert (st == 0).all(), f"{(st != 0).sum()} aircraft terminated"
+    x1 = w.x
+    assert np.isfinite(x1).all()
+    assert (x1[fuel_row] < fuel0).all(), "fuel must strictly decrease on every aircraft"
+    for r0 in (K["FB_X2_KIN"], K["FB_X2_KIN"] + 4):
+        q = x1[r0:r0 + 4]
+        assert np.abs(np.sqrt((q * q).sum(0)) - 1.0).max() <= 1e-8 * (1 + 1e-6)
+    assert np.array_equal(x1.reshape(-1, copies, n1), np.broadcast_to(x1[:, None, :n1], (x1.shape[0], copies, n1))), "a copy of the batch differs from the first"
+    cs1 = w.cs
+    assert np.isfinite(cs1).all()
+    assert (cs1[K["FB_CS_LON_MODE"]] == float(fb.ModeControlLon.EAS_clm)).all() and (cs1[K["FB_CS_LAT_MODE"]] == float(fb.ModeControlLat.φ_β)).all()
+    assert np.array_equal(cs1.reshape(-1, copies, n1), np.broadcast_to(cs1[:, None, :n1], (cs1.shape[0], copies, n1)))
+    x1s, cs1s = np.ascontiguousarray(x1[:, last]), np.ascontiguousarray(cs1[:, last])
+    del x1, cs1
+    w.close()
+    w2 = fb.Cessna172Xv2World(sel.size, gains=gains)
+    w2.set_params(wind_ned=wind)
+    sim2 = fb.Simulation(w2, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+    w2.set_state(small["x"], small["s"]); w2.u = small["u"]; w2.ui = small["ui"]; w2.cu = small["cu"]; w2.cs = small["cs"]
+    fb.step(sim2, 1.0); w2.sync()
+    assert np.array_equal(w2.x, x1s) and np.array_equal(w2.cs, cs1s)
+    w2.close()
+
+
 @pytest.mark.parametrize("kin", ["ECEF", "NED"])
 def test_config2_full_size_other_mechanisations(fb, oracle, kin):
     """configs[2]'s batch (N = 1 048 576 on bench.py's lattice) in the ECEF and NED mechanisations, stepped by k_step_duo<KIN>: invariants on

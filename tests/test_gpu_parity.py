@@ -226,6 +226,52 @@ def test_step_trajectory_matches_oracle(fb, oracle):
     w.close()
 
 
+def test_globally_scattered_batch_matches_oracle(fb, oracle):
+    """A fleet spread over the whole Earth (bench.py's batch sits at ϕ = λ = 0: one EGM96 cell): 1000 RK4 steps against the oracle on
+    aircraft placed uniformly over the sphere, within 1° and within 300 m of either pole (|ϕ| > 89°: the geoid grid's first / last row,
+    `Line` extrapolation beyond it; WA kinematics carry an aircraft across the pole), astride the antimeridian and astride λ = 0 (the
+    λ ∈ [0, 2π) wrap of the geoid lookup, FP/geodesy.jl:186-211) close enough to cross them during the run, every one on its own heading."""
+    rng = np.random.default_rng(41)
+    groups = []
+    m = 2048; groups.append((np.arcsin(rng.uniform(-1, 1, m)), rng.uniform(-np.pi, np.pi, m)))              # uniform over the sphere
+    for sgn in (1.0, -1.0):
+        m = 256; groups.append((sgn * (np.pi / 2 - np.deg2rad(rng.uniform(0.0, 1.0, m))), rng.uniform(-np.pi, np.pi, m)))       # within 1° of a pole
+        m = 256; groups.append((sgn * (np.pi / 2 - rng.uniform(0.0, 300.0, m) / 6.36e6), rng.uniform(-np.pi, np.pi, m)))        # within 300 m of it
+    m = 512; groups.append((rng.uniform(-1.4, 1.4, m), np.pi * rng.choice([-1.0, 1.0], m) * (1 - rng.uniform(0, 2e-5, m) / np.pi)))     # antimeridian ± 130 m
+    m = 512; groups.append((rng.uniform(-1.4, 1.4, m), rng.uniform(-2e-5, 2e-5, m)))                                                  # λ = 0 ± 130 m
+    lat = np.concatenate([g[0] for g in groups]); lon = np.concatenate([g[1] for g in groups])
+    n = lat.size
+    assert n == 4096 and (np.abs(lat) > np.deg2rad(89.0)).sum() >= 1024
+    n_e = np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)])
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, fb.TrimParameters(n_e=n_e, h_e=rng.uniform(200.0, 3000.0, n), EAS=rng.uniform(35.0, 55.0, n), ψ_nb=rng.uniform(-np.pi, np.pi, n)))
+    assert w.trim_success.all()
+    x = w.x
+    x[21:24] += rng.normal(0, 0.02, (3, n)); x[24:27] += rng.normal(0, 1.0, (3, n))
+    w.set_state(x, w.s)
+    x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+    fb.f_ode(w); y0 = w.y
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.step(sim, 10.0); w.sync()
+    fb.f_ode(w); y1 = w.y
+    K = fb.K
+    la0, lo0, la1, lo1 = y0[K["FB_Y_KIN"] + 15], y0[K["FB_Y_KIN"] + 16], y1[K["FB_Y_KIN"] + 15], y1[K["FB_Y_KIN"] + 16]
+    crossed_anti = int(((np.abs(lo0) > 3.0) & (np.sign(lo0) != np.sign(lo1))).sum())
+    crossed_zero = int(((np.abs(lo0) < 0.1) & (np.sign(lo0) != np.sign(lo1))).sum())
+    over_pole = int(((np.abs(la0) > 1.57) & (np.abs(np.angle(np.exp(1j * (lo1 - lo0)))) > np.pi / 2)).sum())
+    print(f"crossed the antimeridian: {crossed_anti}, crossed λ = 0: {crossed_zero}, passed within sight of a pole (longitude swung by > 90°): {over_pole}")
+    assert crossed_anti > 50 and crossed_zero > 50 and over_pole > 20
+    xo, so, sto = oracle.step(x0, u0, ui0, s0, oracle.default_env(), 0.01, 1000)
+    assert (w.status == 0).all() and (sto == 0).all() and np.array_equal(w.s, so)
+    err = np.abs(w.x - xo) / state_scale(xo)
+    print("globally scattered batch: max scaled error after 1000 steps: %.3e" % err.max())
+    assert err.max() < 1e-6
+    yo = oracle.f_ode(xo, u0, ui0, so, oracle.default_env())[1]
+    h_o = K["FB_Y_KIN"] + 21    # orthometric altitude: the geoid lookup's output (h_e − N)
+    assert np.abs(y1[h_o] - yo[h_o]).max() < 1e-6
+    w.close()
+
+
 def test_steps_per_launch_invariance(fb):
     """Fusing k steps per launch must not change the result (bit-for-bit): idempotence of the launch split."""
     n = 1024
