@@ -206,6 +206,7 @@ struct KArgs {
     const float* egm96;
     int64_t n;
     Env env;
+    const double* env_rows;   // [ENV_DEV_ROWS x n] per-aircraft environment (fb_set_env), or null: the batch-wide block `env` (fb_params)
     double dt;
     // Cessna172X only
     double* cs;         // [FB_NCS x n] control-law record (actuator commands live here)
@@ -245,6 +246,21 @@ FBD kargs_cptr kernarg() {
     asm volatile("" : "+s"(p));
     return p;
 }
+// Per-aircraft environment (fb_set_env): in the reference wind, sea-level conditions and terrain elevation are inputs of EACH simulation's own
+// atmosphere / terrain models (FP/atmosphere.jl:75-84,156-165, FP/terrain.jl:34-48) — N simulations, N environments. Rows FB_ENV_* of the
+// caller's panel, then two derived rows the host fills like make_args fills Env::ln_p_sl / k_rt. The surface type stays batch-wide.
+// A kernel instance with PERENV holds the lane's nine values in VGPRs (the batch-wide block sits in SGPRs): the stepping kernels that have
+// the registers for it (k_step_air, one wave per SIMD) are instantiated both ways, k_step_duo — 248 of 256 registers — only batch-wide
+// (fb_step routes a handle with per-aircraft rows through k_step_air<.., true>), the single-call verbs choose at run time.
+constexpr int ENV_DEV_LN_P = FB_NENV, ENV_DEV_K_RT = FB_NENV + 1, ENV_DEV_ROWS = FB_NENV + 2;
+FBD Env env_of(const KArgs& a, int64_t i) {
+    const double* e = a.env_rows + i;
+    const int64_t n = a.n;
+    return {e[(int64_t)FB_ENV_T_SL * n], e[(int64_t)FB_ENV_P_SL * n], e[(int64_t)FB_ENV_WIND_N * n], e[(int64_t)FB_ENV_WIND_E * n], e[(int64_t)FB_ENV_WIND_D * n],
+            e[(int64_t)FB_ENV_H_TERRAIN * n], a.env.surface, e[(int64_t)ENV_DEV_LN_P * n], e[(int64_t)ENV_DEV_K_RT * n]};
+}
+// the single-call verbs: one instance, the choice made at run time (the nine values in VGPRs either way)
+FBD Env env_any(const KArgs& a, int64_t i) { return a.env_rows ? env_of(a, i) : a.env; }
 // A status bit raised outside fb_step (the single-call verbs): the record says so, with the step count of the moment — unless the
 // aircraft already carries a record (fb_get_termination promises a valid step and place next to every termination bit)
 FBD void mark_outside_step(int32_t* status, long long* term_step, int32_t* term_where, long long step0, int64_t i, int32_t st) {
@@ -318,7 +334,7 @@ FBD CtlIn x2_ctl_inputs(const KArgs& a, int64_t i, const Tables& T, const double
     const InputsX in = {&x[X2_ACT], a.u + i, a.n, ui};
     StepAux aux;
     CtlSink tap;
-    rhs<KIN, GROUND>(x, stall, eng, in, a.env, T, [](int, double) {}, aux, tap);
+    rhs<KIN, GROUND>(x, stall, eng, in, env_any(a, i), T, [](int, double) {}, aux, tap);
     CtlIn v;
     v.lat = tap.lat; v.lon = tap.lon;
     v.EAS = tap.EAS; v.h_e = x[h_e_row<KIN>()]; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
@@ -421,13 +437,13 @@ __global__ __launch_bounds__(256) void k_f_ode(KArgs a, double* xdot, double* y)
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, env_any(a, i), T, emit, aux, PanelSink{y + i, a.n});
 #pragma unroll
         for (int k = 0; k < FB_NACT; k++) xd[X2_ACT + k] = 1 / ACT_TAU * (x2_command(a, i, k) - x[X2_ACT + k]);   // Actuator1.f_ode!, c172x.jl:39-52
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, a.env, T, emit, aux, PanelSink{y + i, a.n});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, a.s[i], a.s[a.n + i], in, env_any(a, i), T, emit, aux, PanelSink{y + i, a.n});
     }
     if (xdot) {
 #pragma unroll
@@ -456,12 +472,12 @@ __global__ __launch_bounds__(256) void k_f_step(KArgs a) {
     int32_t st;
     if constexpr (X) {
         const InputsX in = {&x[X2_ACT], a.u + i, a.n, a.ui[i]};
-        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, env_any(a, i), T, emit, aux, NoSink{});
         f_step<KIN>(x, stall, eng, in, aux, st);
     } else {
         Inputs in;
         load_inputs(a, i, in);
-        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, a.env, T, emit, aux, NoSink{});
+        st = rhs<KIN, true, FB_VERB_FAST>(x, stall, eng, in, env_any(a, i), T, emit, aux, NoSink{});
         f_step<KIN>(x, stall, eng, in, aux, st);
     }
 #pragma unroll
@@ -577,7 +593,7 @@ template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND
 #ifndef FB_STEP_ATTR
 #define FB_STEP_ATTR
 #endif
-template <int KIN, bool X = false, bool GROUND = false>
+template <int KIN, bool X = false, bool GROUND = false, bool PERENV = false>
 __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step_air(KArgs a, int nsteps) {
     constexpr int B = step_block<X, GROUND>(), NR = GROUND ? (int)FB_NX : FB_NX - 6;
     constexpr bool ACC_REGS = step_acc_in_regs<X, GROUND>();
@@ -601,6 +617,7 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     }
     if (a.status[i] != 0) return;
     const int t = threadIdx.x;
+    const Env env = [&] { if constexpr (PERENV) return env_of(a, i); else return a.env; }();   // per lane (VGPRs) or the batch-wide block (SGPRs)
     double acc_r[ACC_REGS ? NR : 1];
     const AccStore<B, ACC_REGS> acc = [&] { if constexpr (ACC_REGS) return AccStore<B, true>{acc_r}; else return AccStore<B, false>{(lds_ptr)acc_l, t}; }();
     // ---- termination (FC/sim.jl:561-570; include/flightbatch.h FB_TERM_*) ----
@@ -754,10 +771,10 @@ restart:
             if constexpr (X) {
                 // the evaluation at x_{n+1} of a step that closes a control period is the "last f_ode!" whose outputs the control
                 // laws read: it runs with the partial sink (a second instance of rhs() in the loop, taken once per period)
-                if (tap_now) bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, tap);
-                else bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+                if (tap_now) bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, tap);
+                else bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
             } else
-                bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, a.env, T, emit, aux, NoSink{});
+                bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
             if constexpr (!GROUND) {
                 // within reach of the ground, or an exception: nothing is committed for this lane, the ground-capable pass takes it over
                 if (bits != 0) { handoff = true; alive = false; run = false; bits = 0; }
@@ -2143,11 +2160,11 @@ __device__ __forceinline__ void trim_load_params(TrimP& p, const double* tp, int
     for (int k = 0; k < 5; k++) p.payload[k] = tp[(int64_t)(FB_TP_PAYLOAD + k) * n + i];
 }
 // assign!(vehicle, params, state_opt): leave the trimmed initial condition in x, u, s, the trim state in ts
-__device__ __forceinline__ void trim_leave_body(const KArgs& a, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
+__device__ __forceinline__ void trim_leave_body(const KArgs& a, const Env& env, const TrimP& p, const double (&z)[TRIM_N], const Tables& T, double* ts, int32_t* success, double* cost_out, double cost, int64_t i) {
     const int64_t n = a.n;
     double x[FB_NX], uraw[FB_NU];
     Inputs in;
-    trim_assign(p, z, a.env, T, x, in, uraw);
+    trim_assign(p, z, env, T, x, in, uraw);
     for (int k = 0; k < FB_NX; k++) a.x[(int64_t)k * n + i] = x[k];
     double* uw = const_cast<double*>(a.u);
     for (int k = 0; k < FB_NU; k++) uw[(int64_t)k * n + i] = uraw[k];
@@ -2183,7 +2200,7 @@ constexpr int TRIM_MAX_ITER = 500;
 //    and walks the blend back to the requested ones in steps that halve on failure and double on success.
 // workspace rows per lane: the TrimParameters of the descent in progress; Jc | Jf | Jb; three trim states of the continuation (the given one, the
 // first descent's result, the last good continuation point)
-constexpr int TRIM_WS_J = FB_NTP, TRIM_WS_Z = TRIM_WS_J + 3 * TRIM_N * TRIM_N, TRIM_WS_ROWS = TRIM_WS_Z + 3 * TRIM_N;
+constexpr int TRIM_WS_J = FB_NTP, TRIM_WS_Z = TRIM_WS_J + 3 * TRIM_N * TRIM_N, TRIM_WS_ENV = TRIM_WS_Z + 3 * TRIM_N, TRIM_WS_ROWS = TRIM_WS_ENV + ENV_DEV_ROWS;   // (the last rows: the lane's aircraft's environment, k_trim<true>)
 template <class A7>
 __device__ __forceinline__ double pick7(const A7& v, int k) {   // v[k] for a lane-dependent k: a select chain (a dynamic register index would be scratch)
     double x = v[0];
@@ -2191,6 +2208,9 @@ __device__ __forceinline__ double pick7(const A7& v, int k) {   // v[k] for a la
     for (int m = 1; m < TRIM_N; m++) x = (k == m) ? v[m] : x;
     return x;
 }
+// PERENV: every aircraft in its own environment (fb_set_env): a lane parks its aircraft's rows in the workspace next to the trim parameters
+// when it takes the aircraft from the queue and reads them back where the residual is evaluated (the parameters' own way)
+template <bool PERENV>
 __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* ts, int32_t* success, double* cost_out, unsigned long long* next, double* ws) {
     __shared__ double lds[LDS_TABLE_DOUBLES_STEP];
     __shared__ double rk[LDS_RK_DOUBLES];
@@ -2203,6 +2223,12 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     double* const wsl = ws + slot;
     auto Jrow = [&](int m, int i, int j) -> double& { return wsl[(int64_t)(TRIM_WS_J + (m * N + i) * N + j) * W]; };
     auto Zrow = [&](int v, int k) -> double& { return wsl[(int64_t)(TRIM_WS_Z + v * N + k) * W]; };   // v: 0 the given state, 1 the first descent's result, 2 the last good continuation point
+    auto env_now = [&]() -> Env {
+        if constexpr (PERENV) {
+            auto E = [&](int k) { return wsl[(int64_t)(TRIM_WS_ENV + k) * W]; };
+            return {E(FB_ENV_T_SL), E(FB_ENV_P_SL), E(FB_ENV_WIND_N), E(FB_ENV_WIND_E), E(FB_ENV_WIND_D), E(FB_ENV_H_TERRAIN), a.env.surface, E(ENV_DEV_LN_P), E(ENV_DEV_K_RT)};
+        } else return a.env;
+    };
     const double lo[N] = {TRIM_LO[0], TRIM_LO[1], TRIM_LO[2], TRIM_LO[3], TRIM_LO[4], TRIM_LO[5], TRIM_LO[6]};
     const double hi[N] = {TRIM_HI[0], TRIM_HI[1], TRIM_HI[2], TRIM_HI[3], TRIM_HI[4], TRIM_HI[5], TRIM_HI[6]};
     const double fd = 1e-6;
@@ -2223,7 +2249,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
             if (!active && i >= 0) {   // assign!(vehicle, params, state_opt) with the REQUESTED parameters
                 TrimP p;
                 trim_load_params(p, tp, n, i);
-                trim_leave_body(a, p, S.z, T, ts, success, cost_out, S.cost, i);
+                trim_leave_body(a, env_now(), p, S.z, T, ts, success, cost_out, S.cost, i);
                 i = -1;
             }
             if (more) {
@@ -2236,6 +2262,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                     if (mine < n) {
                         i = mine;
                         for (int k = 0; k < FB_NTP; k++) wsl[(int64_t)k * W] = tp[(int64_t)k * n + i];
+                        if constexpr (PERENV) for (int k = 0; k < ENV_DEV_ROWS; k++) wsl[(int64_t)(TRIM_WS_ENV + k) * W] = a.env_rows[(int64_t)k * n + i];
 #pragma unroll
                         for (int k = 0; k < N; k++) { S.z[k] = ts[(int64_t)k * n + i]; Zrow(0, k) = S.z[k]; }
                         active = true; fresh = true; mode = 0; maxit = TRIM_MAX_ITER;
@@ -2358,7 +2385,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                 if (need) {
                     TrimP p;
                     trim_load_params(p, ws, W, slot);
-                    trim_resid_body<true>(p, zq, a.env, T, rq);
+                    trim_resid_body<true>(p, zq, env_now(), T, rq);
                 }
             }
             // ---- what the lane does with them

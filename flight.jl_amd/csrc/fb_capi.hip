@@ -52,6 +52,7 @@ struct fb_handle_s {
     float* egm96 = nullptr;
     double* trim_buf = nullptr;  // tp | ts | cost
     int32_t* trim_ok = nullptr;
+    double* env_rows = nullptr;  // [ENV_DEV_ROWS x n] per-aircraft environment (fb_set_env), null: the batch-wide fb_params block
     double* trim_ws = nullptr;   // k_trim's workspace: TRIM_WS_ROWS rows per resident lane, allocated by the first fb_trim and kept until fb_destroy (~100 MB on 256 CUs)
     bool have_table[4] = {false, false, false, false};
     fb_params params;
@@ -88,6 +89,7 @@ static KArgs make_args(fb_handle h) {
     a.env = {h->params.T_sl, h->params.p_sl, h->params.wind_ned[0], h->params.wind_ned[1], h->params.wind_ned[2], h->params.h_terrain, h->params.surface,
              log(h->params.p_sl / 101325.0),
              exp(0.5 * 6.5e-3 * 287.05287 / 9.80665 * log(h->params.p_sl / 101325.0)) / sqrt(h->params.T_sl)};
+    a.env_rows = h->env_rows;
     a.dt = h->params.dt;
     a.cs = h->cs; a.cu = h->cu; a.q_pre = h->q_pre; a.redo = h->redo; a.k1 = h->k1; a.k1_valid = h->k1_valid;
     if (getenv("FB_NO_FSAL_CARRY")) a.k1 = nullptr;   // A/B switch for measurements
@@ -171,8 +173,14 @@ static row_map_t row_map_of(fb_handle h) {
 // by the wave-specialised k_step_duo<KIN, X> (two waves per SIMD) unless it is 0, which selects the one-wave-per-SIMD k_step_air<KIN, X>
 static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
+#define FB_STEP_PERENV(KIN, X, GRID, A, K)                                                                                            \
+    do {   /* per-aircraft environment rows: the one-wave kernel, both passes (KArgs::env_rows) */                                    \
+        hipLaunchKernelGGL((k_step_air<KIN, X, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                           \
+        hipLaunchKernelGGL((k_step_air<KIN, X, true, true>), grid_for(h->n, step_block<X, true>()), dim3(step_block<X, true>()), 0, h->stream, A, K); \
+    } while (0)
 #define FB_STEP_X2(KIN, GRID, A, K)                                                                                                   \
     do {                                                                                                                              \
+        if (h->env_rows) { FB_STEP_PERENV(KIN, true, GRID, A, K); break; }                                                            \
         if (h->duo) hipLaunchKernelGGL((k_step_duo<KIN, true>), grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);         \
         else hipLaunchKernelGGL((k_step_air<KIN, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                                \
         hipLaunchKernelGGL((k_step_air<KIN, true, true>), grid_for(h->n, step_block<true, true>()), dim3(step_block<true, true>()), 0, h->stream, A, K); \
@@ -189,6 +197,9 @@ static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e
         if (is_x2(h) && h->kin == FB_KIN_ECEF) FB_STEP_X2(FB_KIN_ECEF, GRID, A, K);                                                   \
         else if (is_x2(h) && h->kin == FB_KIN_NED) FB_STEP_X2(FB_KIN_NED, GRID, A, K);                                                \
         else if (is_x2(h)) FB_STEP_X2(FB_KIN_WA, GRID, A, K);                                                                         \
+        else if (h->env_rows && h->kin == FB_KIN_ECEF) FB_STEP_PERENV(FB_KIN_ECEF, false, GRID, A, K);                                \
+        else if (h->env_rows && h->kin == FB_KIN_NED) FB_STEP_PERENV(FB_KIN_NED, false, GRID, A, K);                                  \
+        else if (h->env_rows) FB_STEP_PERENV(FB_KIN_WA, false, GRID, A, K);   /* (FB_F32 handles too: the fp32 stepper is batch-wide only) */ \
         else if (h->kin == FB_KIN_ECEF) {                                                                                           \
             if (h->duo) hipLaunchKernelGGL(k_step_duo<FB_KIN_ECEF>, grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);  \
             else hipLaunchKernelGGL(k_step_air<FB_KIN_ECEF>, GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                            \
@@ -324,7 +335,7 @@ int32_t fb_destroy(fb_handle h) {
     log_free(h);
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->term_step); hipFree(h->term_where); hipFree(h->y); hipFree(h->xdot);
-    hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok); hipFree(h->trim_ws);
+    hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok); hipFree(h->trim_ws); hipFree(h->env_rows);
     hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->duo_tap); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     hipStreamDestroy(h->own_stream);
@@ -459,6 +470,45 @@ int32_t fb_get_params(fb_handle h, fb_params* p) {
     *p = h->params;
     return 0;
 }
+// Per-aircraft environment rows (include/flightbatch.h, FB_ENV_*). The two derived rows are filled here the way make_args fills
+// Env::ln_p_sl / Env::k_rt for the batch-wide block (same expressions, the host's libm).
+int32_t fb_set_env(fb_handle h, const double* env) {
+    if (!h) return fail("null handle");
+    if (h->model == FB_MODEL_ROBOT2D) return fail("Robot2D has no environment");
+    fsal_invalidate(h);
+    HIPCHK(hipSetDevice(h->device));
+    if (!env) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->env_rows);
+        h->env_rows = nullptr;
+        return 0;
+    }
+    const int64_t n = h->n;
+    for (int64_t i = 0; i < n; i++) {
+        const double T = env[(int64_t)FB_ENV_T_SL * n + i], p = env[(int64_t)FB_ENV_P_SL * n + i];
+        if (!(T > 0) || !(p > 0)) return fail("fb_set_env: aircraft %lld has sea-level T = %g K, p = %g Pa (both must be positive)", (long long)i, T, p);
+    }
+    std::vector<double> rows((size_t)fbd::ENV_DEV_ROWS * n);
+    std::memcpy(rows.data(), env, sizeof(double) * FB_NENV * n);
+    for (int64_t i = 0; i < n; i++) {
+        const double T = env[(int64_t)FB_ENV_T_SL * n + i], p = env[(int64_t)FB_ENV_P_SL * n + i];
+        const double lnp = log(p / 101325.0);
+        rows[(size_t)fbd::ENV_DEV_LN_P * n + i] = lnp;
+        rows[(size_t)fbd::ENV_DEV_K_RT * n + i] = exp(0.5 * 6.5e-3 * 287.05287 / 9.80665 * lnp) / sqrt(T);
+    }
+    if (!h->env_rows) HIPCHK(hipMalloc(&h->env_rows, sizeof(double) * fbd::ENV_DEV_ROWS * n));
+    HIPCHK(hipMemcpyAsync(h->env_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_get_env(fb_handle h, double* env) {
+    if (!h || !env) return fail("null argument");
+    if (!h->env_rows) return fail("no per-aircraft environment rows are set (fb_set_env): the batch-wide block is fb_get_params'");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(env, h->env_rows, sizeof(double) * FB_NENV * h->n, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 static int32_t set_state_impl(fb_handle h, const double* x, const int32_t* s, bool init) {
     if (h) fsal_invalidate(h);
@@ -547,7 +597,8 @@ int32_t fb_trim(fb_handle h, const double* trim_params, double* trim_state, int3
     HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     const int64_t trim_waves = std::min<int64_t>((n + 63) / 64, (int64_t)n_cu * 4);
     if (!h->trim_ws) HIPCHK(hipMalloc(&h->trim_ws, sizeof(double) * fbd::TRIM_WS_ROWS * 64 * trim_waves));
-    hipLaunchKernelGGL(k_trim, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, h->trim_ws);
+    if (h->env_rows) hipLaunchKernelGGL(k_trim<true>, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, h->trim_ws);
+    else hipLaunchKernelGGL(k_trim<false>, dim3((unsigned)trim_waves), dim3(64), 0, h->stream, make_args(h), (const double*)d_tp, d_ts, h->trim_ok, d_cost, d_next, h->trim_ws);
     HIPCHK(hipGetLastError());
     if (h->kin == FB_KIN_ECEF) hipLaunchKernelGGL(k_kin_convert<FB_KIN_ECEF>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);
     if (h->kin == FB_KIN_NED) hipLaunchKernelGGL(k_kin_convert<FB_KIN_NED>, grid_for(n, 256), dim3(256), 0, h->stream, make_args(h), (const double*)d_tp);

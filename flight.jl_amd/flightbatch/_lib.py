@@ -38,6 +38,8 @@ def _load():
         "fb_set_table": ([H, C.c_int32, VP, C.POINTER(I64), C.c_int32], C.c_int32),
         "fb_set_params": ([H, C.POINTER(fb_params)], C.c_int32),
         "fb_get_params": ([H, C.POINTER(fb_params)], C.c_int32),
+        "fb_set_env": ([H, D], C.c_int32),
+        "fb_get_env": ([H, D], C.c_int32),
         "fb_set_state": ([H, D, I32], C.c_int32),
         "fb_assign_state": ([H, D, I32], C.c_int32),
         "fb_get_state": ([H, D, I32], C.c_int32),

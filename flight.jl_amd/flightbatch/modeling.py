@@ -147,6 +147,44 @@ class BatchedWorld:
                 setattr(p, k, v)
         check(lib.fb_set_params(self._h, C.byref(p)))
 
+    # -- per-aircraft environment: each simulation's own world.atmosphere.sl.u / .wind.u and terrain elevation (FP/atmosphere.jl:75-84,
+    #    156-165; FP/terrain.jl:34-36): rows FB_ENV_WIND_N, _E, _D, FB_ENV_T_SL, FB_ENV_P_SL, FB_ENV_H_TERRAIN of an [FB_NENV, n] array. None (the
+    #    default) = the batch-wide block of `params`. --
+    @property
+    def env(self):
+        if not getattr(self, "_has_env", False):
+            return None
+        e = np.empty((K["FB_NENV"], self.n))
+        check(lib.fb_get_env(self._h, _pd(e)))
+        return e
+
+    @env.setter
+    def env(self, v):
+        if v is None:
+            check(lib.fb_set_env(self._h, None))
+            self._has_env = False
+            return
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NENV"], self.n)
+        check(lib.fb_set_env(self._h, _pd(v)))
+        self._has_env = True
+
+    def set_env(self, wind_ned=None, T_sl=None, p_sl=None, h_terrain=None):
+        """Per-aircraft rows from keyword arrays (scalars broadcast; what is not given comes from the batch-wide `params`,
+        or from the rows already set): wind_ned [3, n] or (N, E, D), T_sl [n], p_sl [n], h_terrain [n]."""
+        e = self.env
+        if e is None:
+            p = self.params
+            e = np.empty((K["FB_NENV"], self.n))
+            e[K["FB_ENV_WIND_N"]], e[K["FB_ENV_WIND_E"]], e[K["FB_ENV_WIND_D"]] = p.wind_ned[0], p.wind_ned[1], p.wind_ned[2]
+            e[K["FB_ENV_T_SL"]], e[K["FB_ENV_P_SL"]], e[K["FB_ENV_H_TERRAIN"]] = p.T_sl, p.p_sl, p.h_terrain
+        if wind_ned is not None:
+            wv = np.asarray(wind_ned, dtype=np.float64)
+            e[K["FB_ENV_WIND_N"]:K["FB_ENV_WIND_D"] + 1] = wv.reshape(3, -1) if wv.ndim == 2 else wv[:, None]
+        for key, val in (("FB_ENV_T_SL", T_sl), ("FB_ENV_P_SL", p_sl), ("FB_ENV_H_TERRAIN", h_terrain)):
+            if val is not None:
+                e[K[key]] = np.asarray(val, dtype=np.float64)
+        self.env = e
+
     # -- mdl.x / mdl.s / mdl.u (FC/modeling.jl:89-101) --
     @property
     def x(self) -> np.ndarray:
@@ -242,11 +280,15 @@ class BatchedWorld:
         cnt = C.c_int64()
         check(lib.fb_get_step_count(self._h, C.byref(cnt)))
         ck = {k: getattr(self, k) for k in self._CKPT_ARRAYS}
+        if getattr(self, "_has_env", False):
+            ck["env"] = self.env
         tstep, twhere = self.termination
         ck.update(status=self.status, term_step=tstep, term_where=twhere, step_count=np.int64(cnt.value), t=np.float64(lib.fb_time(self._h)))
         return ck
 
     def restore(self, ck: dict) -> None:
+        if hasattr(type(self), "env") and self.MODEL != "FB_MODEL_ROBOT2D":
+            self.env = ck.get("env")     # (before the state: fb_set_env invalidates the derivative carried across launches, like any input change)
         if "s" in self._CKPT_ARRAYS:
             self.set_state(ck["x"], ck["s"])
         else:

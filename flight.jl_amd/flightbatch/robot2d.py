@@ -54,6 +54,7 @@ def robot2d_table(vehicle: dict | None = None, gains_path: str | None = None) ->
 
 class Robot2DWorld(BatchedWorld):
     """N independent `Model(Robot2D.Robot())` on one GPU. State record x [10, n] and inputs u [4, n]: include/flightbatch.h."""
+    MODEL = "FB_MODEL_ROBOT2D"
     _CKPT_ARRAYS = ("x", "u")
 
     def __init__(self, n: int, device: int = 0, dtype: str = "f64", vehicle: dict | None = None):

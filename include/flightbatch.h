@@ -230,6 +230,16 @@ typedef struct fb_params {
     double h_terrain;    /* HorizontalTerrain elevation (orthometric), FP/terrain.jl:34-36 */
 } fb_params;
 
+/* Per-aircraft environment (optional). In the reference every simulation owns its world: TunableSeaLevel's T / p, TunableWind's
+ * velocity and HorizontalTerrain's elevation are inputs / parameters of THAT world's atmosphere and terrain models
+ * (FP/atmosphere.jl:75-84, 156-165, 269-278; FP/terrain.jl:34-48; FP/world.jl:20-32) — N simulations, N environments. fb_params holds ONE
+ * block for the whole batch (the SURVEY's configurations share it); fb_set_env replaces its wind / sea-level / terrain-elevation
+ * fields by a row per aircraft: env [N x FB_NENV] (aircraft index fastest, like every array of this ABI). The surface type stays
+ * batch-wide. NULL returns to the batch-wide block. Handles with per-aircraft rows are stepped by the one-wave stepping kernel
+ * (k_step_air), fp64: the wave-pair kernel has no registers for nine more per-lane values. fb_trim, fb_f_ode,
+ * fb_f_step, fb_f_periodic, fb_f_init and fb_step all read the rows. Not for Robot2D (it has no environment). */
+enum { FB_ENV_WIND_N = 0, FB_ENV_WIND_E = 1, FB_ENV_WIND_D = 2, FB_ENV_T_SL = 3, FB_ENV_P_SL = 4, FB_ENV_H_TERRAIN = 5, FB_NENV = 6 };
+
 /* --------------------------------------------------------------------------------------------- */
 /* Model(SimpleWorld(...)) + Simulation(mdl; ...) : FC/modeling.jl:103-153, FC/sim.jl:183-255.
  * device_id >= 0 selects the HIP device; there is no CPU backend (device_id < 0 is an error). */
@@ -253,6 +263,10 @@ int32_t fb_attach_state(fb_handle h, void* x_dev, void* s_dev);
 int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t* dims, int32_t ndims);
 int32_t fb_set_params(fb_handle h, const fb_params* p);
 int32_t fb_get_params(fb_handle h, fb_params* p);
+/* world.atmosphere.{sl, wind}.u / terrain elevation, one row per aircraft (see FB_ENV_* above); env = NULL: back to fb_params.
+ * fb_get_env fails when no rows are set. */
+int32_t fb_set_env(fb_handle h, const double* env);
+int32_t fb_get_env(fb_handle h, double* env);
 
 /* mdl.x / mdl.s / mdl.u access : FC/modeling.jl:89-101 ; property forwarding FC/sim.jl:261-275.
  * fb_set_state sets an INITIAL condition: like init! (FC/sim.jl:390-414) it also clears the sticky status words and restarts the

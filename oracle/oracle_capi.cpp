@@ -30,6 +30,17 @@ static Env env_from(const double* e) {
     v.T_sl = e[0]; v.p_sl = e[1]; v.wind = {e[2], e[3], e[4]}; v.h_trn = e[5]; v.surface = (int)e[6];
     return v;
 }
+// Every simulation of the reference owns its world (atmosphere.jl:75-84,156-165; terrain.jl:34-48): with fo_set_env_per_aircraft(1) the
+// `env` argument of the batch entry points is [7 x n] (row k of aircraft i at env[k n + i]) instead of one block of 7 for the batch.
+static bool g_env_per_aircraft = false;
+struct EnvSrc {
+    const double* env; int64_t n;
+    Env at(int64_t i) const {
+        if (!g_env_per_aircraft) return env_from(env);
+        const double e[7] = {env[0 * n + i], env[1 * n + i], env[2 * n + i], env[3 * n + i], env[4 * n + i], env[5 * n + i], env[6 * n + i]};
+        return env_from(e);
+    }
+};
 static C172Inputs inputs_from(const double* u, const int32_t* ui, int64_t n, int64_t i) {
     C172Inputs c;
     auto U = [&](int k) { return u[k * n + i]; };
@@ -130,6 +141,7 @@ int32_t fo_max_threads() {
 
 // kinematic mechanisation used by every fo_c172_* call that follows (0 WA, 1 ECEF, 2 NED); state arrays keep 27 rows,
 // rows 12.. hold the mechanisation's 9 / 8 / 6 states and the unused ones stay zero
+int32_t fo_set_env_per_aircraft(int32_t on) { g_env_per_aircraft = on != 0; return 0; }
 int32_t fo_set_kinematics(int32_t kin) {
     if (!g_model || kin < 0 || kin > 2) return -1;
     g_model->kin = kin;
@@ -138,8 +150,9 @@ int32_t fo_set_kinematics(int32_t kin) {
 // f_ode!(world) for n aircraft. env[7] = T_sl, p_sl, wind N,E,D, h_terrain, surface.
 int32_t fo_c172_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* env,
                       double* xdot, double* y, int32_t* status) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NX], xd[NX];
         for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
         C172Disc d;
@@ -154,8 +167,9 @@ int32_t fo_c172_f_ode(int64_t n, const double* x, const double* u, const int32_t
 }
 // f_step!(world): acts on the y of an f_ode! at the current x (recomputed here, pure function).
 int32_t fo_c172_f_step(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, int32_t* status) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NX], xd[NX];
         for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
         C172Disc d;
@@ -182,12 +196,13 @@ int32_t fo_c172_f_step(int64_t n, double* x, const double* u, const int32_t* ui,
 static int32_t c172_step_many(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, const double* env, double dt,
                               int64_t nsteps, int32_t* status, int32_t threads, int32_t reference_like, double* traj, int64_t save_every,
                               int64_t step0, int64_t* term_step, int32_t* term_where) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for num_threads(nt) schedule(static)
 #endif
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NX];
         for (int k = 0; k < NX; k++) xi[k] = x[k * n + i];
         C172Disc d;
@@ -234,13 +249,14 @@ int64_t fo_trim_continued(void) { return g_trim_continued; }
 // f_init!(world, TrimParameters) for n aircraft. tp [n x FB_NTP], ts [n x FB_NTS] in/out.
 int32_t fo_c172_trim(int64_t n, const double* tp, double* ts, const double* env, double* x, double* u, int32_t* ui, int32_t* s,
                      int32_t* success, double* cost, int32_t threads) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     int64_t evals = 0, continued = 0;
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for num_threads(nt) schedule(dynamic, 16) reduction(+ : evals, continued)
 #endif
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         auto TP = [&](int k) { return tp[k * n + i]; };
         TrimParams p;
         p.n_e = {TP(FB_TP_N_E), TP(FB_TP_N_E + 1), TP(FB_TP_N_E + 2)};
@@ -659,13 +675,14 @@ void fo_segment_data(const double* p1, const double* p2, const double* ob, doubl
 // f_init!(aircraft, TrimParameters): trim, actuator states, control-law initialisation. dT = controller sample period.
 int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double* env, const double* blob, double dT, double* x,
                            double* u, int32_t* ui, int32_t* s, double* cu, double* cs, int32_t* success, double* cost, int32_t threads) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     CtlGains G; G.bind(blob);
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for num_threads(nt) schedule(dynamic, 16)
 #endif
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         const TrimParams p = trim_params_from(tp, n, i);
         TrimState t{ts[0 * n + i], ts[1 * n + i], ts[2 * n + i], ts[3 * n + i], ts[4 * n + i], ts[5 * n + i], ts[6 * n + i]};
         double xi[NXX], cui[FB_NCU] = {}, csi[FB_NCS] = {}, c = 0;
@@ -688,13 +705,14 @@ int32_t fo_c172x_trim_init(int64_t n, const double* tp, double* ts, const double
 static int32_t c172x_step_many(int64_t n, double* x, const double* u, const int32_t* ui, int32_t* s, double* cu, double* cs,
                                const double* env, const double* blob, double dt, int32_t ratio, int64_t step0, int64_t nsteps, int32_t* status,
                                int32_t threads, double* traj, int64_t save_every, int64_t* term_step, int32_t* term_where) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     CtlGains G; G.bind(blob);
 #ifdef _OPENMP
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for num_threads(nt) schedule(static)
 #endif
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NXX], cui[FB_NCU], csi[FB_NCS];
         for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
         for (int k = 0; k < FB_NCU; k++) cui[k] = cu[k * n + i];
@@ -741,8 +759,9 @@ int32_t fo_c172x_step_term(int64_t n, double* x, const double* u, const int32_t*
 // f_ode!(world) of the X model: xdot [34 x n], y as Cessna172Sv0
 int32_t fo_c172x_f_ode(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, const double* cs, const double* env,
                        double* xdot, double* y, int32_t* status) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NXX], xd[NXX], csi[FB_NCS], cmd7[7];
         for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
         for (int k = 0; k < FB_NCS; k++) csi[k] = cs[k * n + i];
@@ -761,9 +780,10 @@ int32_t fo_c172x_f_ode(int64_t n, const double* x, const double* u, const int32_
 // f_periodic!(Unconditional(), world): the control laws on the y of an f_ode! at the current x
 int32_t fo_c172x_f_periodic(int64_t n, const double* x, const double* u, const int32_t* ui, const int32_t* s, double* cu, double* cs,
                             const double* env, const double* blob, double dT) {
-    const Env e = env_from(env);
+    const EnvSrc E_{env, n};
     CtlGains G; G.bind(blob);
     for (int64_t i = 0; i < n; i++) {
+        const Env e = E_.at(i);
         double xi[NXX], xd[NXX], cui[FB_NCU], csi[FB_NCS], cmd7[7];
         for (int k = 0; k < NXX; k++) xi[k] = x[k * n + i];
         for (int k = 0; k < FB_NCU; k++) cui[k] = cu[k * n + i];

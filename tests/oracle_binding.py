@@ -60,6 +60,26 @@ class Oracle:
     def default_env(T_sl=288.15, p_sl=101325.0, wind=(0.0, 0.0, 0.0), h_trn=0.0, surface=0):
         return np.array([T_sl, p_sl, wind[0], wind[1], wind[2], h_trn, float(surface)])
 
+    def per_aircraft_env(self):
+        """context manager: inside it the `env` argument of every batch call is [7, n] — one environment per aircraft (each simulation of the
+        reference owns its world) — built with env_rows()."""
+        lib = self.lib
+
+        class _Scope:
+            def __enter__(self_inner):
+                lib.fo_set_env_per_aircraft(1)
+
+            def __exit__(self_inner, *a):
+                lib.fo_set_env_per_aircraft(0)
+        return _Scope()
+
+    @staticmethod
+    def env_rows(env6, surface=0):
+        """the product's per-aircraft panel [FB_NENV, n] (wind N, E, D, T_sl, p_sl, h_terrain) in the oracle's row order [7, n]"""
+        env6 = np.asarray(env6, dtype=np.float64)
+        n = env6.shape[1]
+        return np.ascontiguousarray(np.stack([env6[3], env6[4], env6[0], env6[1], env6[2], env6[5], np.full(n, float(surface))]))
+
     def max_threads(self):
         return int(self.lib.fo_max_threads())
 
