@@ -3,7 +3,10 @@
 every aircraft flies the final leg to runway 15 of LOWS under segment guidance in a 6 m/s crosswind, flares 6 m above the
 runway (climb-rate hold at -0.3 m/s, crab turned into a sideslip), closes the throttle at touchdown and brakes to a stop.
 The phase logic is the demo's user callback, vectorised over the batch; the aircraft differ in their starting distance and
-approach speed. `python examples/crosswind_landing.py [n]` prints a summary; tests/test_gpu_scenarios.py asserts on it."""
+approach speed — and, with `crosswind=` (an array, or `python examples/crosswind_landing.py n disperse`), in the WIND each of them
+lands in: the demo sets `world.atmosphere.wind.u.E = 6` on its one simulation (c172_demos.jl:424), a batch is N simulations, each with
+its own world, so a touchdown-dispersion study over a wind distribution is one launch sequence (BatchedWorld.set_env, fb_set_env).
+`python examples/crosswind_landing.py [n]` prints a summary; tests/test_gpu_scenarios.py asserts on it."""
 import os
 import sys
 import numpy as np
@@ -16,15 +19,20 @@ from flightbatch.guidance import Segment  # noqa: E402
 LOC = (np.deg2rad(47.80433), np.deg2rad(12.997)); H_ORTH = 427.2; PSI = np.deg2rad(157.0)   # c172_demos.jl:17-19
 
 
-def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False, kinematics="WA"):
+def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False, kinematics="WA", crosswind=None):
     """hold_decrab = False: the demo's callback to the letter — it leaves `seg.u.hor_gdc_req` set in the flare, so the guidance law puts the
     lateral channel back on track hold (χ_β) at its next update and the de-crab (φ_β with β_ref = ψ − χ_12) lasts one control period.
     hold_decrab = True: the request is dropped at the flare, so the bank + sideslip mode stays in force until touchdown (a variant, not
-    the demo)."""
+    the demo).
+    crosswind: None — the demo's 6 m/s from the east for every aircraft (batch-wide fb_params) — or [n] east-wind components, one per
+    aircraft (per-aircraft environment rows)."""
     K = fb.K
     rng = np.random.default_rng(seed)
     w = fb.Cessna172Xv2World(n, kinematics=kinematics)               # Cessna172Xv2(kinematics): WA (the demo's), ECEF or NED
     w.set_params(h_terrain=H_ORTH, wind_ned=(0.0, 6.0, 0.0))          # HorizontalTerrain(h_LOWS15); atmosphere.wind.u.E = 6
+    if crosswind is not None:   # every simulation's own atmosphere.wind.u (FP/atmosphere.jl:156-165); terrain and sea level from the block above
+        cw = np.asarray(crosswind, dtype=np.float64).reshape(n)
+        w.set_env(wind_ned=np.stack([np.zeros(n), cw, np.zeros(n)]))
     # ellipsoidal altitude of the runway: orthometric + geoid height at the threshold (asked from the device model itself)
     probe = fb.TrimParameters(n_e=np.array([np.cos(LOC[0]) * np.cos(LOC[1]), np.cos(LOC[0]) * np.sin(LOC[1]), np.sin(LOC[0])]), h_e=1000.0)
     sim = fb.Simulation(w, dt=dt, Δt=dt, save_on=False, steps_per_launch=1)
@@ -100,4 +108,15 @@ def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False, ki
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 64, verbose=True, hold_decrab=len(sys.argv) > 2 and sys.argv[2] == "hold")
+    n_ = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    if len(sys.argv) > 2 and sys.argv[2] == "disperse":   # touchdown dispersion over a crosswind distribution: 0 ... 9 m/s from the east
+        cw_ = np.random.default_rng(1).uniform(0.0, 9.0, n_)
+        o_ = run(n_, verbose=True, crosswind=cw_, hold_decrab=True)
+        td_ = o_["touchdown"]
+        for lo_ in range(0, 9, 3):
+            m_ = (cw_ >= lo_) & (cw_ < lo_ + 3) & np.isfinite(td_[0])
+            if m_.any():
+                print(f"crosswind {lo_}-{lo_ + 3} m/s: {int(m_.sum())} aircraft, touchdown {td_[1][m_].mean():.0f} ± {td_[1][m_].std():.0f} m past the threshold, "
+                      f"cross-track {td_[2][m_].mean():+.2f} ± {td_[2][m_].std():.2f} m")
+    else:
+        run(n_, verbose=True, hold_decrab=len(sys.argv) > 2 and sys.argv[2] == "hold")

@@ -27,6 +27,32 @@ def test_crosswind_landing_batch(fb, hold_decrab):
     assert out["v_gnd"].max() < 0.5 and np.abs(out["h_agl"] - 1.85).max() < 0.2         # stopped, sitting on its wheels
 
 
+def test_crosswind_landing_wind_dispersion(fb):
+    """Every aircraft lands in its OWN crosswind (per-aircraft environment rows, fb_set_env): rows that repeat the demo's 6 m/s give the
+    batch-wide run's touchdown points (the rows are read by the one-wave kernels, the batch-wide block by the wave-pair kernel: same
+    arithmetic, to rounding), and over a 0 ... 9 m/s distribution every aircraft still lands on the runway — with the crab angle at
+    the flare growing with the crosswind it flies in."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import crosswind_landing as demo
+    n = 32
+    ref = demo.run(n=n, t_end=150.0, seed=3)
+    same = demo.run(n=n, t_end=150.0, seed=3, crosswind=np.full(n, 6.0))
+    d = np.abs(same["touchdown"] - ref["touchdown"])
+    print("rows = the batch-wide block: touchdown differs by %.2e s, %.2e m along, %.2e m across" % (d[0].max(), d[1].max(), d[2].max()))
+    assert (same["status"] == 0).all() and (same["phase"] == 3).all()
+    assert d[0].max() < 0.05 and d[1].max() < 1.0 and d[2].max() < 0.1
+    cw = np.linspace(0.0, 9.0, n)
+    out = demo.run(n=n, t_end=150.0, seed=3, crosswind=cw)
+    td = out["touchdown"]
+    assert (out["status"] == 0).all() and (out["phase"] == 3).all()
+    assert np.isfinite(td).all() and (td[1] > -50).all() and (td[1] < 300).all() and np.abs(td[2]).max() < 4.0
+    assert out["v_gnd"].max() < 0.5
+    # the wind each aircraft flew in is its own: touchdown times differ with it (ground speed on final = airspeed along track),
+    # and the aircraft in no crosswind touched down closest to the centreline
+    assert np.abs(td[2][:4]).mean() < np.abs(td[2][-4:]).mean() + 0.5
+    assert not np.allclose(td[:, 0], td[:, -1])
+
+
 @pytest.mark.parametrize("kin", ["ECEF", "NED"])
 def test_crosswind_landing_in_the_other_mechanisations(fb, kin):
     """The same scripted landing with Cessna172Xv2(ECEF()) / Cessna172Xv2(NED()): guidance on the tapped latitude / longitude, the flare,
