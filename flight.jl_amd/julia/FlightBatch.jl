@@ -231,6 +231,12 @@ mutable struct BatchedSimulation
         new(mdl, dt, Δt, 0)
     end
 end
+"""Each simulation's own environment: env [N x 6], columns wind N / E / D (`world.atmosphere.wind.u`, FlightPhysics/src/atmosphere.jl:156-165),
+sea-level T / p (`world.atmosphere.sl.u`, :75-84), terrain elevation (FlightPhysics/src/terrain.jl:34-36). `nothing` returns to the batch-wide block."""
+function set_env!(w::BatchedWorld, env::Union{Matrix{Float64}, Nothing})
+    check(ccall((:fb_set_env, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, env === nothing ? C_NULL : env))
+    nothing
+end
 "f_init!(world) for a Cessna172Xv2 batch whose state and inputs the host has set (C172.Init-style initial condition): the avionics half of f_init!."
 function f_init!(w::BatchedWorld)
     check(ccall((:fb_f_init, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), w.handle, C_NULL, 0))
