@@ -32,6 +32,15 @@
 //   * the control and flag words of an evaluation are role D's, written before its point T, which role P waits for at the top of its loop
 //     (role D has waited for W of the evaluation before, so role P has long read the previous ones).
 #pragma once
+// 1: role P keeps its aircraft's EGM96 cell (indices + four samples, six registers of the ~130 it has to spare) across the evaluations of a launch
+// and gathers again only when the aircraft has left the cell: geoid_height_cached (c172_device_impl.inc). 0 (shipped): gather at every evaluation.
+// Measured, round 5 (profiles/r05_ab_geoid_cache.txt, same box, alternating): a fleet spread over the sphere 14.21-14.24 -> 14.01-14.02 ms per
+// launch — the whole cost of dispersion (1.7 %) — but the benchmark batch, which sits in ONE cell (every gather a wave-wide broadcast that
+// hits the L2), 13.96 -> 14.03 ms: the compare-and-branch per evaluation costs the pair more issue slots than the four broadcast loads did.
+// The headline configuration decides; a user whose fleet covers the globe builds with -DFB_DUO_GEOID_CACHE=1.
+#ifndef FB_DUO_GEOID_CACHE
+#define FB_DUO_GEOID_CACHE 0
+#endif
 #include "c172_device.hpp"
 
 namespace fbd {
@@ -123,7 +132,10 @@ __device__ __forceinline__ int32_t rhs_duo(const XV& x, int stall, int eng_state
         emit.xpub(DUO_PT_R);   // ----- point R: state rows read (role D may rewrite the kinematics rows; this wave's previous evaluation is complete) -----
         if constexpr (X) __builtin_amdgcn_s_setprio(0);   // (Cessna172Xv2: this role ran ahead of role D from the top of its loop to here, see k_step_duo)
         double lat, lon;
-        const double N_geoid = geoid_height<true>(T, n_e, lat, lon);
+        // (the Cessna172Sv0 instances: role P has the six registers; in the Cessna172Xv2 ones, where it also carries the actuators, they spill)
+        double N_geoid;
+        if constexpr (FB_DUO_GEOID_CACHE && !Emit::x2) N_geoid = geoid_height_cached(T, n_e, lat, lon, *emit.gcache);
+        else N_geoid = geoid_height<true>(T, n_e, lat, lon);
         const double h_o = h_e - N_geoid;
         if (!(h_o >= H_MIN)) st |= FB_ST_ALT_RANGE;
         if constexpr (X) {

@@ -1276,6 +1276,7 @@ struct DuoEmit {
     bool tap;          // wave-uniform (Cessna172Xv2): this is the step's last f_ode! and a control update follows it
     int64_t ai;        // the lane's aircraft
     const double* xn_r = nullptr;   // role P (FB_DUO_P_XN_REGS): x_n of its own rows
+    GeoidCache* gcache = nullptr;   // role P (FB_DUO_GEOID_CACHE): the EGM96 cell of the lane's aircraft, kept from evaluation to evaluation
     // rows k0 .. k0 + N - 1 of KArgs::duo_tap (base and stride re-read from the kernel's arguments: once per control period, see kernarg())
     template <int N>
     __device__ __forceinline__ void tap_rows(int k0, const double (&v)[N]) const {
@@ -1490,6 +1491,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         }
         double acc_r[NP - DUO_NPL];
         double xn_r[NP] = {0, 0, 0, 0};
+        GeoidCache gcache = {-1, -1, 0.0f, 0.0f, 0.0f, 0.0f};   // (no cell yet: the first evaluation gathers)
 #pragma unroll
         for (int k = 0; k < NP - DUO_NPL; k++) acc_r[k] = 0.0;
 #pragma unroll
@@ -1586,7 +1588,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     DUO_MARK(1, 12);   // (Cessna172Xv2: stage positions and aerodynamic sums formed and stored)
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
                     const DuoEmit<1, X> emit = {(lds_cptr)xs_l, sk.xwr_l, (lds_ptr)accp_l, acc_r, (lds_ptr)xch_l, (lds_ptr)xc_l + 15 * B, sk.eb, sk.ee, sk.em, sk.last, t, &sy,
-                                                tap, i, xn_r};
+                                                tap, i, xn_r, &gcache};
                     if constexpr (X) {
                         if (tap) {   // what the control laws read of the actuators: the Ranged positions of the state x_{n+1} (InputsX::pos), and the commands this f_ode! saw
                             static_assert(DUO_TAP_CMD == DUO_TAP_POS + 4, "positions, then commands");
