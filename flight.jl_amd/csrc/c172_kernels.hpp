@@ -249,9 +249,9 @@ FBD kargs_cptr kernarg() {
 // Per-aircraft environment (fb_set_env): in the reference wind, sea-level conditions and terrain elevation are inputs of EACH simulation's own
 // atmosphere / terrain models (FP/atmosphere.jl:75-84,156-165, FP/terrain.jl:34-48) — N simulations, N environments. Rows FB_ENV_* of the
 // caller's panel, then two derived rows the host fills like make_args fills Env::ln_p_sl / k_rt. The surface type stays batch-wide.
-// A kernel instance with PERENV holds the lane's nine values in VGPRs (the batch-wide block sits in SGPRs): the stepping kernels that have
-// the registers for it (k_step_air, one wave per SIMD) are instantiated both ways, k_step_duo — 248 of 256 registers — only batch-wide
-// (fb_step routes a handle with per-aircraft rows through k_step_air<.., true>), the single-call verbs choose at run time.
+// A kernel instance with PERENV holds the lane's nine values in VGPRs (the batch-wide block sits in SGPRs): k_step_air (one wave per SIMD,
+// registers to spare) in every mechanisation; k_step_duo in the WA mechanisation, where role P keeps its four values in registers and role
+// D reads its four from an 8 KB LDS panel (see there); the single-call verbs choose at run time.
 constexpr int ENV_DEV_LN_P = FB_NENV, ENV_DEV_K_RT = FB_NENV + 1, ENV_DEV_ROWS = FB_NENV + 2;
 FBD Env env_of(const KArgs& a, int64_t i) {
     const double* e = a.env_rows + i;
@@ -1372,7 +1372,11 @@ constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluatio
 #else
 #define DUO_PHASE(k) do { } while (0)
 #endif
-template <int KIN, bool X = false>
+// PERENV: every aircraft in its own environment (KArgs::env_rows, fb_set_env). Role P — ISA atmosphere, engine — keeps its four values (sea-level
+// T and p and the two derived from them) in registers, of which it has ~130 to spare; role D — wind-relative velocity, height over the terrain —
+// has none, and reads its four (wind N / E / D, terrain elevation) from an LDS panel of its own at the point of use (4 rows x 256 lanes: 8 KB
+// of the 10 KB the WA instances leave free; the ECEF / NED instances have no room and are stepped by k_step_air<.., PERENV>).
+template <int KIN, bool X = false, bool PERENV = false>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
     constexpr int NPT = X ? DUO_NPT + 1 : DUO_NPT;   // points per iteration of the evaluation loop
@@ -1389,6 +1393,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __shared__ double xch_l[(XD_ROWS - 6) * B];
     __shared__ int flags_l[B];
     __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
+    __shared__ double envd_l[PERENV ? 4 * B : 1];   // PERENV: role D's wind N / E / D and terrain elevation, [4][B] (written and read by role D alone)
     static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
     int* ctrl_l = (int*)&rk[LDS_ATAN + ATAN_N];   // one control word per wave pair (the LDS is full to the last 16 bytes)
     int* sync_l = ctrl_l + 4;                      // two synchronisation counters per wave pair: [pair] role P's, [4 + pair] role D's
@@ -1433,6 +1438,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                   (volatile __attribute__((address_space(3))) int*)(sync_l + (role == 1 ? 4 + pair : pair)), 0, 0};
     const bool valid = i < a.n && a.status[i] == 0;
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
+    Env env_p = a.env;   // what role P's evaluation reads of the environment: T_sl, p_sl, ln_p_sl, k_rt (rhs_duo<KIN, 1>)
+    if constexpr (PERENV) {
+        const Env e = (i < a.n) ? env_of(a, i) : a.env;
+        if (role == 1) env_p = e;
+        else { envd_l[0 * B + t] = e.wind_n; envd_l[1 * B + t] = e.wind_e; envd_l[2 * B + t] = e.wind_d; envd_l[3 * B + t] = e.h_trn; }
+    }
     // role D's per-lane bookkeeping word, kept in LDS between evaluations (role P reads it once, when the launch is over)
     enum { D_ALIVE = 1, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };   // (no lane ends its simulation here: a status bit is a hand-over)
     // what an evaluation at stage `stg` needs (wave-uniform)
@@ -1609,7 +1620,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     emit.xwait(DUO_PT_X);
                     (void)xv; (void)aux; (void)inl;
 #else
-                    rhs_duo<KIN, 1>(xv, 0, eng, inl, a.env, T, emit, aux);
+                    rhs_duo<KIN, 1>(xv, 0, eng, inl, env_p, T, emit, aux);
 #endif
                     if constexpr (X) {
                         if (sk.last) {
@@ -1784,7 +1795,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 emit.xpub(DUO_PT_V); emit.xwait(DUO_PT_R); emit.xwait(DUO_PT_A); emit.xwait(DUO_PT_W); emit.xpub(DUO_PT_X);
                 (void)xv; (void)inl; (void)d0;
 #else
-                bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, a.env, T, emit, aux);
+                Env env_d = a.env;   // role D reads wind_n / wind_e / wind_d and h_trn
+                if constexpr (PERENV) {   // (from its LDS panel, at every evaluation: role D has no registers to carry them; lds_off keeps the reads in the loop)
+                    lds_cptr ev = (lds_cptr)envd_l + t + lds_off;
+                    env_d.wind_n = ev[0 * B]; env_d.wind_e = ev[1 * B]; env_d.wind_d = ev[2 * B]; env_d.h_trn = ev[3 * B];
+                }
+                bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, env_d, T, emit, aux);
 #endif
             }
         } else duo_publish(sy, DUO_PT_X);   // (an evaluation nobody runs: role P must not wait for it)
