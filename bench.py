@@ -345,8 +345,8 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
                                   "(wind, EAS + climb-rate and bank + sideslip modes), autopilot every 2 steps (Δt = 0.02), fp64, dt = 0.01",
                       "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
            "stepping_launches": int(nl.value), "kernel_ms": ms.value / max(nl.value, 1), "stream_ms_per_rk4_step": ms.value / steps,
-           "kernel": ("fbd::k_step_duo<0, true> (two waves per SIMD; the control update in two halves inside the launch)" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0"
-                      else "fbd::k_step_air<0, true, false>") + " + the ground-capable pass behind it",
+           "kernel": ("fbd::k_step_duo<0, true, false> (two waves per SIMD; the control update in two halves inside the launch)" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0"
+                      else "fbd::k_step_air<0, true, false, false>") + " + the ground-capable pass behind it",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
                         "note": "algorithmic bytes = 756 B per aircraft-step (SURVEY §8d)"}}
     if gather_ms is not None:
@@ -600,7 +600,7 @@ def main():
                        "trim_success_fraction": head["trim_ok"] / head["n_total"], "trim_seconds": head["trim_s"], "terminated_aircraft": head["status_bad"],
                        "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= " + ("1e-8" if args.dtype == "f64" else "5e-7") + " (q_wb, q_ew), all states finite"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": (("fbd::k_step_duo<0, false>" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "fbd::k_step_air<0, false>") if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": (("fbd::k_step_duo<0, false, false>" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "fbd::k_step_air<0, false, false, false>") if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": f"algorithmic bytes = {bytes_per_unit:.0f} B per aircraft-step (SURVEY §8d" + ("" if args.dtype == "f64" else ", fp32 rows; q_ew / h_e stay fp64") + ") x N x inner steps per launch; the fused "
                                  "stepper is " + ("fp64" if args.dtype == "f64" else "fp32") + "-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,

@@ -23,7 +23,7 @@ N, INNER = 1 << 19, 50
 c = collections.defaultdict(list); dur = []
 for f in glob.glob("$OUT/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_step_duo<0, true>" in r["Kernel_Name"] or "k_step_air<0, true, false>" in r["Kernel_Name"]:
+        if "k_step_duo<0, true, false>" in r["Kernel_Name"] or "k_step_air<0, true, false, false>" in r["Kernel_Name"]:
             kname = r["Kernel_Name"]
             c[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))

@@ -20,16 +20,16 @@ for pl in point box sphere; do
 done
 python3 - >> $OUT/${TAG}_dispersed.txt <<PY
 import csv, glob, collections
-print("\n# per placement: rocprofv3 --kernel-trace --stats (k_step_duo<0, false>: calls, average / min / max ns) and the L2 counters per launch of that kernel")
+print("\n# per placement: rocprofv3 --kernel-trace --stats (k_step_duo<0, false, false>: calls, average / min / max ns) and the L2 counters per launch of that kernel")
 for pl in ("point", "box", "sphere"):
     for f in glob.glob("$OUT/stats_disp_%s/*/*_kernel_stats.csv" % pl):
         for r in csv.DictReader(open(f)):
-            if "k_step_duo<0, false>" in r["Name"]:
+            if "k_step_duo<0, false, false>" in r["Name"]:
                 print("%-7s stats: calls %s avg %.0f ns min %s max %s" % (pl, r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
     c = collections.defaultdict(list)
     for f in glob.glob("$OUT/pmc_disp_%s_*/*/*_counter_collection.csv" % pl):
         for r in csv.DictReader(open(f)):
-            if "k_step_duo<0, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "k_step_duo<0, false, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
     if c: print("%-7s pmc per launch: " % pl + ", ".join("%s %.4g" % (k, sum(v) / len(v)) for k, v in sorted(c.items())))
 PY
 echo "dispersed done"

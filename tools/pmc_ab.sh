@@ -23,7 +23,7 @@ for duo in (0, 1):
     c = collections.defaultdict(list); d = []
     for f in glob.glob("$OUT/duo%d_*/*/*_counter_collection.csv" % duo):
         for r in csv.DictReader(open(f)):
-            if "k_step_duo" in r["Kernel_Name"] or "k_step_air<0, false, false>" in r["Kernel_Name"]:
+            if "k_step_duo" in r["Kernel_Name"] or "k_step_air<0, false, false, false>" in r["Kernel_Name"]:
                 c[r["Counter_Name"]].append(float(r["Counter_Value"])); d.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     print("duo=%d  mean kernel ns under pmc %.0f" % (duo, sum(d) / max(len(d), 1)))
     for k in sorted(c): print("   %-24s %.4g" % (k, sum(c[k]) / len(c[k])))

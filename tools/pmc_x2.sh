@@ -16,6 +16,6 @@ import csv, glob, collections
 c = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_step_air<0, true, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if "k_step_air<0, true, false, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(c): print("%-24s %.4g  (x %d launches)" % (k, sum(c[k]) / len(c[k]), len(c[k])))
 PY

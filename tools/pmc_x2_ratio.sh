@@ -22,7 +22,7 @@ for ratio in (1, 50):
     c = collections.defaultdict(list)
     for f in glob.glob("$OUT/r%d_p*/*/*_counter_collection.csv" % ratio):
         for r in csv.DictReader(open(f)):
-            if "k_step_air<0, true, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "k_step_air<0, true, false, false>" in r["Kernel_Name"]: c[r["Counter_Name"]].append(float(r["Counter_Value"]))
     res[ratio] = {k: sum(v) / len(v) for k, v in c.items()}
 waves = res[1].get("SQ_WAVES", 8192.0)
 print("%-22s %14s %14s %18s" % ("counter", "ratio 1", "ratio 50", "per update per wave"))

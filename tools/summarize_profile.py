@@ -7,7 +7,7 @@ summ = os.path.join(out, "summary"); os.makedirs(summ, exist_ok=True)
 for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(summ, f"{tag}_kernel_stats.csv"))
 # the airborne pass of the stepping kernel (the ground-capable pass that follows it finds no lane to redo in this workload)
-NAMES = {"k_step": ("k_step_duo<0, false>", "k_step_air<0, false, false>"), "k_f_ode": ("k_f_ode<false, 0>",)}   # (whichever airborne stepper ran)
+NAMES = {"k_step": ("k_step_duo<0, false, false>", "k_step_air<0, false, false, false>"), "k_f_ode": ("k_f_ode<false, 0>",)}   # (whichever airborne stepper ran)
 ctr = {"k_step": collections.defaultdict(list), "k_f_ode": collections.defaultdict(list)}
 dur = {"k_step": [], "k_f_ode": []}
 for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
