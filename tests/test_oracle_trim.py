@@ -102,3 +102,32 @@ def test_kinked_maps_do_not_trap_the_descent(oracle):
         cost = oracle.lib.fo_c172_trim_cost(np.ascontiguousarray(tp[:, k]).ctypes.data_as(D), np.ascontiguousarray(r["ts"][:, k]).ctypes.data_as(D), env.ctypes.data_as(D))
         assert cost <= 1e-16
     assert np.abs(r["ts"][2, 1:3] - 1.074).max() < 1e-3      # the two engine-knot cases
+
+
+def test_per_aircraft_environment_equals_one_call_per_aircraft(oracle):
+    """the oracle's per-aircraft environment mode (fo_set_env_per_aircraft: env [7, n], one Env per aircraft — every simulation of the
+    reference owns its world, FP/atmosphere.jl:75-84,156-165) against n single-aircraft calls with that aircraft's block: trim, f_ode!
+    and 200 steps, bit for bit."""
+    n = 16
+    rng = np.random.default_rng(4)
+    tp = default_tp(n)
+    tp[5] = rng.uniform(38, 52, n); tp[3] = rng.uniform(300, 2500, n); tp[4] = rng.uniform(-3, 3, n)
+    env6 = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(-1, 1, n), rng.uniform(260, 310, n), rng.uniform(97e3, 104e3, n),
+                     rng.uniform(0, 100, n)])
+    envs = oracle.env_rows(env6)
+    ts0 = np.tile(TS0[:, None], (1, n))
+    with oracle.per_aircraft_env():
+        r = oracle.trim(tp, ts0, envs)
+        xd, y, st = oracle.f_ode(r["x"], r["u"], r["ui"], r["s"], envs)
+        xf, sf, stf = oracle.step(r["x"], r["u"], r["ui"], r["s"], envs, 0.01, 200)
+    assert r["ok"].all() and (stf == 0).all()
+    for k in range(n):
+        e1 = np.ascontiguousarray(envs[:, k])
+        r1 = oracle.trim(np.ascontiguousarray(tp[:, k:k + 1]), ts0[:, k:k + 1], e1)
+        assert np.array_equal(r1["x"][:, 0], r["x"][:, k]) and np.array_equal(r1["ts"][:, 0], r["ts"][:, k])
+        xd1, y1, _ = oracle.f_ode(r1["x"], r1["u"], r1["ui"], r1["s"], e1)
+        assert np.array_equal(xd1[:, 0], xd[:, k]) and np.array_equal(y1[:, 0], y[:, k])
+        xf1, _, _ = oracle.step(r1["x"], r1["u"], r1["ui"], r1["s"], e1, 0.01, 200)
+        assert np.array_equal(xf1[:, 0], xf[:, k])
+    # the environments differ, and so do the trims (density and wind enter the trim)
+    assert np.ptp(r["ts"][3]) > 0.02
