@@ -179,3 +179,52 @@ def test_per_aircraft_terrain_elevation_ground_contact(fb, oracle):
     gnd = ok & (sto == 0) & touched
     assert np.abs(w.x[20] - xo[20])[gnd].max() < 1e-3 and np.abs(w.x[12:16] - xo[12:16])[:, gnd].max() < 1e-3
     w.close()
+
+
+def test_per_aircraft_env_every_stepping_path_agrees(fb, monkeypatch):
+    """The rows are read by four stepping kernels in the WA mechanisation: k_step_duo<WA, X, PERENV> (default), k_step_air<WA, X, false, PERENV>
+    (FLIGHTBATCH_DUO=0, and FB_F32 handles — the fp32 stepper has no per-aircraft form, such a handle is stepped in fp64) and the ground-capable
+    pass behind each. Same batch, same rows: the paths agree to rounding (they order a few sums differently, like their batch-wide forms)."""
+    K = fb.K
+    n = 2048
+    tp = lattice_trim_params(fb, n, seed=81)
+    env6 = random_env(fb, n, 21)
+    runs = {}
+    w0 = fb.BatchedWorld(n); w0.env = env6
+    fb.f_init(w0, tp)
+    x0, s0, u0, ui0 = w0.x, w0.s, w0.u, w0.ui
+    w0.close()
+    for name, duo, dtype in (("duo", "1", "f64"), ("air", "0", "f64"), ("f32 handle", "1", "f32")):
+        monkeypatch.setenv("FLIGHTBATCH_DUO", duo)       # (read when a handle is created)
+        w = fb.BatchedWorld(n, dtype=dtype)
+        w.env = env6
+        w.set_state(x0, s0); w.u = u0; w.ui = ui0
+        sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+        fb.step(sim, 5.0); w.sync()
+        assert (w.status == 0).all()
+        runs[name] = w.x
+        w.close()
+    monkeypatch.delenv("FLIGHTBATCH_DUO")
+    sc = state_scale(runs["duo"])
+    assert (np.abs(runs["air"] - runs["duo"]) / sc).max() < 1e-10
+    assert np.array_equal(runs["f32 handle"], runs["air"])      # the very same kernel
+    # Cessna172Xv2: wave-pair against one-wave kernel, closed loop
+    gains = fb.ctl_gains.ctl_gains_blob()
+    xs = {}
+    for duo in ("1", "0"):
+        monkeypatch.setenv("FLIGHTBATCH_DUO", duo)
+        w = fb.Cessna172Xv2World(n, gains=gains)
+        w.env = env6
+        sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=50)
+        fb.init(sim, tp)
+        w.ctl.lon.mode_req = float(fb.ModeControlLon.EAS_clm); w.ctl.lon.clm_ref = 1.0
+        w.ctl.lat.mode_req = float(fb.ModeControlLat.φ_β); w.ctl.lat.φ_ref = 0.2
+        fb.step(sim, 5.0); w.sync()
+        ok = w.trim_success & (w.status == 0)
+        xs[duo] = (w.x, ok)
+        w.close()
+    monkeypatch.delenv("FLIGHTBATCH_DUO")
+    assert np.array_equal(xs["1"][1], xs["0"][1]) and xs["1"][1].mean() > 0.99
+    d = np.abs(xs["1"][0] - xs["0"][0])[:, xs["1"][1]] / np.maximum(np.abs(xs["0"][0][:, xs["1"][1]]), 1.0)
+    print("Xv2 with per-aircraft rows, wave-pair vs one-wave kernel after 500 closed-loop steps: %.2e" % d.max())
+    assert d.max() < 1e-8
