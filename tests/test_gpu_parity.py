@@ -88,6 +88,23 @@ def test_trim_bench_lattice_all_succeed(fb, oracle):
     w.close()
 
 
+def test_trim_theta_constraint_gives_the_requested_flight_path_angle(fb):
+    """FPt/test_aircraft_base.jl:15-41 on the device: at every trimmed state of a batch with random flight-path angles, sideslip and turn rates
+    (bank angles up to ~0.4 rad) the ground flight-path angle of f_ode!'s output record equals the requested γ_wb_n (still air)."""
+    n = 4096
+    rng = np.random.default_rng(12)
+    tp = fb.TrimParameters(h_e=rng.uniform(500, 2500, n), EAS=rng.uniform(40, 52, n), ψ_nb=rng.uniform(-3, 3, n), γ_wb_n=rng.uniform(-0.07, 0.05, n),
+                           ψ_wb_dot=rng.uniform(-0.08, 0.08, n), β_a=rng.uniform(-0.05, 0.05, n))
+    for kin in ("WA", "NED"):
+        w = fb.BatchedWorld(n, kinematics=kin)
+        fb.f_init(w, tp)
+        ok = w.trim_success
+        assert ok.mean() > 0.9 and np.abs(w.trim_state[1][ok]).max() > 0.3
+        fb.f_ode(w)
+        assert np.abs(w.y[fb.K["FB_Y_KIN"] + 39] - np.asarray(tp.γ_wb_n))[ok].max() < 1e-12
+        w.close()
+
+
 def test_trim_batch_sizes_around_the_wave_size(fb):
     """k_trim runs one wave per 64 aircraft up to one per SIMD and hands aircraft out from a queue: batches of 1, 2, 63, 64, 65, 127 and 1000
     copies of TrimParameters() all trim, every copy to the same bits."""

@@ -328,3 +328,25 @@ def test_c172s_trim_succeeds_and_holds(oracle):
         xd_k, y_k, _ = oracle.f_ode(traj[k], r["u"], r["ui"], r["s"], env)
         assert np.all(np.abs(y_k[25:28, 0] - w0) < 1e-5)
         assert np.all(np.abs(traj[k][24:27, 0] - r["x"][24:27, 0]) < 1e-2)
+
+
+def test_theta_constraint_gives_the_requested_flight_path_angle(oracle):
+    """FPt/test_aircraft_base.jl:15-41: θ_constraint(v_wb_b, γ_wb_n, φ_nb) must return the pitch angle for which the wind-relative velocity has
+    the requested inclination γ_wb_n at the bank angle φ_nb. The reference checks it on one hand-set (α, β, γ, φ); here on every trimmed state
+    of a batch with random flight-path angles, sideslip and turn rates (so that the trim's bank angle is far from zero): in still air
+    v_eb_n = v_wb_n, and KinData's γ_gnd = inclination(v_eb_n) (FP/kinematics.jl:77-91) must equal the TrimParameters' γ_wb_n."""
+    n = 512
+    rng = np.random.default_rng(12)
+    tp = np.zeros((18, n)); tp[0] = 1; tp[3] = rng.uniform(500, 2500, n); tp[5] = rng.uniform(40, 52, n); tp[10] = 0.5; tp[11] = 0.5
+    tp[13:18] = np.array([75, 75, 0, 0, 50.0])[:, None]
+    tp[4] = rng.uniform(-3, 3, n)                  # ψ_nb
+    tp[6] = rng.uniform(-0.07, 0.05, n)            # γ_wb_n
+    tp[7] = rng.uniform(-0.08, 0.08, n)            # ψ_wb_dot: banked trims
+    tp[9] = rng.uniform(-0.05, 0.05, n)            # β_a
+    ts0 = np.tile(np.array([0.1, 0.0, 0.75, 0.47, 0.014, -0.0015, 0.02])[:, None], (1, n))
+    env = oracle.default_env()
+    r = oracle.trim(tp, ts0, env)
+    ok = r["ok"]
+    assert ok.mean() > 0.9 and np.abs(r["ts"][1][ok]).max() > 0.3          # bank angles up to ~0.4 rad
+    xd, y, st = oracle.f_ode(r["x"], r["u"], r["ui"], r["s"], env)
+    assert np.abs(y[39] - tp[6])[ok].max() < 1e-12                          # FB_Y_KIN + 39 = γ_gnd
