@@ -180,6 +180,38 @@ def _gather_state(fb, x_dev, n_total):
     return fb.sharding.all_gather_state(x_dev.cpu() if REHEARSAL else x_dev, n_total)
 
 
+def per_launch_ms(fb, C, w):
+    """the per-launch durations recorded by fb_timing_begin_per_launch (call after fb_timing_end)"""
+    nl = C.c_int64()
+    fb._lib.check(fb.lib.fb_timing_launches(w._h, None, 0, C.byref(nl)))
+    buf = (C.c_float * max(nl.value, 1))()
+    fb._lib.check(fb.lib.fb_timing_launches(w._h, buf, nl.value, C.byref(nl)))
+    return [float(buf[k]) for k in range(nl.value)]
+
+
+def launch_stats(ms):
+    """median / min / max / count of a list of per-launch durations (the figure quoted as kernel_ms is the MEDIAN)"""
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"kernel_ms": float(np.median(a)), "kernel_ms_min": float(a[0]), "kernel_ms_max": float(a[-1]), "launches_timed": int(a.size),
+            "kernel_ms_per_launch": [round(float(v), 4) for v in ms]}
+
+
+def warm_until_stable(fb, C, w, launch, tol=0.01, cap=30, at_least=3):
+    """Warm-up for the extra legs: launch until the last three launches agree within `tol` (max / min - 1), at most `cap` launches.
+    Each launch is timed by its own HIP-event pair. Returns the warm-up launches' durations (kept in the bench line: they show the
+    clock ramp after an idle period, profiles/r06_x2_repro.txt)."""
+    seen = []
+    while len(seen) < cap:
+        fb._lib.check(fb.lib.fb_timing_begin_per_launch(w._h, 1))
+        launch()
+        ms = C.c_float(); nl = C.c_int64()
+        fb._lib.check(fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl)))
+        seen += per_launch_ms(fb, C, w)[:1]
+        if len(seen) >= at_least and max(seen[-3:]) / min(seen[-3:]) - 1.0 < tol:
+            break
+    return seen
+
+
 def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     """trim + warm-up + the timed region for one shard of the Cessna172Sv0 batch. Returns a dict of measurements (and the
     initial condition on the host, for the CPU legs)."""
@@ -207,7 +239,7 @@ def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     for _ in range(args.warmup):
         fb.step(sim, args.inner * DT)
     barrier()
-    fb.lib.fb_timing_begin(w._h)
+    fb._lib.check(fb.lib.fb_timing_begin_per_launch(w._h, args.steps))   # (one event pair per launch as well: the spread rides along)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fb.step(sim, args.inner * DT)
@@ -215,7 +247,9 @@ def time_c172s0(fb, torch, dist, C, EAS, h, psi, args, local_rank, world):
     elapsed = time.perf_counter() - t0
     ms = C.c_float(); nl = C.c_int64()
     fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
-    out = {"n": n, "elapsed": elapsed, "kernel_ms": ms.value / max(nl.value, 1), "trim_ok": trim_ok, "trim_s": trim_s, "ic": ic}
+    # roofline.achieved divides by the AVERAGE launch duration over the timed region (the contract's definition); median / min / max ride along
+    out = {"n": n, "elapsed": elapsed, "kernel_ms": ms.value / max(nl.value, 1), "launch_stats": launch_stats(per_launch_ms(fb, C, w)),
+           "trim_ok": trim_ok, "trim_s": trim_s, "ic": ic}
     # full-size invariants over ALL aircraft of the shard
     st = w.status
     xf = w.x
@@ -265,6 +299,8 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
     different gain-schedule cells, aerodynamic table cells and control-law branches — configs[3]'s identical-aircraft scenario is the
     best case of every wave-uniform load and branch in the update, this is the other end."""
     n = N_TOTAL // 2
+    if float(getattr(args, "x2_pre_sleep", 0.0)) > 0:   # (tools/bench_x2.py --pre-sleep: an idle GPU in front of the leg, as round 5's driver run had behind the CPU legs)
+        time.sleep(float(args.x2_pre_sleep))
     w = fb.Cessna172Xv2World(n, device=local_rank)
     x_dev = None
     if world > 1:   # the state in a torch tensor, so that RCCL gathers it in place
@@ -302,18 +338,20 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
         if world > 1:
             torch.cuda.synchronize()
 
-    block = 0.5
-    fb.step(sim, 2 * block)
+    block = args.x2_inner * DT
+    warm = warm_until_stable(fb, C, w, lambda: fb.step(sim, block), cap=int(getattr(args, "x2_warm_cap", 30)))
     barrier()
-    fb.lib.fb_timing_begin(w._h)
+    blocks = int(getattr(args, "x2_blocks", 12))
+    fb._lib.check(fb.lib.fb_timing_begin_per_launch(w._h, blocks))
     t0 = time.perf_counter()
-    blocks = 6
     for _ in range(blocks):
         fb.step(sim, block)
     barrier()
     el = time.perf_counter() - t0
     ms = C.c_float(); nl = C.c_int64()
     fb.lib.fb_timing_end(w._h, C.byref(ms), C.byref(nl))
+    stats = launch_stats(per_launch_ms(fb, C, w))
+    stats["warmup_ms_per_launch"] = [round(v, 4) for v in warm]
     steps = int(round(block / DT)) * blocks
     bad = int((w.status != 0).sum())
     n_total, gather_ms = n, None
@@ -330,13 +368,14 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
         del gathered
     w.close()
     value = n_total * steps / el
-    gbs = BYTES_PER_X2_STEP * value / 1e9
+    # roofline.achieved: algorithmic bytes of one launch / the kernel's AVERAGE launch duration over the timed region (HIP events), x ranks
+    gbs = BYTES_PER_X2_STEP * n * args.x2_inner / (ms.value / max(nl.value, 1) * 1e-3) / 1e9 * world
     if divergent:
         return {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64",
                 "config": {"workload": f"N={n} Cessna172Xv2 on lattice(3)'s randomised trims (EAS 35-55 m/s x h 200-3000 m x heading), wind as configs[3], every aircraft in its own "
                                        "(lon, lat) control-mode pair drawn from all 9 x 5 with its own references: the divergent counterpart of extra.x2",
                            "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
-                "kernel_ms": ms.value / max(nl.value, 1),
+                **stats, "kernel_ms_mean": ms.value / max(nl.value, 1),
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}}
     out = {"metric": "aircraft-steps/sec", "value": value, "unit": "aircraft-steps/s", "dtype": "f64", "n_gpus": world,
            "config": {"workload": (f"N={n_total} Cessna172Xv2 over {world} GPUs, {n} per GPU (BASELINE.json configs[3]" + (")" if world == 8 else f" at {world} of its 8 GPUs)")
@@ -344,7 +383,7 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
                                   ", default trim, README example 2 scenario "
                                   "(wind, EAS + climb-rate and bank + sideslip modes), autopilot every 2 steps (Δt = 0.02), fp64, dt = 0.01",
                       "rk4_steps_per_launch": args.x2_inner, "terminated_aircraft": bad},
-           "stepping_launches": int(nl.value), "kernel_ms": ms.value / max(nl.value, 1), "stream_ms_per_rk4_step": ms.value / steps,
+           "stepping_launches": int(nl.value), **stats, "kernel_ms_mean": ms.value / max(nl.value, 1), "stream_ms_per_rk4_step": ms.value / steps,
            "kernel": ("fbd::k_step_duo<0, true, false> (two waves per SIMD; the control update in two halves inside the launch)" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0"
                       else "fbd::k_step_air<0, true, false, false>") + " + the ground-capable pass behind it",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": gbs / (HBM_PEAK_GBS * world),
@@ -374,10 +413,10 @@ def time_x2(fb, torch, dist, C, args, local_rank=0, world=1, divergent=False):
     return out
 
 
-def extra_x2(fb, C, args, timed=None):
-    """`extra.x2` of the bench line: the timing of time_x2 (measured here on one GPU, or handed in from the multi-rank run) and a
+def extra_x2(fb, C, args, timed):
+    """`extra.x2` of the bench line: the timing of time_x2 (taken BEFORE the CPU legs, on one GPU or by the multi-rank run) and a
     parity sample against the oracle."""
-    out = timed if timed is not None else time_x2(fb, None, None, C, args)
+    out = timed
     # parity sample: 512 aircraft on randomised trims, every aircraft in its own pair of modes, 500 closed-loop steps vs the oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import OracleX
@@ -445,10 +484,11 @@ def extra_fleet(fb, C, args):
     fleet.step(1.0); fleet.sync()
     T = 3.0
     cw = fleet.worlds[KC]
-    fb.lib.fb_timing_begin(cw._h)
+    fb._lib.check(fb.lib.fb_timing_begin_per_launch(cw._h, 6))
     t0 = time.perf_counter(); fleet.step(T); fleet.sync(); el = time.perf_counter() - t0
     ms = C.c_float(); nl = C.c_int64()
     fb.lib.fb_timing_end(cw._h, C.byref(ms), C.byref(nl))
+    stats = launch_stats(per_launch_ms(fb, C, cw))
     steps = int(round(T / DT))
     st = fleet.gather("status", fill=-1)
     value = n * steps / el
@@ -458,12 +498,18 @@ def extra_fleet(fb, C, args):
     out = {"metric": "vehicle-steps/sec", "value": value, "unit": "vehicle-steps/s", "dtype": "f32",
            "config": {"workload": f"mixed fleet N={n}: 50% Cessna172Sv0 (fp32 airborne stepper, randomised trims) / 50% Robot2D (fp32), interleaved input order, "
                                   "packed by model onto two HIP streams, dt=0.01, Δt=0.02 (BASELINE.json configs[4] on one GPU)", "terminated": int((st != 0).sum())},
-           "kernel_ms": ms.value / max(nl.value, 1), "kernel": "fbf::k_step_f32 (50 steps of 524 288 aircraft per launch)",
+           **stats, "kernel_ms_mean": ms.value / max(nl.value, 1), "kernel": "fbf::k_step_f32 (50 steps of 524 288 aircraft per launch; its stream also carries Robot2D's waits)",
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "note": f"algorithmic bytes: {bytes_c} B per fp32 aircraft-step, {bytes_r:.0f} B per fp32 robot-step"}}
     fleet.close()
-    # parity sample of the fp32 aircraft kernel against the fp64 oracle (physical units: fp32 cannot meet 1e-6)
+    return out
+
+
+def fleet_parity(fb, out):
+    """parity sample of the fp32 aircraft kernel against the fp64 oracle (physical units: fp32 cannot meet 1e-6); after the timed legs"""
     orc = _oracle()
+    nc = N_TOTAL // 2
+    EAS, h, psi, _ = lattice(1)
     m = 1024
     sel = np.arange(0, nc, nc // m)[:m]
     w = fb.BatchedWorld(m, dtype="f32")
@@ -600,7 +646,8 @@ def main():
                        "trim_success_fraction": head["trim_ok"] / head["n_total"], "trim_seconds": head["trim_s"], "terminated_aircraft": head["status_bad"],
                        "checked_on_all_aircraft": "status == 0, fuel strictly decreasing, | |q| - 1 | <= " + ("1e-8" if args.dtype == "f64" else "5e-7") + " (q_wb, q_ew), all states finite"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": (("fbd::k_step_duo<0, false, false>" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "fbd::k_step_air<0, false, false, false>") if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel_ms_median": head["launch_stats"]["kernel_ms"], "kernel_ms_min": head["launch_stats"]["kernel_ms_min"],
+                         "kernel_ms_max": head["launch_stats"]["kernel_ms_max"], "kernel": (("fbd::k_step_duo<0, false, false>" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "fbd::k_step_air<0, false, false, false>") if args.dtype == "f64" else "fbf::k_step_f32") + " (+ the ground-capable pass behind it)", "kernel_ms": kernel_ms,
                          "note": f"algorithmic bytes = {bytes_per_unit:.0f} B per aircraft-step (SURVEY §8d" + ("" if args.dtype == "f64" else ", fp32 rows; q_ew / h_e stay fp64") + ") x N x inner steps per launch; the fused "
                                  "stepper is " + ("fp64" if args.dtype == "f64" else "fp32") + "-VALU-bound, see roofline_valu and DESIGN.md"},
             "roofline_valu": valu,
@@ -616,12 +663,18 @@ def main():
                 "value": float(other["n_total"]) * args.inner * args.steps / other["elapsed"], "unit": "aircraft-steps/s",
                 "aircraft_total": other["n_total"], "aircraft_per_gpu": other["n"], "ms_per_step": other["elapsed"] / args.steps * 1e3,
                 "kernel_ms": other["kernel_ms"], "gather_ms": other["gather_ms"]}
-    x2_timed = None
+    # every GPU-timed leg runs BEFORE the CPU legs (the ~20 s of oracle work leave the GPU idle: round 5's driver run timed configs[3]
+    # behind them with two warm-up launches and got 15.1 ms where 9.85 is the kernel's time — profiles/r06_x2_repro.txt)
+    x2_timed = x2_lat = fleet_timed = None
+    extras = not args.no_extra and args.dtype == "f64"
+    if extras:
+        x2_timed = time_x2(fb, torch, dist, C, args, local_rank, world)   # configs[3]: one GPU's share, or this node's split with every rank taking part
     if world > 1:
-        if not args.no_extra and args.dtype == "f64":
-            x2_timed = time_x2(fb, torch, dist, C, args, local_rank, world)   # configs[3] at this node's split: every rank takes part
         dist.barrier()
         dist.destroy_process_group()
+    elif extras:
+        x2_lat = time_x2(fb, None, None, C, args, divergent=True)
+        fleet_timed = extra_fleet(fb, C, args)
     if rank == 0:
         # the CPU baseline and the parity sample ride on every line, multi-GPU ones included: rank 0, on its own shard, after the
         # process group is gone (nothing of this is inside a timed region)
@@ -634,11 +687,11 @@ def main():
                 line["rel_err_vs_cpu"]["sample"] += " (rank 0's shard)"
         if not args.no_extra and args.dtype == "f64":
             head.pop("ic", None)
-            line["extra"] = {"x2": extra_x2(fb, C, args, timed=x2_timed)}
+            line["extra"] = {"x2": extra_x2(fb, C, args, x2_timed)}
             if world == 1:
-                line["extra"]["x2_lattice"] = time_x2(fb, None, None, C, args, divergent=True)
-                line["extra"]["x2_lattice"]["vs_identical_aircraft"] = line["extra"]["x2_lattice"]["kernel_ms"] / line["extra"]["x2"]["kernel_ms"]
-                line["extra"]["fleet"] = extra_fleet(fb, C, args)
+                line["extra"]["x2_lattice"] = x2_lat
+                x2_lat["vs_identical_aircraft"] = x2_lat["kernel_ms"] / x2_timed["kernel_ms"]
+                line["extra"]["fleet"] = fleet_parity(fb, fleet_timed)
         print(json.dumps(line), flush=True)
 
 

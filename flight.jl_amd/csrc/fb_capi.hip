@@ -62,6 +62,8 @@ struct fb_handle_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
     int64_t launches = 0;
+    std::vector<hipEvent_t> lev;   // fb_timing_begin_per_launch: one event pair per stepping launch (both passes), created on demand and kept
+    int64_t lev_max = 0, lev_used = 0;   // pairs wanted in this timing window / pairs recorded
     struct R2State* r2 = nullptr;  // Robot2D handles only
     // Cessna172Xv2 handles only
     double* cs = nullptr;      // [FB_NCS x n] control-law record
@@ -243,6 +245,16 @@ static int32_t copy_rows(fb_handle h, double* dev, const double* host_in, double
 #include "fb_log.inc"
 struct ncclUniqueIdBlob { char internal[128]; };   // ncclUniqueId (rccl.h:40-43), passed by value
 
+// The scratch rows of the stepping kernels (ctl_bak, duo_pld, duo_tap) are zeroed when a handle is created: hipMalloc hands out zero pages in
+// a fresh process and whatever the previous owner left in a block that is reused, and nothing a launch does — its time included — may depend
+// on which (docs/design/roofline.md, "Round 6": what the driver's round-5 bench run measured). FLIGHTBATCH_SCRATCH_FILL is the diagnostic
+// behind that paragraph: a byte value fills the rows with that byte instead (255: NaNs, 127: 1.4e306), "none" leaves them as allocated.
+static int scratch_fill() {
+    const char* e = getenv("FLIGHTBATCH_SCRATCH_FILL");
+    if (!e || !*e) return 0;
+    if (!strcmp(e, "none")) return -1;
+    return atoi(e) & 255;
+}
 // device-side resources of a new handle; on failure fb_create destroys the partially built handle (nothing leaks)
 static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, int64_t n) {
     HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -253,6 +265,7 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
         return r2_create(h, dtype);
     }
     const int nx = is_x2(h) ? (int)FB_X2_NX : (int)FB_NX;   // device rows
+    const int sf = scratch_fill();
     HIPCHK(hipMalloc(&h->x_own, sizeof(double) * nx * n));
     HIPCHK(hipMalloc(&h->s_own, sizeof(int32_t) * FB_NS * n));
     if (is_x2(h)) {
@@ -260,6 +273,7 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
         HIPCHK(hipMalloc(&h->cu, sizeof(double) * FB_NCU * n));
         HIPCHK(hipMalloc(&h->q_pre, sizeof(double) * 8 * n));
         HIPCHK(hipMalloc(&h->ctl_bak, sizeof(double) * (FB_NCS + FB_NCU) * n));
+        if (sf >= 0) HIPCHK(hipMemsetAsync(h->ctl_bak, sf, sizeof(double) * (FB_NCS + FB_NCU) * n, h->stream));   // (scratch rows start defined: see scratch_fill())
         HIPCHK(hipMemsetAsync(h->cs, 0, sizeof(double) * FB_NCS * n, h->stream));
         HIPCHK(hipMemsetAsync(h->cu, 0, sizeof(double) * FB_NCU * n, h->stream));
         HIPCHK(hipMemsetAsync(h->q_pre, 0, sizeof(double) * 8 * n, h->stream));
@@ -275,8 +289,14 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
     HIPCHK(hipMemsetAsync(h->term_step, 0, sizeof(long long) * n, h->stream));
     HIPCHK(hipMemsetAsync(h->term_where, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->redo, sizeof(int32_t) * n));
-    if (h->duo) HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * n));   // (here, not in the first fb_step: hipMalloc synchronises the device)
-    if (h->duo && model_id == FB_MODEL_C172X2) HIPCHK(hipMalloc(&h->duo_tap, sizeof(double) * DUO_NTAP * n));
+    if (h->duo) {   // (here, not in the first fb_step: hipMalloc synchronises the device)
+        HIPCHK(hipMalloc(&h->duo_pld, sizeof(double) * DUO_NCONST * n));
+        if (sf >= 0) HIPCHK(hipMemsetAsync(h->duo_pld, sf, sizeof(double) * DUO_NCONST * n, h->stream));
+    }
+    if (h->duo && model_id == FB_MODEL_C172X2) {
+        HIPCHK(hipMalloc(&h->duo_tap, sizeof(double) * DUO_NTAP * n));
+        if (sf >= 0) HIPCHK(hipMemsetAsync(h->duo_tap, sf, sizeof(double) * DUO_NTAP * n, h->stream));
+    }
     HIPCHK(hipMemsetAsync(h->redo, 0, sizeof(int32_t) * n, h->stream));
     HIPCHK(hipMalloc(&h->tables, sizeof(double) * TABLE_BUF_DOUBLES));
     HIPCHK(hipMalloc(&h->egm96, sizeof(float) * 721 * 1441));
@@ -339,6 +359,7 @@ int32_t fb_destroy(fb_handle h) {
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok); hipFree(h->trim_ws); hipFree(h->env_rows);
     hipFree(h->cs); hipFree(h->cu); hipFree(h->q_pre); hipFree(h->ctl_bak); hipFree(h->duo_pld); hipFree(h->duo_tap); hipFree(h->gains); hipFree(h->redo); hipFree(h->k1); hipFree(h->k1_valid);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->lev) hipEventDestroy(e);
     hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -751,7 +772,10 @@ static int32_t step_raw(fb_handle h, int64_t nsteps) {
         const int k = (int)(left < h->steps_per_launch ? left : h->steps_per_launch);
         a.ctl_phase = a.ctl_ratio > 0 ? (int)(h->steps_done % a.ctl_ratio) : 0;
         a.step0 = h->steps_done;
+        const bool stamp = h->timing && h->lev_used < h->lev_max;
+        if (stamp) HIPCHK(hipEventRecord(h->lev[2 * h->lev_used], h->stream));
         FB_LAUNCH_STEP(grid_for(h->n, 256), a, k);
+        if (stamp) { HIPCHK(hipEventRecord(h->lev[2 * h->lev_used + 1], h->stream)); h->lev_used++; }
         left -= k;
         h->steps_done += k;
         h->launches++;
@@ -950,8 +974,34 @@ int32_t fb_timing_begin(fb_handle h) {
     if (!h) return fail("null handle");
     HIPCHK(hipSetDevice(h->device));
     h->launches = 0;
+    h->lev_max = h->lev_used = 0;
     h->timing = true;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+int32_t fb_timing_begin_per_launch(fb_handle h, int64_t max_launches) {
+    if (!h) return fail("null handle");
+    if (h->model == FB_MODEL_ROBOT2D) return fail("fb_timing_begin_per_launch: not supported for Robot2D");
+    if (max_launches < 0 || max_launches > 65536) return fail("fb_timing_begin_per_launch: max_launches must be in [0, 65536]");
+    HIPCHK(hipSetDevice(h->device));
+    while ((int64_t)h->lev.size() < 2 * max_launches) {
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreate(&e));
+        h->lev.push_back(e);
+    }
+    if (int32_t rc = fb_timing_begin(h)) return rc;
+    h->lev_max = max_launches;
+    return 0;
+}
+int32_t fb_timing_launches(fb_handle h, float* ms, int64_t cap, int64_t* n) {
+    if (!h || !n) return fail("null argument");
+    if (h->timing) return fail("fb_timing_launches: call fb_timing_end first");
+    HIPCHK(hipSetDevice(h->device));
+    *n = h->lev_used;
+    for (int64_t k = 0; ms && k < h->lev_used && k < cap; k++) {
+        HIPCHK(hipEventSynchronize(h->lev[2 * k + 1]));
+        HIPCHK(hipEventElapsedTime(&ms[k], h->lev[2 * k], h->lev[2 * k + 1]));
+    }
     return 0;
 }
 int32_t fb_timing_end(fb_handle h, float* ms, int64_t* n_launches) {

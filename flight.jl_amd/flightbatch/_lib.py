@@ -77,6 +77,8 @@ def _load():
         "fb_comm_destroy": ([VP], C.c_int32),
         "fb_timing_begin": ([H], C.c_int32),
         "fb_timing_end": ([H, C.POINTER(C.c_float), C.POINTER(I64)], C.c_int32),
+        "fb_timing_begin_per_launch": ([H, I64], C.c_int32),
+        "fb_timing_launches": ([H, C.POINTER(C.c_float), I64, C.POINTER(I64)], C.c_int32),
         "fb_last_error": ([], C.c_char_p),
         "fb_version": ([], C.c_char_p),
     }

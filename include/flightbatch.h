@@ -378,6 +378,11 @@ int32_t fb_set_status(fb_handle h, const int32_t* status);
  * reports total elapsed ms and the number of stepping-kernel launches. */
 int32_t fb_timing_begin(fb_handle h);
 int32_t fb_timing_end(fb_handle h, float* ms, int64_t* n_launches);
+/* The same window with ONE event pair per stepping launch (both passes of a launch between its pair), up to max_launches of them;
+ * after fb_timing_end, fb_timing_launches returns their durations in launch order (ms[0 .. min(*n, cap))), *n = pairs recorded.
+ * A measurement aid (bench.py reports median / min / max over launches and warms up until launches agree); no reference counterpart. */
+int32_t fb_timing_begin_per_launch(fb_handle h, int64_t max_launches);
+int32_t fb_timing_launches(fb_handle h, float* ms, int64_t cap, int64_t* n);
 
 const char* fb_last_error(void);
 const char* fb_version(void);

@@ -17,7 +17,7 @@ def step(sim, *a, **k):
     return orig_step(sim, *a, **k)
 fb.step = step
 args = types.SimpleNamespace(x2_inner=50)
-bench.extra_x2(fb, C, args)
+bench.extra_x2(fb, C, args, bench.time_x2(fb, None, None, C, args))
 acc = (C.c_ulonglong * 32)(); cnt = (C.c_ulonglong * 32)()
 fb.lib.fb_debug_stamps(acc, cnt, 0)
 names = {21: "end of evaluation -> entry of x2_periodic (bookkeeping, arguments, call)", 22: "record burst (94 rows) issued", 23: "guidance", 27: "lon: inputs, mode logic",
