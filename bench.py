@@ -13,11 +13,11 @@ every aircraft by `--inner` RK4 steps (default 50, i.e. 0.5 s of flight), includ
 at the new state and f_step!. Trim, table generation and upload are outside the timed region; state is resident in HBM
 when timing starts.
 
-Multi-GPU (one process per GPU, aircraft are independent, NO data-path collective). The path partitions into independent
-aircraft, so for --gpus > 1 the default is `--scaling weak`: every rank steps its own 1 048 576 aircraft (configs[2] per GPU, rank r
-on lattice(r)) and `value` is the whole job's rate. BASELINE's whole-node figure — the SAME 1 048 576 aircraft cut into contiguous
-shards (flightbatch.sharding.shard_range), 131 072 per GPU at N = 8 — is measured in the same run and attached as
-"strong_scaling" (`--scaling strong` makes it the headline instead). One RCCL all-gather of the final states collects the
+Multi-GPU (one process per GPU, aircraft are independent, NO data-path collective). For --gpus > 1 the default is `--scaling strong`:
+BASELINE.json's metric is the whole node at N = 1 M, i.e. the SAME 1 048 576 aircraft cut into contiguous shards
+(flightbatch.sharding.shard_range), 131 072 per GPU at N = 8, and `value` is the whole job's rate on THAT configuration. The weak figure —
+every rank stepping its own 1 048 576 aircraft (configs[2] per GPU, rank r on lattice(r)) — is measured in the same run and attached as
+"weak_scaling" (`--scaling weak` makes it the headline instead). One RCCL all-gather of the final states collects the
 trajectory endpoint after the timed region (gather_ms, not part of `value`). At --gpus 1 the two coincide.
 
 On one GPU the line also carries, under "extra", one GPU's share of configs[3] (524 288 Cessna172Xv2 with the autopilot at
@@ -546,8 +546,8 @@ def main():
     ap.add_argument("--inner", type=int, default=50, help="RK4 steps fused per launch (= per contract step)")
     ap.add_argument("--x2-inner", type=int, default=50, help="RK4 steps per launch of the Cessna172Xv2 stepper (control laws run inside the launch)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
-                    help="N > 1: weak (default) = 1 048 576 aircraft per rank; strong = the same 1 048 576 aircraft sharded over the ranks "
-                         "(BASELINE's whole-node figure). The other mode is measured too and attached as an extra key")
+                    help="N > 1: strong (default) = the same 1 048 576 aircraft sharded over the ranks (BASELINE's whole-node figure); "
+                         "weak = 1 048 576 aircraft per rank. The other mode is measured too and attached as an extra key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] legs (1-GPU runs)")
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
@@ -578,7 +578,7 @@ def main():
     import ctypes as C
     import flightbatch as fb
 
-    scaling = args.scaling or "weak"
+    scaling = args.scaling or "strong"   # (N > 1 only; BASELINE.json: "whole node at N = 1M")
     results = {}
     for mode in ((scaling, "weak" if scaling == "strong" else "strong") if world > 1 else ("weak",)):
         if mode == "strong":

@@ -1017,9 +1017,21 @@ template <int HALF> __device__ __forceinline__ void half_stamp(int k) {
 #ifndef FB_X2_HALF_ATTR
 #define FB_X2_HALF_ATTR __forceinline__
 #endif
-template <int HALF>
+// FB_X2_SPLIT_PITCH = 1 (round 6; OFF: measured, no gain): the longitudinal half is the long one of an update — 27 k cycles
+// against the lateral half's 14 k, profiles/r05_x2_half_stamps.txt — so its pitch-axis outer loops (c2θ PID, θ -> q, q2e integrator + PID: 5 k of its
+// 8 k of outer loops) run on the LATERAL half's wave, ahead of the lateral laws, and their elevator reference reaches the te2te LQR — restructured so
+// that everything that does not need it comes first (lqr_run_g_late) — through an LDS slot and a fifth point Z of the pair's counters. Correct
+// (26 GPU tests, 2.5e-12 against the oracle) and NOT faster: 9.96-9.99 ms per launch against 9.84-9.86, at every combination of issue priorities
+// (profiles/r06_ab_x2_split_pitch.txt). The two halves share one SIMD's issue slots: an update costs what the pair's ~4 900 instructions cost,
+// whichever wave issues them — the lateral wave's "waiting" was never idle time that work could be moved into. Kept for the record.
+#ifndef FB_X2_SPLIT_PITCH
+#define FB_X2_SPLIT_PITCH 0
+#endif
+// hand: how the pitch-axis outer loops' elevator reference crosses from the lateral half's wave to the longitudinal half's (k_step_duo: an LDS
+// slot and the pair's counters): hand.put(v) in the lateral half — store, then publish —, hand.get() in the longitudinal one — wait, then load
+template <int HALF, class Hand>
 __device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_cs, const double* a_gains, const double* a_tap, int64_t a_n, double a_dT, uint32_t o01,
-                                              uint32_t o23, uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, double h_e, lds_cptr xs) {
+                                              uint32_t o23, uint32_t o45, uint32_t o67, uint32_t o89, uint32_t tsg, int64_t i, double h_e, lds_cptr xs, const Hand& hand) {
     constexpr int B = 256;   // (= DUO_B, defined below)
     using SV = StateLds<B, false>;
     FB_HALF_STAMP(HALF, -1);
@@ -1042,9 +1054,14 @@ __device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_c
             v.pos[1] = v.pos[3] = v.cmd[1] = v.cmd[3] = 0; v.chi = 0; v.beta = 0;
         } else {
             v.chi = TAP(DUO_TAP_CHI); v.beta = TAP(DUO_TAP_BETA);
+            v.theta = 0; v.clm = 0;
             v.w_wb_b = {TAP(DUO_TAP_WX), 0.0, 0.0};
+            if constexpr (FB_X2_SPLIT_PITCH != 0) {   // (+ pitch and yaw rate: what the pitch-axis outer loops read, ctl_lon_pitch_half)
+                v.theta = TAP(DUO_TAP_THETA); v.clm = -TAP(DUO_TAP_VD);
+                v.w_wb_b = {TAP(DUO_TAP_WX), TAP(DUO_TAP_WY), TAP(DUO_TAP_WZ)};
+            }
             v.pos[1] = TAP(DUO_TAP_POS + 1); v.pos[3] = TAP(DUO_TAP_POS + 3); v.cmd[1] = TAP(DUO_TAP_CMD + 1); v.cmd[3] = TAP(DUO_TAP_CMD + 3);
-            v.pos[0] = v.pos[2] = v.cmd[0] = v.cmd[2] = 0; v.theta = 0; v.clm = 0; v.alpha = 0;
+            v.pos[0] = v.pos[2] = v.cmd[0] = v.cmd[2] = 0; v.alpha = 0;
         }
 #pragma unroll
         for (int k = 0; k < FB_NCU; k++) lu[k] = u0[(int64_t)k * n];
@@ -1060,10 +1077,16 @@ __device__ FB_X2_HALF_ATTR Ctl2 x2_periodic_half(const double* a_cu, double* a_c
     FB_HALF_STAMP(HALF, HALF == CTL_HALF_LON ? 23 : 17);   // guidance
     const CtlTabT<gcptr> tab = ctl_tab((gcptr)(uintptr_t)A.gains, A.off, v.EAS, v.h_e);
     if constexpr (HALF == CTL_HALF_LON) {
-        ctl_lon<true>(tab, M, A.dT, v, (int)M.U(FB_CU_LON_MODE_REQ));
+        // (FB_X2_SPLIT_PITCH: the pitch-axis outer loops run on the partner wave; their elevator reference arrives inside the te2te LQR's run)
+        ctl_lon<true, FB_X2_SPLIT_PITCH != 0>(tab, M, A.dT, v, (int)M.U(FB_CU_LON_MODE_REQ), [&]() { return hand.get(); });
         FB_HALF_STAMP(HALF, 24);   // (behind ctl_lon's fence 29: the LQR run and the stores)
         return {clampd(M.S(FB_CS_THROTTLE_CMD), 0, 1), clampd(M.S(FB_CS_ELEVATOR_CMD), -1, 1)};
     } else {
+        if constexpr (FB_X2_SPLIT_PITCH != 0) {
+            // first the longitudinal channel's pitch-axis outer loops (c2θ, θ -> q, q2e), whose result the partner wave's te2te LQR waits for
+            hand.put(ctl_lon_pitch_half(tab, M, A.dT, v, (int)M.U(FB_CU_LON_MODE_REQ)));
+            FB_HALF_STAMP(HALF, 18);   // pitch-axis outer loops, reference handed over
+        }
         const int lat_req = (int)M.U(FB_CU_LAT_MODE_REQ);
         LatGains G;   // (not read: the gains are taken where they are used)
         G.P = {0, 0, 0, 0};
@@ -1365,6 +1388,7 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
 //     stepped here, the ground-capable pass evaluates its own.
 constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
+constexpr int DUO_PT_Z = DUO_NPT + 1;                   // role D (inside its half of an update): the pitch-axis outer loops' elevator reference put (x2_periodic_half)
 // Diagnostic builds (-DFB_STAMP -DFB_DUO_PHASES, tools/duo_phases.py): the shader clock when role D's first wave of workgroup 0 passes the
 // phases of a launch (g_stamp_acc[8 + k]: 0 entry, 1 tables staged, 2 state loaded and launch constants formed, 3 last evaluation done, 4 exit)
 #if defined(FB_STAMP) && defined(FB_DUO_PHASES)
@@ -1379,7 +1403,7 @@ constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluatio
 template <int KIN, bool X = false, bool PERENV = false>
 __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     constexpr int B = DUO_B, NR = FB_NX - 6, NP = DUO_NP, ND = DUO_ND;
-    constexpr int NPT = X ? DUO_NPT + 1 : DUO_NPT;   // points per iteration of the evaluation loop
+    constexpr int NPT = X ? DUO_NPT + 2 : DUO_NPT;   // points per iteration of the evaluation loop
     constexpr int NAL = FB_ACT_BRAKE_LEFT;           // actuators the airborne evaluation reads
     using SV = StateLds<B, false>;
     __shared__ double lds[AT_SIZE + PT_SIZE];   // aero | piston tables (the propeller table stays in global memory, see rhs_duo())
@@ -1415,6 +1439,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
 #endif
 #ifndef FB_X2_UPD_PRIO
 #define FB_X2_UPD_PRIO 0   // ... and role D's wave during ITS half (the shorter one): 9.86 -> 9.82 ms per launch
+#endif
+#ifndef FB_X2_PITCH_PRIO
+#define FB_X2_PITCH_PRIO 3 // ... and role D's wave from the start of its half to its point Z (the pitch-axis outer loops, which role P's LQR waits for)
 #endif
 #ifndef FB_X2_SPEC_PRIO
 #define FB_X2_SPEC_PRIO 3  // ... and while it forms the next stage's aerodynamic sums at the end of an iteration
@@ -1467,12 +1494,23 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         return k;
     };
     // one half of a control update (the arguments re-read from the kernel's argument block where the call stands: kernarg())
+    // The elevator reference of the pitch-axis outer loops, from the lateral half's wave (role D's) to the longitudinal half's (role P's): through
+    // the lane's slot of the exchange row that carries h_rot during an evaluation (role P writes it ahead of its point W, role D reads it behind W:
+    // idle between evaluations, like the rho / h_o rows that carry the lateral commands) and role D's point Z (an LDS-only release: what crosses is
+    // this one row). NOT the evaluation panel's velocity rows: the tapped evaluation is stage 0 of the next step, its emits have left the stage-1
+    // state there.
+    struct CtlHand {
+        lds_ptr slot; DuoSync* sy;
+        __device__ __forceinline__ void put(double v) const { *slot = v; duo_publish<false>(*sy, DUO_PT_Z); __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO); }
+        __device__ __forceinline__ double get() const { duo_wait(*sy, DUO_PT_Z); return *slot; }
+    };
     [[maybe_unused]] auto ctl_half = [&](auto half, int64_t lane) {
         const kargs_cptr ka = kernarg();
         auto pk = [&](int k) { return (uint32_t)ka->ctl_off.off[k] | ((uint32_t)ka->ctl_off.off[k + 1] << 16); };
+        const CtlHand hand = {(lds_ptr)xch_l + (XD_HROT - 6) * B + t, &sy};
         return x2_periodic_half<decltype(half)::value>(ka->cu, ka->cs, ka->gains, ka->duo_tap, ka->n, ka->ctl_dT, pk(0), pk(2), pk(4), pk(6), pk(8),
                                                        (uint32_t)ka->ctl_off.total | ((uint32_t)ka->ctl_off.same_grid << 16), lane,
-                                                       xs_l[SV::row(h_e_row<KIN>()) * B + t], (lds_cptr)xs_l + t);
+                                                       xs_l[SV::row(h_e_row<KIN>()) * B + t], (lds_cptr)xs_l + t, hand);
     };
     if (role == 1) {
         // ================= role P =================
@@ -1871,7 +1909,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 // does not touch). Role P's wave runs the longitudinal half meanwhile.
                 DUO_MARK(2, 12);   // f_step! done, flags written: at U
                 duo_publish<true>(sy, DUO_PT_U);
-                __builtin_amdgcn_s_setprio(FB_X2_UPD_PRIO);   // (its half is the shorter one: behind role P's, which runs at FB_X2_LON_PRIO)
+                __builtin_amdgcn_s_setprio(FB_X2_SPLIT_PITCH ? FB_X2_PITCH_PRIO : FB_X2_UPD_PRIO);   // (its half is the shorter one: behind role P's, which runs at FB_X2_LON_PRIO; FB_X2_SPLIT_PITCH: ahead up to its point Z, CtlHand::put)
 #ifdef FB_X2_SERIAL   // (timing diagnostic: the lateral half only after the longitudinal one has finished)
                 duo_wait(sy, DUO_PT_F);
 #endif

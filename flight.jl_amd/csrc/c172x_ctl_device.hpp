@@ -314,6 +314,85 @@ FBD void lqr_run_g(const MEM& M, int s0, const G& g, const double (&lo)[2], cons
         out[i] = fmin(fmax(out_free, lo[i]), hi[i]);
     }
 }
+// The same run for the longitudinal half of an update whose pitch-axis outer loops run on the PARTNER wave (ctl_lon_pitch_half, below): everything
+// that does not depend on z_ref — the trims, x - x_trim, both outputs' feedback sums, the K_int / K_fwd gains — is formed first, `late()` then
+// waits for the partner and returns z_ref, and the run ends with lqr_run_g's own expressions for int_in, fwd and the outputs. Same operations on
+// the same operands as lqr_run_g; fourteen values ride across the wait.
+template <int NX, class MEM, class G, class Late>
+FBD void lqr_run_g_late(const MEM& M, int s0, const G& g, const double (&lo)[2], const double (&hi)[2], double dT, const double (&x)[NX],
+                        const double (&z)[2], double z_ref0, const Late& late, double (&out)[2], double& z_ref1_out) {
+    constexpr int KF = 0, KW = 2 * NX, KI = KW + 4, XT = KI + 4, UT = XT + NX, ZT = UT + 2;
+    const double st0 = M.S(s0), st1 = M.S(s0 + 1), st2 = M.S(s0 + 2), st3 = M.S(s0 + 3);
+    int i1[NX + 4];
+    double t1[NX + 4];
+#pragma unroll
+    for (int k = 0; k < NX + 4; k++) i1[k] = XT + k;
+    static_assert(UT == XT + NX && ZT == UT + 2, "record layout");
+    g.template fetch<NX + 4>(i1, t1);
+    double dx[NX];
+#pragma unroll
+    for (int k = 0; k < NX; k++) dx[k] = x[k] - t1[k];
+    const double ut0 = t1[NX], ut1 = t1[NX + 1], zt0 = t1[NX + 2], zt1 = t1[NX + 3];
+    asm volatile("" : "+v"(dx[0]) : : "memory");
+    // (groups sized for the registers of a wave that shares its SIMD: the two feedback rows one after the other, 4 NX corner loads in flight each,
+    // then K_int and K_fwd of both outputs in one group — 32 loads — whose eight results are what rides across the wait with the two sums)
+    double fbk0, fbk1;
+    {
+        int i2[NX];
+        double t2[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) i2[k] = KF + 2 * k;
+        g.template fetch<NX>(i2, t2);
+        double f = t2[0] * dx[0];
+#pragma unroll
+        for (int k = 1; k < NX; k++) f += t2[k] * dx[k];
+        fbk0 = f;
+    }
+    // (the next group's corner loads stay behind this one's arithmetic — in lqr_run_g the record's stores between the outputs see to that; without a
+    // fence the load vectoriser merges all 144 corner loads of the record into one burst of dwordx4 and the allocator spills sixty values around it)
+    asm volatile("" : "+v"(fbk0) : : "memory");
+    {
+        int i2[NX];
+        double t2[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) i2[k] = KF + 1 + 2 * k;
+        g.template fetch<NX>(i2, t2);
+        double f = t2[0] * dx[0];
+#pragma unroll
+        for (int k = 1; k < NX; k++) f += t2[k] * dx[k];
+        fbk1 = f;
+    }
+    asm volatile("" : "+v"(fbk1) : : "memory");
+    const int i3[8] = {KI, KI + 2, KW, KW + 2, KI + 1, KI + 3, KW + 1, KW + 3};
+    double t3[8];
+    g.template fetch<8>(i3, t3);
+    asm volatile("" : "+v"(t3[0]), "+v"(t3[1]), "+v"(t3[2]), "+v"(t3[3]), "+v"(t3[4]), "+v"(t3[5]), "+v"(t3[6]), "+v"(t3[7]) : : "memory");   // (interpolated AHEAD of the wait)
+    const double z_ref1 = late();   // ----- the partner's outer loops have put their reference -----
+    z_ref1_out = z_ref1;
+    M.S(s0 + 4) = z_ref0; M.S(s0 + 5) = z_ref1;
+    const double dz0 = z_ref0 - z[0], dz1 = z_ref1 - z[1];
+    const double dt0 = z_ref0 - zt0, dt1 = z_ref1 - zt1;
+    {
+        const double int_in = t3[0] * dz0 + t3[1] * dz1;
+        const bool halted = sgnd(int_in * st2) > 0;
+        const double int_out = st0 + dT * int_in * (halted ? 0.0 : 1.0);
+        const double fwd = t3[2] * dt0 + t3[3] * dt1;
+        const double out_free = ut0 + int_out + fwd - fbk0;
+        M.S(s0) = int_out;
+        M.S(s0 + 2) = (out_free >= hi[0] ? 1.0 : 0.0) - (out_free <= lo[0] ? 1.0 : 0.0);
+        out[0] = fmin(fmax(out_free, lo[0]), hi[0]);
+    }
+    {
+        const double int_in = t3[4] * dz0 + t3[5] * dz1;
+        const bool halted = sgnd(int_in * st3) > 0;
+        const double int_out = st1 + dT * int_in * (halted ? 0.0 : 1.0);
+        const double fwd = t3[6] * dt0 + t3[7] * dt1;
+        const double out_free = ut1 + int_out + fwd - fbk1;
+        M.S(s0 + 1) = int_out;
+        M.S(s0 + 3) = (out_free >= hi[1] ? 1.0 : 0.0) - (out_free <= lo[1] ? 1.0 : 0.0);
+        out[1] = fmin(fmax(out_free, lo[1]), hi[1]);
+    }
+}
 template <int NX, class MEM, class G>
 FBD void lqr_init_g(const MEM& M, int s0, const G& g, const double (&lo)[2], const double (&hi)[2], double dT) {
     double x[NX], out[2];
@@ -325,18 +404,81 @@ FBD void lqr_init_g(const MEM& M, int s0, const G& g, const double (&lo)[2], con
 }
 
 // ---- longitudinal channel ------------------------------------------------------------------------------------------
+// which compensators a longitudinal mode runs (c172x_ctl.jl:46-77)
+struct LonLoops { bool te2te, q2e, th2q, v2t; };
+FBD LonLoops lon_loops(int mode) {
+    LonLoops L;
+    L.te2te = mode == FB_LON_SAS || mode == FB_LON_THR_Q || mode == FB_LON_THR_THETA || mode == FB_LON_EAS_Q || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    L.q2e = L.te2te && mode != FB_LON_SAS;
+    L.th2q = mode == FB_LON_THR_THETA || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    L.v2t = mode == FB_LON_EAS_Q || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    return L;
+}
+// The pitch-axis outer loops of a mode that runs q2e (c172x_ctl.jl:355-398): climb rate -> θ_ref (c2θ PID), θ_ref -> q_ref, q_ref -> the elevator
+// reference of the te2te LQR (q2e integrator + PID). One body, used by ctl_lon (everything on one wave) and by ctl_lon_pitch_half (the partner wave
+// of the wave-pair stepper): same operations in the same order either way.
+template <class MEM>
+FBD double lon_pitch_loops(const MEM& M, double dT, const CtlIn& v, int mode, bool changed, bool th2q, const PidGains& P, const PidGains& Pc,
+                           double sat_ele, double clm_ref, double& q_ref, double& theta_ref) {
+    constexpr double k_p_theta = 1.0;   // c172x_ctl.jl:235
+    const double theta = v.theta, q = v.w_wb_b.y, r = v.w_wb_b.z;
+    if (changed) {
+        integ_init(M, FB_CS_Q2E_INT, dT);
+        pid_init(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT);
+        if (P.k_i != 0) M.S(FB_CS_Q2E_PID) = M.S(FB_CS_TE2TE + 5);
+    }
+    if (th2q) {
+        if (mode == FB_LON_EAS_CLM) {
+            if (changed) { pid_init(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT); if (Pc.k_i != 0) M.S(FB_CS_C2THETA_PID) = theta; }
+            theta_ref = pid_run(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT, clm_ref - v.clm, sat_ele);
+        }
+        const double theta_dot_ref = k_p_theta * (theta_ref - theta);
+        const double phi_bnd = clampd(v.phi, -PI / 3, PI / 3);
+        q_ref = 1 / cos(phi_bnd) * theta_dot_ref + r * tan(phi_bnd);
+    }
+    const double io = integ_run(M, FB_CS_Q2E_INT, dT, q_ref - q, sat_ele);
+    return pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
+}
+// The pitch-axis outer loops as the PARTNER wave of the wave-pair stepper runs them (x2_periodic_half<CTL_HALF_LAT>, ahead of the lateral laws):
+// the longitudinal half is the long one of an update — te2te LQR 14 k cycles behind 8 k of outer loops, profiles/r05_x2_half_stamps.txt — and
+// of its outer loops only v2t (throttle) stays with it. Returns the elevator reference the longitudinal half's LQR takes (lqr_run_g_late);
+// writes the loops' rows, Q_REF and THETA_REF (the longitudinal half, ctl_lon<true, true>, leaves those rows alone). The mode is formed as
+// ctl_lon forms it as far as it matters here: an EAS_alt request resolves to thr_EAS or EAS_alt by the altitude state, and neither runs these
+// loops, so the altitude state (which the longitudinal half rewrites meanwhile) is not read. The previous mode and the rows read on a mode change
+// (LON_MODE, TE2TE + 5) are rewritten by the longitudinal half only BEHIND its wait for this function's result.
+template <class TAB, class MEM>
+FBD double ctl_lon_pitch_half(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
+    double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
+    const double clm_ref = M.U(FB_CU_CLM_REF);
+    double elevator_ref = clampd(clampd(M.U(FB_CU_ELEVATOR_AXIS), -1, 1) + clampd(M.U(FB_CU_ELEVATOR_OFFSET), -1, 1), -1, 1);
+    const int mode = v.on_gnd ? (int)FB_LON_DIRECT : mode_req;
+    const LonLoops L = lon_loops(mode);
+    if (L.q2e) {
+        const bool changed = mode != (int)M.S(FB_CS_LON_MODE);
+        const PidGains P_q2e = pid_gains(T, T.lk(3), v.EAS, v.h_e);
+        const PidGains P_c2t = pid_gains(T, T.lk(4), v.EAS, v.h_e);
+        const double sat_ele = M.S(FB_CS_TE2TE + 3);
+        elevator_ref = lon_pitch_loops(M, dT, v, mode, changed, L.th2q, P_q2e, P_c2t, sat_ele, clm_ref, q_ref, theta_ref);
+    }
+    M.S(FB_CS_Q_REF) = q_ref; M.S(FB_CS_THETA_REF) = theta_ref;
+    return elevator_ref;
+}
+struct NoLate { FBD double operator()() const { return 0.0; } };
 // STREAM: the LQR gains through lqr_gain_src / lqr_run_g (the halves of an update), instead of a record interpolated up front
-template <bool STREAM = false, class TAB, class MEM>
-FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req) {
+// SPLIT (with STREAM): the pitch-axis outer loops run on the partner wave (ctl_lon_pitch_half); `late()` waits for it and returns its elevator
+// reference, taken where the mode runs those loops
+template <bool STREAM = false, bool SPLIT = false, class TAB, class MEM, class Late = NoLate>
+FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode_req, const Late& late = Late()) {
+    static_assert(!SPLIT || STREAM, "the split form exists for the halves of an update");
     double q_ref = M.U(FB_CU_Q_REF), theta_ref = M.U(FB_CU_THETA_REF);
     const double EAS_ref = M.U(FB_CU_EAS_REF), clm_ref = M.U(FB_CU_CLM_REF), h_ref = M.U(FB_CU_H_REF);
-    const double EAS = v.EAS, h_e = v.h_e, q = v.w_wb_b.y, r = v.w_wb_b.z, theta = v.theta;
+    const double EAS = v.EAS, h_e = v.h_e, theta = v.theta;
     const double h_err = h_ref - h_e;
     const int h_state = (int)M.S(FB_CS_H_STATE), mode_prev = (int)M.S(FB_CS_LON_MODE);
     double throttle_ref = clampd(clampd(M.U(FB_CU_THROTTLE_AXIS), 0, 1) + clampd(M.U(FB_CU_THROTTLE_OFFSET), 0, 1), 0, 1);
     double elevator_ref = clampd(clampd(M.U(FB_CU_ELEVATOR_AXIS), -1, 1) + clampd(M.U(FB_CU_ELEVATOR_OFFSET), -1, 1), -1, 1);
     double throttle_cmd = throttle_ref, elevator_cmd = elevator_ref;
-    constexpr double h_thr = 10.0, h_hys = 1.0, k_p_theta = 1.0;   // c172x_ctl.jl:233-235
+    constexpr double h_thr = 10.0, h_hys = 1.0;   // c172x_ctl.jl:233-234
     int mode;
     if (v.on_gnd) mode = FB_LON_DIRECT;
     else if (mode_req == FB_LON_EAS_ALT) {
@@ -350,11 +492,8 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
         }
     } else mode = mode_req;
     const bool changed = mode != mode_prev;
-    const bool te2te = mode == FB_LON_SAS || mode == FB_LON_THR_Q || mode == FB_LON_THR_THETA || mode == FB_LON_EAS_Q ||
-                       mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
-    const bool q2e = te2te && mode != FB_LON_SAS;
-    const bool th2q = mode == FB_LON_THR_THETA || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
-    const bool v2t = mode == FB_LON_EAS_Q || mode == FB_LON_EAS_THETA || mode == FB_LON_EAS_CLM;
+    const LonLoops L = lon_loops(mode);
+    const bool te2te = L.te2te, q2e = L.q2e, th2q = L.th2q, v2t = L.v2t;
     const double lo[2] = {0, -1}, hi[2] = {1, 1};
     const double x_red[8] = {v.w_eb_b.y, theta, EAS, v.alpha, v.alpha_filt, v.n_eng, v.pos[0], v.pos[2]};
     double out[2];
@@ -366,8 +505,10 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     PidGains P_v2t = {0, 0, 0, 0}, P_q2e = {0, 0, 0, 0}, P_c2t = {0, 0, 0, 0};
     if (q2e) {
         P_v2t = pid_gains(T, T.lk(5), EAS, h_e);
-        P_q2e = pid_gains(T, T.lk(3), EAS, h_e);
-        P_c2t = pid_gains(T, T.lk(4), EAS, h_e);
+        if constexpr (!SPLIT) {
+            P_q2e = pid_gains(T, T.lk(3), EAS, h_e);
+            P_c2t = pid_gains(T, T.lk(4), EAS, h_e);
+        }
     }
     if (te2te) {
         const double sat_thr = M.S(FB_CS_TE2TE + 2), sat_ele = M.S(FB_CS_TE2TE + 3);   // te2te_lqr.y.out_sat of the previous update
@@ -376,29 +517,18 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
             if (changed) { pid_init(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT); if (P.k_i != 0) M.S(FB_CS_V2T_PID) = M.S(FB_CS_THROTTLE_CMD); }
             throttle_ref = pid_run(M, FB_CS_V2T_PID, P, -CTL_INF, CTL_INF, dT, EAS_ref - EAS, sat_thr);
         }
-        if (q2e) {
-            const PidGains P = P_q2e;
-            if (changed) {
-                integ_init(M, FB_CS_Q2E_INT, dT);
-                pid_init(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT);
-                if (P.k_i != 0) M.S(FB_CS_Q2E_PID) = M.S(FB_CS_TE2TE + 5);
-            }
-            if (th2q) {
-                if (mode == FB_LON_EAS_CLM) {
-                    const PidGains Pc = P_c2t;
-                    if (changed) { pid_init(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT); if (Pc.k_i != 0) M.S(FB_CS_C2THETA_PID) = theta; }
-                    theta_ref = pid_run(M, FB_CS_C2THETA_PID, Pc, -CTL_INF, CTL_INF, dT, clm_ref - v.clm, sat_ele);
-                }
-                const double theta_dot_ref = k_p_theta * (theta_ref - theta);
-                const double phi_bnd = clampd(v.phi, -PI / 3, PI / 3);
-                q_ref = 1 / cos(phi_bnd) * theta_dot_ref + r * tan(phi_bnd);
-            }
-            const double io = integ_run(M, FB_CS_Q2E_INT, dT, q_ref - q, sat_ele);
-            elevator_ref = pid_run(M, FB_CS_Q2E_PID, P, -CTL_INF, CTL_INF, dT, io, sat_ele);
+        if constexpr (!SPLIT) {
+            if (q2e) elevator_ref = lon_pitch_loops(M, dT, v, mode, changed, th2q, P_q2e, P_c2t, sat_ele, clm_ref, q_ref, theta_ref);
         }
         FB_X2_STAMP(28);
-        const double z[2] = {v.cmd[0], v.cmd[2]}, z_ref[2] = {throttle_ref, elevator_ref};
-        if constexpr (STREAM) {
+        const double z[2] = {v.cmd[0], v.cmd[2]};
+        double z_ref[2] = {throttle_ref, elevator_ref};
+        if constexpr (STREAM && SPLIT) {
+            // (the partner's elevator reference arrives inside the run, behind everything that does not need it; rows TE2TE + 4 / + 5 are written there)
+            const double er0 = elevator_ref;
+            lqr_run_g_late<8>(M, FB_CS_TE2TE, lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(0), EAS, h_e), lo, hi, dT, x_red, z, throttle_ref,
+                              [&]() { const double h = late(); return q2e ? h : er0; }, out, elevator_ref);
+        } else if constexpr (STREAM) {
             M.S(FB_CS_TE2TE + 4) = z_ref[0]; M.S(FB_CS_TE2TE + 5) = z_ref[1];
             lqr_run_g<8>(M, FB_CS_TE2TE, lqr_gain_src<FB_CTL_LQR8_REC>(T, T.lk(0), EAS, h_e), lo, hi, dT, x_red, z, z_ref, out);
         } else {
@@ -441,7 +571,7 @@ FBD void ctl_lon(const TAB& T, const MEM& M, double dT, const CtlIn& v, int mode
     }
     M.S(FB_CS_LON_MODE) = mode;
     M.S(FB_CS_THROTTLE_REF) = clampd(throttle_ref, 0, 1); M.S(FB_CS_ELEVATOR_REF) = clampd(elevator_ref, -1, 1);
-    M.S(FB_CS_Q_REF) = q_ref; M.S(FB_CS_THETA_REF) = theta_ref;
+    if constexpr (!SPLIT) { M.S(FB_CS_Q_REF) = q_ref; M.S(FB_CS_THETA_REF) = theta_ref; }
     M.S(FB_CS_THROTTLE_CMD) = clampd(throttle_cmd, 0, 1); M.S(FB_CS_ELEVATOR_CMD) = clampd(elevator_cmd, -1, 1);
 }
 

@@ -10,6 +10,7 @@
 #include "c172x_kernels.hpp"
 #include "c172_kernels_f32.hpp"
 #include "robot2d_kernels.hpp"
+#include "scenario_kernels.hpp"
 
 using namespace fbd;
 
@@ -82,6 +83,9 @@ struct fb_handle_s {
     bool have_gains = false;
     int64_t steps_done = 0;    // steps since the last init (phase of the periodic update)
     struct LogState* log = nullptr;  // on-device TimeSeries log (fb_log_*)
+    // scripted scenario (FB_TABLE_SCENARIO): the program blob and the per-aircraft rows, all in device memory
+    double* scn_prog = nullptr; int scn_nph = 0, scn_nrule = 0, scn_nact = 0, scn_npar = 0, scn_nrec = 0, scn_every = 0;
+    int32_t* scn_phase = nullptr; long long* scn_since = nullptr; double* scn_par = nullptr; double* scn_rec = nullptr;
 };
 
 static KArgs make_args(fb_handle h) {
@@ -313,6 +317,85 @@ static int32_t create_resources(fb_handle h, int32_t model_id, int32_t dtype, in
     return 0;
 }
 
+// ---- scripted scenarios (FB_TABLE_SCENARIO, include/flightbatch.h; kernel: scenario_kernels.hpp) ----
+static void scn_free(fb_handle h) {
+    hipFree(h->scn_prog); hipFree(h->scn_phase); hipFree(h->scn_since); hipFree(h->scn_par); hipFree(h->scn_rec);
+    h->scn_prog = nullptr; h->scn_phase = nullptr; h->scn_since = nullptr; h->scn_par = nullptr; h->scn_rec = nullptr;
+    h->scn_nph = h->scn_nrule = h->scn_nact = h->scn_npar = h->scn_nrec = h->scn_every = 0;
+}
+// every index the kernel will follow is checked HERE, on the host: a table is data from outside, and an out-of-range row on the device is a fault
+static int32_t scn_load(fb_handle h, const double* b, int64_t len) {
+    if (!is_x2(h)) return fail("FB_TABLE_SCENARIO: scenarios drive the Cessna172Xv2's inputs (control-law inputs, vehicle inputs); this handle is another model");
+    if (len < FB_SCN_HDR) return fail("scenario blob: %lld doubles, shorter than its header", (long long)len);
+    if (b[0] != 5000001.0) return fail("scenario blob: unknown layout version %g", b[0]);
+    auto as_int = [&](double v, int64_t lo, int64_t hi, const char* what, int64_t* out) -> bool {
+        if (!(v >= (double)lo && v <= (double)hi) || v != floor(v)) { fail("scenario blob: %s = %g is not an integer in [%lld, %lld]", what, v, (long long)lo, (long long)hi); return false; }
+        *out = (int64_t)v; return true;
+    };
+    int64_t nph, nrule, nact, npar, nrec;
+    if (!as_int(b[1], 1, 4096, "n_phase", &nph) || !as_int(b[2], 0, 65536, "n_rule", &nrule) || !as_int(b[3], 0, 65536, "n_act", &nact) ||
+        !as_int(b[4], 0, 4096, "n_par", &npar) || !as_int(b[5], 0, 4096, "n_rec", &nrec)) return -1;
+    const int64_t need = FB_SCN_HDR + FB_SCN_PHASE_REC * nph + FB_SCN_RULE_REC * nrule + FB_SCN_ACT_REC * nact;
+    if (len != need) return fail("scenario blob: %lld doubles given, its header needs %lld", (long long)len, (long long)need);
+    const double* PH = b + FB_SCN_HDR; const double* RU = PH + FB_SCN_PHASE_REC * nph; const double* AC = RU + FB_SCN_RULE_REC * nrule;
+    const int nx_dev = (int)FB_X2_NX;
+    auto src_ok = [&](double kind, double row, const char* where, int64_t idx) -> bool {
+        int64_t k, r;
+        if (!as_int(kind, 0, FB_SCN_NSRC - 1, "a source kind", &k)) return false;
+        const int64_t lim = k == FB_SCN_SRC_X ? nx_dev : k == FB_SCN_SRC_CS ? (int64_t)FB_NCS : k == FB_SCN_SRC_CU ? (int64_t)FB_NCU : k == FB_SCN_SRC_U ? (int64_t)FB_NU :
+                            k == FB_SCN_SRC_S ? (int64_t)FB_NS : k == FB_SCN_SRC_PAR ? npar : k == FB_SCN_SRC_REC ? nrec : (int64_t)1 << 30;
+        if (!as_int(row, 0, lim - 1, "a source row", &r)) { g_err += std::string(" (") + where + " " + std::to_string(idx) + ")"; return false; }
+        return true;
+    };
+    for (int64_t p = 0; p < nph; p++) {
+        int64_t a0, na, r0, nr;
+        if (!as_int(PH[4 * p], 0, nact, "a phase's first action", &a0) || !as_int(PH[4 * p + 1], 0, nact - a0, "a phase's action count", &na) ||
+            !as_int(PH[4 * p + 2], 0, nrule, "a phase's first rule", &r0) || !as_int(PH[4 * p + 3], 0, nrule - r0, "a phase's rule count", &nr)) return -1;
+    }
+    for (int64_t r = 0; r < nrule; r++) {
+        const double* ru = RU + FB_SCN_RULE_REC * r;
+        int64_t v, f;
+        if (!src_ok(ru[0], ru[1], "rule", r)) return -1;
+        if (!as_int(ru[2], 0, FB_SCN_ALWAYS, "a comparison", &v) || !as_int(ru[4], -1, npar - 1, "a rule's parameter row", &v) ||
+            !as_int(ru[5], 0, nact, "a rule's first action", &f) || !as_int(ru[6], 0, nact - f, "a rule's action count", &v) ||
+            !as_int(ru[7], 0, nph - 1, "a rule's next phase", &v)) return -1;
+        if (!std::isfinite(ru[3])) return fail("scenario blob: rule %lld compares with a non-finite constant", (long long)r);
+    }
+    for (int64_t k = 0; k < nact; k++) {
+        const double* ac = AC + FB_SCN_ACT_REC * k;
+        int64_t dst, row, nt, v;
+        if (!as_int(ac[0], 0, FB_SCN_NDST - 1, "a destination kind", &dst)) return -1;
+        const int64_t lim = dst == FB_SCN_DST_CU ? (int64_t)FB_NCU : dst == FB_SCN_DST_U ? (int64_t)FB_NU : dst == FB_SCN_DST_REC ? nrec : (int64_t)1 << 30;
+        if (!as_int(ac[1], 0, lim - 1, "a destination row", &row) || !as_int(ac[2], 0, 1, "a wrap flag", &v) || !as_int(ac[4], 0, FB_SCN_NTERM, "a term count", &nt)) return -1;
+        for (int64_t t = 0; t < nt; t++) if (!src_ok(ac[5 + 3 * t], ac[6 + 3 * t], "action", k)) return -1;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    scn_free(h);
+    const int64_t n = h->n;
+    HIPCHK(hipMalloc(&h->scn_prog, sizeof(double) * len));
+    HIPCHK(hipMemcpy(h->scn_prog, b, sizeof(double) * len, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->scn_phase, sizeof(int32_t) * n));
+    HIPCHK(hipMalloc(&h->scn_since, sizeof(long long) * n));
+    HIPCHK(hipMalloc(&h->scn_par, sizeof(double) * (npar > 0 ? npar : 1) * n));
+    HIPCHK(hipMalloc(&h->scn_rec, sizeof(double) * (nrec > 0 ? nrec : 1) * n));
+    HIPCHK(hipMemset(h->scn_phase, 0, sizeof(int32_t) * n));
+    HIPCHK(hipMemset(h->scn_since, 0, sizeof(long long) * n));
+    HIPCHK(hipMemset(h->scn_par, 0, sizeof(double) * (npar > 0 ? npar : 1) * n));
+    HIPCHK(hipMemset(h->scn_rec, 0, sizeof(double) * (nrec > 0 ? nrec : 1) * n));
+    h->scn_nph = (int)nph; h->scn_nrule = (int)nrule; h->scn_nact = (int)nact; h->scn_npar = (int)npar; h->scn_nrec = (int)nrec; h->scn_every = 1;
+    return 0;
+}
+// one evaluation of the table for every aircraft, behind the step that has just completed (steps_done counts it)
+static int32_t scn_evaluate(fb_handle h) {
+    ScnArgs sc;
+    sc.prog = h->scn_prog; sc.n_ph = h->scn_nph; sc.n_rule = h->scn_nrule; sc.n_act = h->scn_nact; sc.n_par = h->scn_npar; sc.n_rec = h->scn_nrec;
+    sc.phase = h->scn_phase; sc.since = h->scn_since; sc.par = h->scn_par; sc.rec = h->scn_rec;
+    sc.step = h->steps_done; sc.dt = h->params.dt; sc.t = (double)h->steps_done * h->params.dt;   // sim.t = t_start + nstep dt with t_start = 0 (FC/sim.jl:261-275)
+    FB_LAUNCH_X2K(k_scenario, h->n, make_args(h), sc);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 const char* fb_last_error(void) { return g_err.c_str(); }
@@ -354,6 +437,7 @@ int32_t fb_destroy(fb_handle h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     log_free(h);
+    scn_free(h);
     r2_destroy(h);
     hipFree(h->x_own); hipFree(h->s_own); hipFree(h->u); hipFree(h->ui); hipFree(h->status); hipFree(h->term_step); hipFree(h->term_where); hipFree(h->y); hipFree(h->xdot);
     hipFree(h->tables); hipFree(h->tables_f32); hipFree(h->egm96); hipFree(h->trim_buf); hipFree(h->trim_ok); hipFree(h->trim_ws); hipFree(h->env_rows);
@@ -420,6 +504,7 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
         h->r2->have_table = true;
         return 0;
     }
+    if (kind == FB_TABLE_SCENARIO) return scn_load(h, (const double*)data, ndims == 1 ? dims[0] : -1);
     if (kind == FB_TABLE_CTL_GAINS) {
         if (!is_x2(h)) return fail("table kind does not belong to this model");
         const double* b = (const double*)data;
@@ -480,11 +565,18 @@ int32_t fb_set_table(fb_handle h, int32_t kind, const void* data, const int64_t*
     h->tables_f32_stale = true;
     return 0;
 }
+// TunableSeaLevelU holds T and p as Ranged values: an assignment saturates to [T_std - 50, T_std + 50] K and [p_std - 10000, p_std + 10000] Pa
+// (FP/atmosphere.jl:69-77) — so does every sea-level value that enters through this ABI (fb_get_params / fb_get_env return what is in force)
+static double sat_T_sl(double T) { return fmin(fmax(T, isa::T_std - 50.0), isa::T_std + 50.0); }
+static double sat_p_sl(double p) { return fmin(fmax(p, isa::p_std - 10000.0), isa::p_std + 10000.0); }
 int32_t fb_set_params(fb_handle h, const fb_params* p) {
     if (h) fsal_invalidate(h);
     if (!h || !p) return fail("null argument");
     if (!(p->dt > 0)) return fail("dt must be positive");
+    if (!std::isfinite(p->T_sl) || !std::isfinite(p->p_sl) || !std::isfinite(p->wind_ned[0]) || !std::isfinite(p->wind_ned[1]) || !std::isfinite(p->wind_ned[2]) ||
+        !std::isfinite(p->h_terrain)) return fail("fb_set_params: T_sl, p_sl, wind_ned and h_terrain must be finite");
     h->params = *p;
+    h->params.T_sl = sat_T_sl(p->T_sl); h->params.p_sl = sat_p_sl(p->p_sl);
     return 0;
 }
 int32_t fb_get_params(fb_handle h, fb_params* p) {
@@ -506,14 +598,15 @@ int32_t fb_set_env(fb_handle h, const double* env) {
         return 0;
     }
     const int64_t n = h->n;
-    for (int64_t i = 0; i < n; i++) {
-        const double T = env[(int64_t)FB_ENV_T_SL * n + i], p = env[(int64_t)FB_ENV_P_SL * n + i];
-        if (!(T > 0) || !(p > 0)) return fail("fb_set_env: aircraft %lld has sea-level T = %g K, p = %g Pa (both must be positive)", (long long)i, T, p);
-    }
+    for (int64_t i = 0; i < n; i++)
+        for (int k = 0; k < FB_NENV; k++)
+            if (!std::isfinite(env[(int64_t)k * n + i])) return fail("fb_set_env: aircraft %lld has a non-finite value in row %d (%g)", (long long)i, k, env[(int64_t)k * n + i]);
     std::vector<double> rows((size_t)fbd::ENV_DEV_ROWS * n);
     std::memcpy(rows.data(), env, sizeof(double) * FB_NENV * n);
     for (int64_t i = 0; i < n; i++) {
-        const double T = env[(int64_t)FB_ENV_T_SL * n + i], p = env[(int64_t)FB_ENV_P_SL * n + i];
+        // (the reference's Ranged sea-level inputs saturate; a row outside their range is brought to the bound, as `atmosphere.sl.u.T = ...` would)
+        const double T = sat_T_sl(env[(int64_t)FB_ENV_T_SL * n + i]), p = sat_p_sl(env[(int64_t)FB_ENV_P_SL * n + i]);
+        rows[(size_t)FB_ENV_T_SL * n + i] = T; rows[(size_t)FB_ENV_P_SL * n + i] = p;
         const double lnp = log(p / 101325.0);
         rows[(size_t)fbd::ENV_DEV_LN_P * n + i] = lnp;
         rows[(size_t)fbd::ENV_DEV_K_RT * n + i] = exp(0.5 * 6.5e-3 * 287.05287 / 9.80665 * lnp) / sqrt(T);
@@ -522,6 +615,10 @@ int32_t fb_set_env(fb_handle h, const double* env) {
     HIPCHK(hipMemcpyAsync(h->env_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
+}
+int32_t fb_has_env(fb_handle h) {
+    if (!h) return fail("null handle");
+    return h->env_rows ? 1 : 0;
 }
 int32_t fb_get_env(fb_handle h, double* env) {
     if (!h || !env) return fail("null argument");
@@ -791,17 +888,23 @@ int32_t fb_step(fb_handle h, int64_t nsteps) {
     if (nsteps < 0) return fail("nsteps must be >= 0");
     HIPCHK(hipSetDevice(h->device));
     LogState* L = h->log;
-    if (!L || L->every <= 0) return step_raw(h, nsteps);
-    // launches are cut at the save instants; a sample is taken after the step's callbacks (cb_save comes last, FC/sim.jl:217)
+    const bool logging = L && L->every > 0, scripted = h->scn_every > 0;
+    if (!logging && !scripted) return step_raw(h, nsteps);
+    // launches are cut at the scenario's evaluation instants and at the save instants; behind a step the callbacks run in the reference's order:
+    // the user callback (here: the scenario table, evaluated on the device), then the save (cb_save comes last, FC/sim.jl:204-218)
     int64_t left = nsteps;
     while (left > 0) {
-        const int64_t to_save = L->every - (L->step_index % L->every);
-        const int64_t k = left < to_save ? left : to_save;
-        if (k == to_save && L->count >= L->capacity) return fail("log capacity (%lld samples) exhausted", (long long)L->capacity);
+        int64_t k = left;
+        if (logging) { const int64_t to_save = L->every - (L->step_index % L->every); if (to_save < k) k = to_save; }
+        if (scripted) { const int64_t to_scn = h->scn_every - (h->steps_done % h->scn_every); if (to_scn < k) k = to_scn; }
+        const bool saves = logging && (L->step_index + k) % L->every == 0;
+        if (saves && L->count >= L->capacity) return fail("log capacity (%lld samples) exhausted", (long long)L->capacity);
         if (int32_t rc = step_raw(h, k)) return rc;
-        L->step_index += k;
+        if (logging) L->step_index += k;
         left -= k;
-        if (L->step_index % L->every == 0)
+        if (scripted && h->steps_done % h->scn_every == 0)
+            if (int32_t rc = scn_evaluate(h)) return rc;
+        if (saves)
             if (int32_t rc = log_record(h)) return rc;
     }
     return 0;
@@ -967,6 +1070,56 @@ int32_t fb_get_termination(fb_handle h, int64_t* step, int32_t* where) {
         if (step) step[i] = term ? (int64_t)ts[(size_t)i] : -1;
         if (where && !term) where[i] = FB_TERM_NONE;
     }
+    return 0;
+}
+
+int32_t fb_scenario_configure(fb_handle h, int32_t every) {
+    if (!h) return fail("null handle");
+    if (every < 0) return fail("fb_scenario_configure: the evaluation period must be >= 1 step (0: scenario off)");
+    HIPCHK(hipSetDevice(h->device));
+    if (every == 0) { HIPCHK(hipStreamSynchronize(h->stream)); scn_free(h); return 0; }
+    if (!h->scn_prog) return fail("fb_scenario_configure: no scenario table is loaded (fb_set_table FB_TABLE_SCENARIO)");
+    h->scn_every = every;
+    return 0;
+}
+int32_t fb_scenario_set_params(fb_handle h, const double* par) {
+    if (!h || !par) return fail("null argument");
+    if (!h->scn_prog) return fail("no scenario table is loaded (fb_set_table FB_TABLE_SCENARIO)");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->scn_npar > 0) HIPCHK(hipMemcpyAsync(h->scn_par, par, sizeof(double) * h->scn_npar * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_scenario_get_params(fb_handle h, double* par) {
+    if (!h || !par) return fail("null argument");
+    if (!h->scn_prog) return fail("no scenario table is loaded (fb_set_table FB_TABLE_SCENARIO)");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->scn_npar > 0) HIPCHK(hipMemcpyAsync(par, h->scn_par, sizeof(double) * h->scn_npar * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_scenario_get_state(fb_handle h, int32_t* phase, int64_t* since_step, double* rec) {
+    if (!h) return fail("null handle");
+    if (!h->scn_prog) return fail("no scenario table is loaded (fb_set_table FB_TABLE_SCENARIO)");
+    HIPCHK(hipSetDevice(h->device));
+    static_assert(sizeof(long long) == sizeof(int64_t), "");
+    if (phase) HIPCHK(hipMemcpyAsync(phase, h->scn_phase, sizeof(int32_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (since_step) HIPCHK(hipMemcpyAsync(since_step, h->scn_since, sizeof(int64_t) * h->n, hipMemcpyDeviceToHost, h->stream));
+    if (rec && h->scn_nrec > 0) HIPCHK(hipMemcpyAsync(rec, h->scn_rec, sizeof(double) * h->scn_nrec * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int32_t fb_scenario_set_state(fb_handle h, const int32_t* phase, const int64_t* since_step, const double* rec) {
+    if (!h) return fail("null handle");
+    if (!h->scn_prog) return fail("no scenario table is loaded (fb_set_table FB_TABLE_SCENARIO)");
+    if (phase)
+        for (int64_t i = 0; i < h->n; i++)
+            if (phase[i] < 0 || phase[i] >= h->scn_nph) return fail("fb_scenario_set_state: aircraft %lld in phase %d, the table has %d", (long long)i, (int)phase[i], h->scn_nph);
+    HIPCHK(hipSetDevice(h->device));
+    if (phase) HIPCHK(hipMemcpyAsync(h->scn_phase, phase, sizeof(int32_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    if (since_step) HIPCHK(hipMemcpyAsync(h->scn_since, since_step, sizeof(int64_t) * h->n, hipMemcpyHostToDevice, h->stream));
+    if (rec && h->scn_nrec > 0) HIPCHK(hipMemcpyAsync(h->scn_rec, rec, sizeof(double) * h->scn_nrec * h->n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
 

@@ -12,4 +12,5 @@ from . import sharding  # noqa: F401
 from .robot2d import Robot2DWorld, InitParameters  # noqa: F401
 from .c172x import Cessna172Xv2World, ModeControlLon, ModeControlLat, ModeGuidance  # noqa: F401
 from . import ctl_gains  # noqa: F401
+from . import scenario  # noqa: F401
 from .fleet import MixedFleet  # noqa: F401

@@ -75,6 +75,12 @@ def _load():
         "fb_comm_shard_sizes": ([VP, C.POINTER(I64), C.POINTER(I64)], C.c_int32),
         "fb_gather_state": ([H, VP, VP], C.c_int32),
         "fb_comm_destroy": ([VP], C.c_int32),
+        "fb_has_env": ([H], C.c_int32),
+        "fb_scenario_configure": ([H, C.c_int32], C.c_int32),
+        "fb_scenario_set_params": ([H, D], C.c_int32),
+        "fb_scenario_get_params": ([H, D], C.c_int32),
+        "fb_scenario_get_state": ([H, I32, C.POINTER(I64), D], C.c_int32),
+        "fb_scenario_set_state": ([H, I32, C.POINTER(I64), D], C.c_int32),
         "fb_timing_begin": ([H], C.c_int32),
         "fb_timing_end": ([H, C.POINTER(C.c_float), C.POINTER(I64)], C.c_int32),
         "fb_timing_begin_per_launch": ([H, I64], C.c_int32),

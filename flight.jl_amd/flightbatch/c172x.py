@@ -114,3 +114,62 @@ class Cessna172Xv2World(BatchedWorld):
     def cs(self, v):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NCS"], self.n)
         check(lib.fb_set_ctl_state(self._h, _pd(v)))
+
+    # -- scripted scenarios: the device-side user_callback! (flightbatch/scenario.py; FC/sim.jl:185, 334-336) --
+    def set_scenario(self, scn, params: np.ndarray | None = None, every: int = 1, rec_init: float = 0.0) -> None:
+        """Load a scenario table (scenario.Scenario, or None to switch scenarios off), the per-aircraft parameter rows [n_par, n] and the
+        evaluation period in steps (1: after every step, like the reference's user_callback!). Every aircraft starts in phase 0."""
+        if scn is None:
+            check(lib.fb_scenario_configure(self._h, 0))
+            self._scn = None
+            return
+        blob = np.ascontiguousarray(scn.pack(), dtype=np.float64)
+        dims = (C.c_int64 * 1)(blob.size)
+        check(lib.fb_set_table(self._h, K["FB_TABLE_SCENARIO"], blob.ctypes.data_as(C.c_void_p), dims, 1))
+        check(lib.fb_scenario_configure(self._h, int(every)))
+        self._scn = (blob, scn.n_par, scn.n_rec, int(every), list(scn.names))
+        if scn.n_par:
+            p = np.ascontiguousarray(params, dtype=np.float64).reshape(scn.n_par, self.n)
+            check(lib.fb_scenario_set_params(self._h, _pd(p)))
+        if scn.n_rec and rec_init != 0.0:
+            self.set_scenario_state(np.zeros(self.n, np.int32), np.zeros(self.n, np.int64), np.full((scn.n_rec, self.n), rec_init))
+
+    def scenario_state(self) -> dict:
+        """phase [n], since [n] (step count at the entry of the phase), rec [n_rec, n]"""
+        if getattr(self, "_scn", None) is None:
+            raise RuntimeError("no scenario is loaded (set_scenario)")
+        n_rec = self._scn[2]
+        phase = np.empty(self.n, np.int32); since = np.empty(self.n, np.int64); rec = np.empty((max(n_rec, 1), self.n))
+        check(lib.fb_scenario_get_state(self._h, phase.ctypes.data_as(C.POINTER(C.c_int32)), since.ctypes.data_as(C.POINTER(C.c_int64)), _pd(rec)))
+        return {"phase": phase, "since": since, "rec": rec[:n_rec]}
+
+    def set_scenario_state(self, phase, since, rec=None) -> None:
+        phase = np.ascontiguousarray(phase, dtype=np.int32).reshape(self.n); since = np.ascontiguousarray(since, dtype=np.int64).reshape(self.n)
+        r = None if rec is None else np.ascontiguousarray(rec, dtype=np.float64).reshape(self._scn[2], self.n)
+        check(lib.fb_scenario_set_state(self._h, phase.ctypes.data_as(C.POINTER(C.c_int32)), since.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        _pd(r) if r is not None and r.size else None))
+
+    def checkpoint(self) -> dict:
+        ck = super().checkpoint()
+        if getattr(self, "_scn", None) is not None:   # the scenario travels with the checkpoint: table, period, parameters, per-aircraft state
+            blob, n_par, n_rec, every, names = self._scn
+            st = self.scenario_state()
+            par = np.empty((max(n_par, 1), self.n))
+            if n_par:
+                check(lib.fb_scenario_get_params(self._h, _pd(par)))
+            ck.update(scn_blob=blob, scn_every=np.int64(every), scn_par=par[:n_par], scn_phase=st["phase"], scn_since=st["since"], scn_rec=st["rec"],
+                      scn_dims=np.array([n_par, n_rec], np.int64))
+        return ck
+
+    def restore(self, ck: dict) -> None:
+        super().restore(ck)
+        if "scn_blob" in ck:
+            blob = np.ascontiguousarray(ck["scn_blob"], dtype=np.float64)
+            dims = (C.c_int64 * 1)(blob.size)
+            check(lib.fb_set_table(self._h, K["FB_TABLE_SCENARIO"], blob.ctypes.data_as(C.c_void_p), dims, 1))
+            check(lib.fb_scenario_configure(self._h, int(ck["scn_every"])))
+            n_par, n_rec = (int(v) for v in ck["scn_dims"])
+            self._scn = (blob, n_par, n_rec, int(ck["scn_every"]), [])
+            if n_par:
+                check(lib.fb_scenario_set_params(self._h, _pd(np.ascontiguousarray(ck["scn_par"], dtype=np.float64))))
+            self.set_scenario_state(ck["scn_phase"], ck["scn_since"], ck["scn_rec"] if n_rec else None)

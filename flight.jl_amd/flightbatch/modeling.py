@@ -152,7 +152,7 @@ class BatchedWorld:
     #    default) = the batch-wide block of `params`. --
     @property
     def env(self):
-        if not getattr(self, "_has_env", False):
+        if not self.has_env:
             return None
         e = np.empty((K["FB_NENV"], self.n))
         check(lib.fb_get_env(self._h, _pd(e)))
@@ -162,11 +162,17 @@ class BatchedWorld:
     def env(self, v):
         if v is None:
             check(lib.fb_set_env(self._h, None))
-            self._has_env = False
             return
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(K["FB_NENV"], self.n)
         check(lib.fb_set_env(self._h, _pd(v)))
-        self._has_env = True
+
+    @property
+    def has_env(self) -> bool:
+        """whether the handle carries per-aircraft environment rows — asked of the handle (fb_has_env), not remembered here"""
+        rc = lib.fb_has_env(self._h)
+        if rc < 0:
+            check(rc)
+        return rc == 1
 
     def set_env(self, wind_ned=None, T_sl=None, p_sl=None, h_terrain=None):
         """Per-aircraft rows from keyword arrays (scalars broadcast; what is not given comes from the batch-wide `params`,
@@ -280,15 +286,20 @@ class BatchedWorld:
         cnt = C.c_int64()
         check(lib.fb_get_step_count(self._h, C.byref(cnt)))
         ck = {k: getattr(self, k) for k in self._CKPT_ARRAYS}
-        if getattr(self, "_has_env", False):
-            ck["env"] = self.env
+        if self.MODEL != "FB_MODEL_ROBOT2D":   # (the marker says whether the world had rows: restore() clears a world's rows only when told to)
+            ck["has_env"] = np.bool_(self.has_env)
+            if ck["has_env"]:
+                ck["env"] = self.env
         tstep, twhere = self.termination
         ck.update(status=self.status, term_step=tstep, term_where=twhere, step_count=np.int64(cnt.value), t=np.float64(lib.fb_time(self._h)))
         return ck
 
     def restore(self, ck: dict) -> None:
-        if hasattr(type(self), "env") and self.MODEL != "FB_MODEL_ROBOT2D":
-            self.env = ck.get("env")     # (before the state: fb_set_env invalidates the derivative carried across launches, like any input change)
+        # (before the state: fb_set_env invalidates the derivative carried across launches, like any input change. A checkpoint that says
+        # nothing about rows — written before they existed — leaves the world's rows as they are; one that says "no rows" clears them.)
+        if self.MODEL != "FB_MODEL_ROBOT2D" and ("has_env" in ck or "env" in ck):
+            has = bool(ck["has_env"]) if "has_env" in ck else True
+            self.env = ck["env"] if has else None
         if "s" in self._CKPT_ARRAYS:
             self.set_state(ck["x"], ck["s"])
         else:

@@ -234,6 +234,8 @@ end
 """Each simulation's own environment: env [N x 6], columns wind N / E / D (`world.atmosphere.wind.u`, FlightPhysics/src/atmosphere.jl:156-165),
 sea-level T / p (`world.atmosphere.sl.u`, :75-84), terrain elevation (FlightPhysics/src/terrain.jl:34-36). `nothing` returns to the batch-wide block."""
 function set_env!(w::BatchedWorld, env::Union{Matrix{Float64}, Nothing})
+    # the C ABI takes no length: a matrix of another size would be read out of bounds, a transposed 6 x N one silently misread
+    env === nothing || size(env) == (w.n, 6) || throw(DimensionMismatch("set_env!: env must be $(w.n) x 6 (aircraft x wind N / E / D, T_sl, p_sl, h_terrain), got $(size(env))"))
     check(ccall((:fb_set_env, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, env === nothing ? C_NULL : env))
     nothing
 end

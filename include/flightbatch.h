@@ -217,7 +217,8 @@ enum {
     FB_TABLE_PISTON = 2,    /* packed blob, layout in csrc/tables.h; FP/piston.jl:70-195 */
     FB_TABLE_AERO = 3,      /* packed blob, layout in csrc/tables.h; FA/c172/c172.jl:51-199 */
     FB_TABLE_ROBOT2D = 4,   /* FB_R2_TABLE_SIZE doubles, see above; FA/robot2d/robot2d.jl:20-30,419-436 */
-    FB_TABLE_CTL_GAINS = 5  /* Cessna172Xv2 autopilot gain lookups, layout above; FP/control.jl:879-994 */
+    FB_TABLE_CTL_GAINS = 5, /* Cessna172Xv2 autopilot gain lookups, layout above; FP/control.jl:879-994 */
+    FB_TABLE_SCENARIO = 6   /* Cessna172Xv2: a scripted scenario as a table (below): the device-side user_callback!; FC/sim.jl:185, 334-336 */
 };
 
 /* World-level parameters shared by the whole batch (one SimpleWorld each in the reference, identical here) */
@@ -268,6 +269,7 @@ int32_t fb_get_params(fb_handle h, fb_params* p);
  * fb_get_env fails when no rows are set. */
 int32_t fb_set_env(fb_handle h, const double* env);
 int32_t fb_get_env(fb_handle h, double* env);
+int32_t fb_has_env(fb_handle h);   /* 1: per-aircraft rows are set, 0: the batch-wide block is in force, < 0: error */
 
 /* mdl.x / mdl.s / mdl.u access : FC/modeling.jl:89-101 ; property forwarding FC/sim.jl:261-275.
  * fb_set_state sets an INITIAL condition: like init! (FC/sim.jl:390-414) it also clears the sticky status words and restarts the
@@ -373,6 +375,42 @@ int32_t fb_comm_destroy(void* comm);
 int32_t fb_get_step_count(fb_handle h, int64_t* count);
 int32_t fb_set_step_count(fb_handle h, int64_t count, double t);
 int32_t fb_set_status(fb_handle h, const int32_t* status);
+
+/* ---- Scripted scenarios: `user_callback!` on the device (Cessna172Xv2) -------------------------------------------------------------
+ * The reference's scenarios are closures that run after every step, behind f_step! / f_periodic! and ahead of the save (FC/sim.jl:185,
+ * 204-218, 334-336): a phase symbol and, per phase, "set these inputs; if <condition on the model's outputs> set those and go on to the next
+ * phase" (FA demos/c172_demos.jl:423-486 crosswind landing, :525-642 traffic pattern). For a batch the same logic is a TABLE, interpreted per
+ * aircraft by a kernel that fb_step launches behind every `every`-th step (fb_step cuts its stepping launches there, as it does at the log's
+ * save instants); per aircraft: a phase word (starts at 0), the step count at which the phase was entered, n_par parameter rows (host-set)
+ * and n_rec record rows (written by actions, read back by the host). Nothing crosses to the host during a run.
+ * One evaluation of one aircraft (status word 0 only): the `always` actions of its phase, in order; then its rules, in order — the FIRST whose
+ * condition holds runs its actions and sets the next phase (at most one transition per evaluation, like the demos' if / elseif chains).
+ * Blob (fb_set_table(h, FB_TABLE_SCENARIO, blob, &len, 1); doubles; integers as doubles):
+ *   header [FB_SCN_HDR]:        magic 5000001, n_phase, n_rule, n_act, n_par, n_rec, 0, 0
+ *   phases [n_phase][FB_SCN_PHASE_REC]: first `always` action, their number, first rule, number of rules
+ *   rules  [n_rule][FB_SCN_RULE_REC]:   source kind, source row, comparison (FB_SCN_LT ...), constant c, parameter row p or -1, first action,
+ *                                       number of actions, next phase.   Holds when  source - (p >= 0 ? par[p] : 0)  <cmp>  c
+ *   actions [n_act][FB_SCN_ACT_REC]:    destination kind, destination row (FB_SCN_DST_UI: the bit mask), wrap flag, c0, number of terms (<= 3),
+ *                                       3 x (source kind, source row, coefficient).   value = c0 + sum coefficient * source, summed in order,
+ *                                       then Attitude.wrap_to_pi (FP/attitude.jl:478) if the flag is set; FB_SCN_DST_UI sets the bits where value != 0
+ *                                       and clears them otherwise. A value is read when its action runs (it sees the actions before it).
+ * Sources: FB_SCN_SRC_T = sim.t behind the step (steps taken x dt), T_IN_PHASE = (steps taken - step of entry) x dt, X / CS / CU / U / S = rows of
+ * the state (device row order) / control-law record / control-law inputs / vehicle inputs / discrete states, PAR / REC = the aircraft's own rows,
+ * and of vehicle.y at the current state: ON_GND (is_on_gnd, 0 / 1; c172.jl:998-1001), H_E, PSI / THETA / PHI (e_nb), CHI, EAS, CLM (climb rate). */
+enum { FB_SCN_HDR = 8, FB_SCN_PHASE_REC = 4, FB_SCN_RULE_REC = 8, FB_SCN_ACT_REC = 14, FB_SCN_NTERM = 3 };
+enum { FB_SCN_SRC_CONST = 0, FB_SCN_SRC_T, FB_SCN_SRC_T_IN_PHASE, FB_SCN_SRC_X, FB_SCN_SRC_CS, FB_SCN_SRC_CU, FB_SCN_SRC_U, FB_SCN_SRC_S,
+       FB_SCN_SRC_ON_GND, FB_SCN_SRC_H_E, FB_SCN_SRC_PSI, FB_SCN_SRC_THETA, FB_SCN_SRC_PHI, FB_SCN_SRC_CHI, FB_SCN_SRC_EAS, FB_SCN_SRC_CLM,
+       FB_SCN_SRC_PAR, FB_SCN_SRC_REC, FB_SCN_NSRC };
+enum { FB_SCN_DST_CU = 0, FB_SCN_DST_U, FB_SCN_DST_UI, FB_SCN_DST_REC, FB_SCN_NDST };
+enum { FB_SCN_LT = 0, FB_SCN_GT, FB_SCN_GE, FB_SCN_LE, FB_SCN_EQ, FB_SCN_NE, FB_SCN_ALWAYS };
+/* fb_set_table(FB_TABLE_SCENARIO) validates every index of the blob, allocates the per-aircraft rows (phase 0, entry step 0, parameters and
+ * records zero) and switches the evaluation on with every = 1. fb_scenario_configure: the period in steps (>= 1), or 0: scenario off, rows freed.
+ * The scenario's state is NOT touched by fb_trim / fb_set_state (the reference's closures keep their phase across init!): set it explicitly. */
+int32_t fb_scenario_configure(fb_handle h, int32_t every);
+int32_t fb_scenario_set_params(fb_handle h, const double* par /* [n_par x N] */);
+int32_t fb_scenario_get_params(fb_handle h, double* par /* [n_par x N] */);
+int32_t fb_scenario_get_state(fb_handle h, int32_t* phase /* [N] or NULL */, int64_t* since_step /* [N] or NULL */, double* rec /* [n_rec x N] or NULL */);
+int32_t fb_scenario_set_state(fb_handle h, const int32_t* phase, const int64_t* since_step, const double* rec /* each [..N] or NULL: left as is */);
 
 /* HIP-event timing on the handle's stream around the fb_step launches issued between begin and end;
  * reports total elapsed ms and the number of stepping-kernel launches. */

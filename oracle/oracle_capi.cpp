@@ -27,7 +27,11 @@ static std::unique_ptr<C172Model> g_model;
 
 static Env env_from(const double* e) {
     Env v;
-    v.T_sl = e[0]; v.p_sl = e[1]; v.wind = {e[2], e[3], e[4]}; v.h_trn = e[5]; v.surface = (int)e[6];
+    // TunableSeaLevelU holds T and p as Ranged values: an assignment saturates to [T_std - 50, T_std + 50] K, [p_std - 10000, p_std + 10000] Pa
+    // (FlightPhysics/src/atmosphere.jl:69-77)
+    v.T_sl = std::fmin(std::fmax(e[0], isa::T_std - 50.0), isa::T_std + 50.0);
+    v.p_sl = std::fmin(std::fmax(e[1], isa::p_std - 10000.0), isa::p_std + 10000.0);
+    v.wind = {e[2], e[3], e[4]}; v.h_trn = e[5]; v.surface = (int)e[6];
     return v;
 }
 // Every simulation of the reference owns its world (atmosphere.jl:75-84,156-165; terrain.jl:34-48): with fo_set_env_per_aircraft(1) the
