@@ -228,3 +228,81 @@ def test_per_aircraft_env_every_stepping_path_agrees(fb, monkeypatch):
     d = np.abs(xs["1"][0] - xs["0"][0])[:, xs["1"][1]] / np.maximum(np.abs(xs["0"][0][:, xs["1"][1]]), 1.0)
     print("Xv2 with per-aircraft rows, wave-pair vs one-wave kernel after 500 closed-loop steps: %.2e" % d.max())
     assert d.max() < 1e-8
+
+
+def test_sea_level_rows_saturate_like_the_references_ranged_inputs(fb, oracle):
+    """TunableSeaLevelU holds T and p as Ranged values: an assignment saturates to [T_std - 50, T_std + 50] K and [p_std - 10000, p_std + 10000] Pa
+    (FP/atmosphere.jl:69-77). Rows outside that range are brought to the bound by fb_set_env (fb_get_env returns what is in force) and by the
+    oracle alike — the same trajectory on both sides — non-finite values are refused, and the batch-wide block saturates the same way."""
+    K = fb.K
+    n = 512
+    tp = lattice_trim_params(fb, n, seed=63)
+    env6 = random_env(fb, n, 9, h_trn=0.0)
+    env6[K["FB_ENV_T_SL"], ::4] = 150.0; env6[K["FB_ENV_T_SL"], 1::4] = 400.0      # far outside [238.15, 338.15]
+    env6[K["FB_ENV_P_SL"], ::3] = 50000.0; env6[K["FB_ENV_P_SL"], 1::3] = 130000.0  # far outside [91325, 111325]
+    w = fb.BatchedWorld(n)
+    w.env = env6
+    got = w.env
+    sat = env6.copy()
+    sat[K["FB_ENV_T_SL"]] = np.clip(env6[K["FB_ENV_T_SL"]], 288.15 - 50, 288.15 + 50); sat[K["FB_ENV_P_SL"]] = np.clip(env6[K["FB_ENV_P_SL"]], 101325.0 - 1e4, 101325.0 + 1e4)
+    assert np.array_equal(got, sat) and not np.array_equal(got, env6)
+    fb.f_init(w, tp)
+    ok = w.trim_success
+    assert ok.mean() > 0.9
+    x0, s0, u0, ui0 = w.x, w.s, w.u, w.ui
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.step(sim, 5.0); w.sync()
+    with oracle.per_aircraft_env():
+        xo, so, sto = oracle.step(x0, u0, ui0, s0, oracle.env_rows(env6), 0.01, 500)     # the oracle is handed the UNSATURATED rows
+    assert np.array_equal(w.status, sto)
+    err = (np.abs(w.x - xo) / np.maximum(np.abs(xo), 1.0))[:, sto == 0]
+    print("saturated sea-level rows, max scaled error after 500 steps: %.3e" % err.max())
+    assert err.max() < 1e-6
+    for row, val in ((K["FB_ENV_WIND_E"], np.inf), (K["FB_ENV_T_SL"], np.nan), (K["FB_ENV_H_TERRAIN"], -np.inf)):
+        bad = env6.copy(); bad[row, 7] = val
+        with pytest.raises(fb.FlightBatchError, match="non-finite"):
+            w.env = bad
+    assert np.array_equal(w.env, sat), "a refused call leaves the rows as they were"
+    w.env = None
+    w.set_params(T_sl=500.0, p_sl=10.0)
+    assert w.params.T_sl == 288.15 + 50 and w.params.p_sl == 101325.0 - 1e4
+    w.close()
+
+
+@pytest.mark.parametrize("rows_in_checkpoint", [True, False])
+def test_checkpoint_round_trip_with_environment_rows(fb, rows_in_checkpoint):
+    """checkpoint -> np.savez -> restore: a checkpoint of a world WITH rows carries them (the resumed trajectory is the uninterrupted one, bit for
+    bit); a checkpoint of a world WITHOUT rows says so and clears the rows of the world it is restored into; one that says nothing about rows
+    (written before they existed) leaves the world's rows alone. Whether a handle has rows is asked of the handle (fb_has_env)."""
+    import io
+    n = 1024
+    tp = lattice_trim_params(fb, n, seed=64)
+    env6 = random_env(fb, n, 11, h_trn=0.0)
+    w = fb.BatchedWorld(n)
+    if rows_in_checkpoint:
+        w.env = env6
+    assert w.has_env == rows_in_checkpoint
+    fb.f_init(w, tp)
+    sim = fb.Simulation(w, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.step(sim, 2.0); w.sync()
+    buf = io.BytesIO(); np.savez(buf, **fb.checkpoint(sim)); buf.seek(0)
+    fb.step(sim, 3.0); w.sync()
+    x_ref, st_ref = w.x, w.status
+    w.close()
+    ck = dict(np.load(buf))
+    assert bool(ck["has_env"]) == rows_in_checkpoint and ("env" in ck) == rows_in_checkpoint
+    w2 = fb.BatchedWorld(n)
+    w2.env = random_env(fb, n, 12, h_trn=0.0)          # whatever the target world had before
+    sim2 = fb.Simulation(w2, dt=0.01, save_on=False, steps_per_launch=50)
+    fb.restore(sim2, ck)
+    assert w2.has_env == rows_in_checkpoint
+    if rows_in_checkpoint:
+        assert np.array_equal(w2.env, env6)
+    fb.step(sim2, 3.0); w2.sync()
+    assert np.array_equal(w2.x, x_ref) and np.array_equal(w2.status, st_ref)
+    # a checkpoint that says nothing about rows (older format) leaves the world's rows alone
+    old = {k: v for k, v in ck.items() if k not in ("has_env", "env")}
+    w2.env = env6
+    fb.restore(sim2, old)
+    assert w2.has_env and np.array_equal(w2.env, env6)
+    w2.close()

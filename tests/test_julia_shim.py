@@ -10,7 +10,7 @@ SHIM = os.path.join(ROOT, "flight.jl_amd", "julia", "FlightBatch.jl")
 
 # names every Julia session has (Base / Core exports the shim uses)
 BASE = {"Cint", "Cdouble", "Cstring", "Cvoid", "Ptr", "Ref", "Int", "Int32", "Int64", "UInt8", "UInt32", "Float32", "Float64", "Bool",
-        "Integer", "Real", "Symbol", "Vector", "Matrix", "Array", "Dict", "NTuple", "Any", "ENV", "C_NULL", "Base", "Union", "Nothing"}
+        "Integer", "Real", "Symbol", "Vector", "Matrix", "Array", "Dict", "NTuple", "Any", "ENV", "C_NULL", "Base", "Union", "Nothing", "DimensionMismatch"}
 
 
 def _code_only(src):
