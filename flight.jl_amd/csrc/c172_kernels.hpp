@@ -1417,7 +1417,11 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     __shared__ double xch_l[(XD_ROWS - 6) * B];
     __shared__ int flags_l[B];
     __shared__ int dst_l[B];           // role D's per-lane bookkeeping word
-    __shared__ double envd_l[PERENV ? 4 * B : 1];   // PERENV: role D's wind N / E / D and terrain elevation, [4][B] (written and read by role D alone)
+    // PERENV: role D's wind N / E / D and terrain elevation — in the WA instances from an LDS panel [4][B] of its own (written and read by role D
+    // alone); the ECEF / NED Cessna172Sv0 instances, whose seventeen stage sums fill the LDS, fetch the four rows from memory at every evaluation (L2-resident,
+    // requested at the head of the evaluation like the Sv0 instance's aerodynamic constants)
+    constexpr bool ENV_LDS = PERENV && (KIN == FB_KIN_WA || X);   // (the Cessna172Xv2 instances keep fourteen stage sums in LDS: 8 KB are free in every mechanisation)
+    __shared__ double envd_l[ENV_LDS ? 4 * B : 1];
     static_assert(LDS_RK_DOUBLES >= LDS_ATAN + ATAN_N + 2, "room for the control words behind the atan table");
     int* ctrl_l = (int*)&rk[LDS_ATAN + ATAN_N];   // one control word per wave pair (the LDS is full to the last 16 bytes)
     int* sync_l = ctrl_l + 4;                      // two synchronisation counters per wave pair: [pair] role P's, [4 + pair] role D's
@@ -1469,7 +1473,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     if constexpr (PERENV) {
         const Env e = (i < a.n) ? env_of(a, i) : a.env;
         if (role == 1) env_p = e;
-        else { envd_l[0 * B + t] = e.wind_n; envd_l[1 * B + t] = e.wind_e; envd_l[2 * B + t] = e.wind_d; envd_l[3 * B + t] = e.h_trn; }
+        else if constexpr (ENV_LDS) { envd_l[0 * B + t] = e.wind_n; envd_l[1 * B + t] = e.wind_e; envd_l[2 * B + t] = e.wind_d; envd_l[3 * B + t] = e.h_trn; }
     }
     // role D's per-lane bookkeeping word, kept in LDS between evaluations (role P reads it once, when the launch is over)
     enum { D_ALIVE = 1, D_HANDOFF = 4, D_STALL = 8, D_ACTIVE = 16, D_ENG_SHIFT = 5 };   // (no lane ends its simulation here: a status bit is a hand-over)
@@ -1834,9 +1838,17 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 (void)xv; (void)inl; (void)d0;
 #else
                 Env env_d = a.env;   // role D reads wind_n / wind_e / wind_d and h_trn
-                if constexpr (PERENV) {   // (from its LDS panel, at every evaluation: role D has no registers to carry them; lds_off keeps the reads in the loop)
+                if constexpr (ENV_LDS) {   // (from its LDS panel, at every evaluation: role D has no registers to carry them; lds_off keeps the reads in the loop)
                     lds_cptr ev = (lds_cptr)envd_l + t + lds_off;
                     env_d.wind_n = ev[0 * B]; env_d.wind_e = ev[1 * B]; env_d.wind_d = ev[2 * B]; env_d.h_trn = ev[3 * B];
+                } else if constexpr (PERENV) {   // (from memory: base and stride re-read from the kernel's arguments here, like the Xv2 instance's payload rows)
+                    const kargs_cptr ka = kernarg();
+                    int64_t il = i;
+                    asm volatile("" : "+v"(il));
+                    const double* e = ka->env_rows + il;
+                    const int64_t en = ka->n;
+                    env_d.wind_n = e[(int64_t)FB_ENV_WIND_N * en]; env_d.wind_e = e[(int64_t)FB_ENV_WIND_E * en]; env_d.wind_d = e[(int64_t)FB_ENV_WIND_D * en];
+                    env_d.h_trn = e[(int64_t)FB_ENV_H_TERRAIN * en];
                 }
                 bits = rhs_duo<KIN, 2>(xv, (d0 & D_STALL) ? 1 : 0, (d0 >> D_ENG_SHIFT) & 3, inl, env_d, T, emit, aux);
 #endif

@@ -180,8 +180,8 @@ static row_map_t row_map_of(fb_handle h) {
 static bool env_step_duo() { const char* e = getenv("FLIGHTBATCH_DUO"); return e ? atoi(e) != 0 : true; }
 // the two passes of the stepping kernel (airborne instance, then the ground-capable one over the lanes it handed over)
 #define FB_STEP_PERENV(KIN, X, GRID, A, K)                                                                                            \
-    do {   /* per-aircraft environment rows (KArgs::env_rows): the wave-pair kernel in the WA mechanisation, the one-wave kernel otherwise */ \
-        if (h->duo && KIN == FB_KIN_WA) hipLaunchKernelGGL((k_step_duo<FB_KIN_WA, X, true>), grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K); \
+    do {   /* per-aircraft environment rows (KArgs::env_rows): the wave-pair kernel in every mechanisation (FB_F32 handles: the one-wave fp64 kernel) */ \
+        if (h->duo) hipLaunchKernelGGL((k_step_duo<KIN, X, true>), grid_for(h->n, DUO_B), dim3(2 * DUO_B), 0, h->stream, A, K);         \
         else hipLaunchKernelGGL((k_step_air<KIN, X, false, true>), GRID, dim3(STEP_BLOCK), 0, h->stream, A, K);                      \
         hipLaunchKernelGGL((k_step_air<KIN, X, true, true>), grid_for(h->n, step_block<X, true>()), dim3(step_block<X, true>()), 0, h->stream, A, K); \
     } while (0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The headline batch (bench.lattice(0), 1 048 576 Cessna172Sv0, 50 steps per launch) with a per-aircraft environment (fb_set_env: every
 aircraft in its own wind, sea-level T / p and terrain elevation) against the batch-wide block; the Cessna172Xv2 share of configs[3] likewise.
-    python tools/bench_env.py            (FLIGHTBATCH_DUO=0: the one-wave kernels)"""
+    python tools/bench_env.py [WA|ECEF|NED]           (FLIGHTBATCH_DUO=0: the one-wave kernels)"""
 import ctypes as C
 import os
 import sys
@@ -36,10 +36,12 @@ def timed(w, sim, launches=10):
     return ms.value / max(nl.value, 1)
 
 
+KIN = sys.argv[1] if len(sys.argv) > 1 else "WA"
+print("mechanisation", KIN, "duo" if os.environ.get("FLIGHTBATCH_DUO", "1") != "0" else "one-wave kernels")
 for per_aircraft in (False, True):
     n = N_TOTAL
     EAS, h, psi, _ = lattice(0, n)
-    w = fb.BatchedWorld(n)
+    w = fb.BatchedWorld(n, kinematics=KIN)
     if per_aircraft:
         w.env = env_rows(n)
     fb.f_init(w, fb.TrimParameters(EAS=EAS, h_e=h + 200.0, ψ_nb=psi))
@@ -50,7 +52,7 @@ for per_aircraft in (False, True):
           f"{n * 50 / (ms * 1e-3):.4e} aircraft-steps/s (trim success {ok:.4f}, terminated {int((w.status != 0).sum())})", flush=True)
     w.close()
     n = N_TOTAL // 2
-    w = fb.Cessna172Xv2World(n)
+    w = fb.Cessna172Xv2World(n, kinematics=KIN)
     if per_aircraft:
         w.env = env_rows(n, 5)
     else:
