@@ -180,6 +180,47 @@ def test_trim_wide_envelope_and_hard_cases(fb, oracle):
     w.close()
 
 
+def test_nonlevel_trims_are_cross_checked_by_the_other_sides_cost(fb, oracle):
+    """The reference's stored trims (tests/test_reference_trim_points.py) pin the solver at 28 wings-level conditions; turning, climbing and
+    sideslipping trims (C172.TrimParameters ψ_wb_dot, θ_wb_dot, γ_wb_n, β_a: FA/c172/c172.jl:806-818) have no reference solution to be held to.
+    There the two sides check EACH OTHER: the trim found on the device, evaluated by the oracle's own cost function (c172.jl:857-867: the squared
+    residuals of v̇_b / |v|, ω̇_b, the engine's ω̇ / ω_rated), and the trim found by the oracle, evaluated by the device's f_ode! — both must be
+    solutions (<= 1e-15) in the OTHER side's model, on a grid of 432 non-level conditions (about four in five inside the envelope)."""
+    import ctypes as C
+    import itertools
+    K = fb.K
+    grid = list(itertools.product((38.0, 46.0, 54.0), (400.0, 2400.0), (-0.06, 0.0, 0.1), (0.0, 0.012), (-0.08, 0.0, 0.06), (-0.08, 0.0, 0.08), (0.0, 0.5)))
+    n = len(grid)
+    g = np.array(grid).T
+    tp = fb.TrimParameters(EAS=g[0], h_e=g[1], ψ_wb_dot=g[2], θ_wb_dot=g[3], γ_wb_n=g[4], β_a=g[5], flaps=g[6], ψ_nb=np.linspace(-3, 3, n))
+    w = fb.BatchedWorld(n)
+    fb.f_init(w, tp)
+    env = oracle.default_env()
+    ref = oracle.trim(tp.pack(n), fb.TrimState(n), env)
+    ok = w.trim_success
+    assert np.array_equal(ok, ref["ok"]) and ok.mean() > 0.7, (ok.mean(), (ok != ref["ok"]).sum())   # (the grid reaches beyond the envelope: both sides must agree on where)
+    assert (w.trim_cost[ok] <= 1e-16).all() and (ref["cost"][ok] <= 1e-16).all()
+    # (1) the device's solutions in the oracle's cost
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    tpp = tp.pack(n)
+    c_orc = np.array([oracle.lib.fo_c172_trim_cost(dp(np.ascontiguousarray(tpp[:, i])), dp(np.ascontiguousarray(w.trim_state[:, i])), dp(env)) for i in range(n)])
+    # (2) the oracle's solutions in the device's model: its trimmed state, inputs and discrete states handed to fb_f_ode
+    def device_cost(x, s, u, ui):
+        w.set_state(x, s); w.u = u; w.ui = ui
+        xd = np.zeros((K["FB_NX"], n)); fb.f_ode(w, xd)
+        vd, wd, ed = xd[K["FB_X_V_EB_B"]:K["FB_X_V_EB_B"] + 3], xd[K["FB_X_OMEGA_EB_B"]:K["FB_X_OMEGA_EB_B"] + 3], xd[K["FB_X_ENG_OMEGA"]]
+        nv = np.sqrt((x[K["FB_X_V_EB_B"]:K["FB_X_V_EB_B"] + 3] ** 2).sum(0))
+        return ((vd / nv) ** 2).sum(0) + (wd ** 2).sum(0) + (ed / (2700 * np.pi / 30)) ** 2     # ω_rated: 2700 rpm (FP/piston.jl:203)
+    x_dev, s_dev, u_dev, ui_dev = w.x, w.s, w.u, w.ui
+    c_self = device_cost(x_dev, s_dev, u_dev, ui_dev)
+    c_dev = device_cost(ref["x"], ref["s"], ref["u"], ref["ui"])
+    print("non-level trims (%d of %d trimmable): device solution in the oracle's cost <= %.2e; oracle solution in the device's model <= %.2e; device in its own <= %.2e; "
+          "max |Δ trim state| %.2e" % (ok.sum(), n, c_orc[ok].max(), c_dev[ok].max(), c_self[ok].max(), np.abs(w.trim_state - ref["ts"])[:, ok].max()))
+    assert c_orc[ok].max() <= 1e-15 and c_dev[ok].max() <= 1e-15 and c_self[ok].max() <= 1e-15
+    assert np.abs(w.trim_state - ref["ts"])[:, ok].max() < 1e-7
+    w.close()
+
+
 def test_f_ode_matches_oracle(fb, oracle):
     """Single RHS: xdot and the full 174-double output record at trimmed and perturbed states."""
     n = 4096
