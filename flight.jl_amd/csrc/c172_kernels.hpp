@@ -660,7 +660,11 @@ restart:
     if constexpr (X) {
         // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass, or stepped
         // a second time up to the evaluation that threw, must find them as they were at launch start
-        if (a.ctl_ratio > 0 && mine) {
+        // (a launch of ONE step needs neither the copy nor the way back: its only control update is the last thing it does — behind the step's last
+        // evaluation and f_step!, with no re-evaluation of k1 behind it in this launch — so a lane that is handed over, or that throws, has not had
+        // one. At one step per launch, the shape of every host callback and of a scenario table evaluated after every step, the two copies were
+        // 1.5 KB per aircraft and launch, as much again as the state and the record the step itself moves.)
+        if (a.ctl_ratio > 0 && nsteps > 1 && mine) {
             if (!replaying) {
                 copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
                 copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
@@ -923,7 +927,7 @@ restart:
     }
     if (!GROUND && handoff) {
         if constexpr (X) {
-            if (a.ctl_ratio > 0) {   // nothing of this lane's launch is committed: undo the control-law updates it has made
+            if (a.ctl_ratio > 0 && nsteps > 1) {   // nothing of this lane's launch is committed: undo the control-law updates it has made (one step: it has made none)
 #pragma unroll 1
                 for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
 #pragma unroll 1
@@ -1529,7 +1533,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
                 in.mixture = clampd(a.u[(int64_t)FB_U_MIXTURE * a.n + i], 0, 1);
                 in.ui = a.ui[i];
-                if (a.ctl_ratio > 0) {   // its half of the launch-start copy of the control-law record (role D copies cu)
+                if (a.ctl_ratio > 0 && nsteps > 1) {   // its half of the launch-start copy of the control-law record (role D copies cu); not for a launch of one step: see k_step_air
                     static_assert(FB_NCS % 11 == 0 && FB_NCU % 14 == 0, "batch sizes of the record copies");
                     copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
                 }
@@ -1761,7 +1765,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 }
                 in.ui = in0.ui;
                 if (a.k1) a.k1_valid[i] = 0;   // (nothing is carried across launches here; the ground-capable pass evaluates its own k1)
-                if (a.ctl_ratio > 0 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
+                if (a.ctl_ratio > 0 && nsteps > 1 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
                     copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
                 }
             } else {
@@ -1954,7 +1958,7 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
     if (!(d & D_ACTIVE)) return;
     if (d & D_HANDOFF) {
         if constexpr (X) {
-            if (a.ctl_ratio > 0) {   // nothing of this lane's launch is committed: undo the control-law updates it has made (both halves are at rest: point F)
+            if (a.ctl_ratio > 0 && nsteps > 1) {   // nothing of this lane's launch is committed: undo the control-law updates it has made (both halves are at rest: point F)
 #pragma unroll 1
                 for (int k = 0; k < FB_NCS; k++) a.cs[(int64_t)k * a.n + i] = a.ctl_bak[(int64_t)k * a.n + i];
 #pragma unroll 1
