@@ -43,8 +43,8 @@ BYTES_PER_AIRCRAFT_STEP_F32 = 264.0   # the fp32 stepper: 2 * (27 * 4 B + 5 rows
 BYTES_PER_X2_STEP = 756.0         # Cessna172Xv2
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6      # MI355X vector fp64 peak (spec): 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_COUNTERS = "r05_counters.json"
-PROFILE_COUNTERS_X2 = "r05_x2_counters.json"   # the same for the Cessna172Xv2 airborne stepper (tools/collect_profile_x2.sh)   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
+PROFILE_COUNTERS = "r06_counters.json"
+PROFILE_COUNTERS_X2 = "r06_x2_counters.json"   # the same for the Cessna172Xv2 airborne stepper (tools/collect_profile_x2.sh)   # rocprofv3 PMC summary of the CURRENT airborne stepper (tools/collect_profile.sh)
 
 
 def lattice(seed_offset: int = 0, n: int = N_TOTAL):

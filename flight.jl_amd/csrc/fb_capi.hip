@@ -611,6 +611,11 @@ int32_t fb_set_env(fb_handle h, const double* env) {
         rows[(size_t)fbd::ENV_DEV_LN_P * n + i] = lnp;
         rows[(size_t)fbd::ENV_DEV_K_RT * n + i] = exp(0.5 * 6.5e-3 * 287.05287 / 9.80665 * lnp) / sqrt(T);
     }
+    if (!h->env_rows && h->dtype == FB_F32) {   // (say so once — the fp32 stepper reads the batch-wide block only)
+        static bool said = false;
+        if (!said) { said = true; std::fprintf(stderr, "flightbatch: per-aircraft environment rows on an FB_F32 handle: the fp32 stepper has no instance that reads them, "
+                                                       "this handle is stepped by the fp64 one-wave kernel k_step_air<WA, false, *, true> from now on\n"); }
+    }
     if (!h->env_rows) HIPCHK(hipMalloc(&h->env_rows, sizeof(double) * fbd::ENV_DEV_ROWS * n));
     HIPCHK(hipMemcpyAsync(h->env_rows, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -254,6 +254,31 @@ function step!(sim::BatchedSimulation, Δt_total::Real = sim.dt, stop_at_tdt::Bo
 end
 Base.getproperty(sim::BatchedSimulation, s::Symbol) = s === :t ? getfield(sim, :nstep) * getfield(sim, :dt) : getfield(sim, s)
 
+# ---- scripted scenarios: `user_callback!` as a table on the device (include/flightbatch.h, FB_TABLE_SCENARIO) ------------------------
+# Simulation(mdl; user_callback!) calls a closure after every step (FC/sim.jl:185, 334-336); for a batch the closures of the demos
+# (FlightApps/demos/c172_demos.jl:423-486, 525-642: a phase symbol, per phase "set these inputs; if <condition> set those, next phase") are
+# a table of phases, rules and actions that a kernel interprets between the stepping launches. `blob` is the packed table (the layout is in
+# the header; flightbatch/scenario.py builds it on the Python side), `par` the per-aircraft parameter rows [N x n_par].
+const TABLE_SCENARIO = Cint(6)
+function set_scenario!(w::BatchedWorld, blob::Vector{Float64}, par::Union{Matrix{Float64}, Nothing} = nothing; every::Integer = 1)
+    len = Ref{Int64}(length(blob))
+    check(ccall((:fb_set_table, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Int64}, Cint), w.handle, TABLE_SCENARIO, blob, len, 1))
+    check(ccall((:fb_scenario_configure, lib), Cint, (Ptr{Cvoid}, Cint), w.handle, every))
+    n_par = round(Int, blob[5])
+    if n_par > 0
+        par !== nothing && size(par) == (w.n, n_par) || throw(DimensionMismatch("set_scenario!: par must be $(w.n) x $(n_par)"))
+        check(ccall((:fb_scenario_set_params, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), w.handle, par))
+    end
+    nothing
+end
+clear_scenario!(w::BatchedWorld) = (check(ccall((:fb_scenario_configure, lib), Cint, (Ptr{Cvoid}, Cint), w.handle, 0)); nothing)
+"every aircraft's phase, the step at which it entered it, and its record rows [N x n_rec]"
+function scenario_state(w::BatchedWorld, n_rec::Integer)
+    phase = Vector{Int32}(undef, w.n); since = Vector{Int64}(undef, w.n); rec = Matrix{Float64}(undef, w.n, max(n_rec, 1))
+    check(ccall((:fb_scenario_get_state, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int64}, Ptr{Cdouble}), w.handle, phase, since, rec))
+    return phase, since, rec[:, 1:n_rec]
+end
+
 # ---- multi-GPU trajectory collection: one process per GPU, one RCCL all-gather of the state panels (include/flightbatch.h) -------
 "rank 0: `id = comm_unique_id()`, hand the 128 bytes to the other ranks (file, MPI, sockets); every rank: `comm_init(world_handle, nranks, rank, id)`"
 comm_unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:fb_comm_unique_id, lib), Cint, (Ptr{UInt8},), id)); id)

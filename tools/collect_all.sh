@@ -28,4 +28,4 @@ python3 tools/bench_x2_divergence.py > $OUT/${TAG}_x2_divergence.txt 2>&1
 X2_RATIO=50 python3 tools/bench_x2_divergence.py identical trim both >> $OUT/${TAG}_x2_divergence.txt 2>&1
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_x2_lattice -- python3 $ROOT/tools/bench_x2_divergence.py both > $OUT/x2_lattice_under_rocprof.txt 2> $OUT/stats_x2_lattice.log)
 cp $OUT/stats_x2_lattice/*/*_kernel_stats.csv $OUT/${TAG}_x2_lattice_kernel_stats.csv; echo "x2 divergence done"
-bash tools/collect_tail.sh $TAG
+[ -n "$SKIP_TAIL" ] || bash tools/collect_tail.sh $TAG
