@@ -574,16 +574,18 @@ struct AirEmit {
     }
 };
 // Lanes per workgroup, and where the stage sum lives. The airborne instances: 256 lanes, three 21-row panels (151 KB). The
-// ground-capable instances need all 27 rows. Cessna172Sv0: 256 lanes, two 27-row panels + the stage sum in 54 registers (450-458
-// registers, no scratch). Cessna172Xv2 (whose control-law call pushes it to 512 registers + scratch): three 27-row panels fit the LDS
-// for 192 lanes (147 KB), three waves per workgroup.
+// ground-capable instances need all 27 rows: 256 lanes, two 27-row panels + the stage sum in 54 registers — Cessna172Sv0 450-458
+// registers, no scratch; Cessna172Xv2 512 registers + ~1 KB of scratch.
 // History: at full register pressure this LLVM places spill code before the exec restore of control-flow join blocks in some
-// instances (tools/check_isa_spills.py, which the build enforces): lanes then reload garbage and results change from run to run
+// instances (tools/check_mir_spills.py, which the build enforces): lanes then reload garbage and results change from run to run
 // (seen in the scripted crosswind landing, tools/det_check.py). With machine LICM on (the fp64 literal pairs hoisted out of the loop,
 // see __graft_entry__.py) the 256-lane form tripped that check and every ground instance ran 192 lanes (7.9e8 aircraft-steps/s on a
-// batch sitting on the ground); without it the Sv0 instances have registers to spare and no spill code at all.
+// batch sitting on the ground); without it the Sv0 instances have registers to spare and no spill code at all. The Cessna172Xv2 instances
+// stayed at 192 lanes (three panels in LDS: three one-wave SIMDs of four) with the gear units' ground contact behind calls until round 6:
+// inlined (FB_X2_GROUND_CALLS = 0) and at 256 lanes they pass the check, and a batch on the ground steps 2.9 x as fast
+// (4.31e8 -> 8.95e8 -> 1.24e9 aircraft-steps/s, profiles/r06_ab_x2_ground_inline.txt).
 #ifndef FB_GROUND_BLOCK_X
-#define FB_GROUND_BLOCK_X 192
+#define FB_GROUND_BLOCK_X 256
 #endif
 #ifndef FB_GROUND_BLOCK_S
 #define FB_GROUND_BLOCK_S 256
