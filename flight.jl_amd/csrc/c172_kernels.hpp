@@ -734,7 +734,8 @@ restart:
         const lds_cptr xrd_l = stage == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
         const lds_ptr xwr_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
-        [[maybe_unused]] CtlSink tap;
+        [[maybe_unused]] CtlSinkOpt tap;
+        tap.on = false;
         [[maybe_unused]] const bool tap_now = X && a.ctl_ratio > 0 && stage == 0 && pending_cb && !redoing && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
         // which evaluation of the reference's schedule this is (wave-uniform): the one at the new state of an RK update that has just
         // been made — `step` counts the callbacks that have run, so one update more is complete — a re-evaluation at the accepted state, or
@@ -776,9 +777,9 @@ restart:
             const SV xv = {xrd_l + t + lds_off};
             if constexpr (X) {
                 // the evaluation at x_{n+1} of a step that closes a control period is the "last f_ode!" whose outputs the control
-                // laws read: it runs with the partial sink (a second instance of rhs() in the loop, taken once per period)
-                if (tap_now) bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, tap);
-                else bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
+                // laws read: the partial sink is switched on for it (ONE instance of rhs() in the loop: CtlSinkOpt)
+                tap.on = tap_now;
+                bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, tap);
             } else
                 bits = rhs<KIN, GROUND, FB_AIR_SCALAR_KNOTS>(xv, stall, eng, inl, env, T, emit, aux, NoSink{});
             if constexpr (!GROUND) {

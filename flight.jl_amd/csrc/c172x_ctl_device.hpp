@@ -173,6 +173,15 @@ struct CtlSink {
     }
 };
 
+// The same sink with a run-time switch (wave-uniform): the one-wave stepping kernels evaluate every f_ode! through ONE instance of rhs() and switch the tap
+// on for the step's last evaluation. Up to round 5 that evaluation ran a SECOND inlined instance of rhs() (partial sink) next to the plain one: the
+// ground-capable Cessna172Xv2 kernel was ~90 KB of code, more than the 64 KB instruction cache two CUs share — every workgroup of a short launch fetched
+// it from L2 again (~70 us per workgroup), and the stepping loop thrashed it (profiles/r06_ab_x2_ground_inline.txt, second part).
+struct CtlSinkOpt : CtlSink {
+    typedef void dynamic_tag;
+    bool on;
+};
+
 FBD double sgnd(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
 FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
 constexpr double CTL_INF = __builtin_huge_val();
