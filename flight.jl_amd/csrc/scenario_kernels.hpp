@@ -101,9 +101,11 @@ __global__ __launch_bounds__(256) void k_scenario(KArgs a, ScnArgs sc) {
         if (ac[2] != 0) v = wrap_to_pi(v);
         const int dst = (int)ac[0], row = (int)ac[1];
         if (dst == FB_SCN_DST_CU) cu[(int64_t)row * n + i] = v;
-        else if (dst == FB_SCN_DST_U) { uu[(int64_t)row * n + i] = v; inputs_changed = true; }
+        // (an `always` action that assigns what is there already — brakes held, throttle closed, every evaluation of the ground phase — changes nothing:
+        // the derivative the steppers carry from launch to launch stays valid)
+        else if (dst == FB_SCN_DST_U) { double& r = uu[(int64_t)row * n + i]; if (!(r == v)) { r = v; inputs_changed = true; } }
         else if (dst == FB_SCN_DST_REC) sc.rec[(int64_t)row * n + i] = v;
-        else if (dst == FB_SCN_DST_UI) { const int w = uiw[i]; uiw[i] = v != 0 ? (w | row) : (w & ~row); inputs_changed = true; }
+        else if (dst == FB_SCN_DST_UI) { const int w = uiw[i], w1 = v != 0 ? (w | row) : (w & ~row); if (w1 != w) { uiw[i] = w1; inputs_changed = true; } }
     };
     auto acts_need_y = [&](int first, int count) {
         bool need = false;
