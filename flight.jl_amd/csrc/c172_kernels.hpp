@@ -734,8 +734,12 @@ restart:
         const lds_cptr xrd_l = stage == 0 ? (lds_cptr)xs_l : (lds_cptr)xc_l;
         const lds_ptr xwr_l = last ? (lds_ptr)xs_l : (lds_ptr)xc_l;
         int32_t bits = 0;
-        [[maybe_unused]] CtlSinkOpt tap;
+        // (the tap's twelve values: in an LDS panel where the LDS has room — the ground-capable instances at 256 lanes —, in registers otherwise)
+        constexpr bool TAP_LDS = X && GROUND && B == 256;
+        __shared__ double tap_l[TAP_LDS ? 12 * B : 1];
+        [[maybe_unused]] typename std::conditional<TAP_LDS, CtlSinkLds<B>, CtlSinkOpt>::type tap;
         tap.on = false;
+        if constexpr (TAP_LDS) tap.base = (lds_ptr)tap_l + t;
         [[maybe_unused]] const bool tap_now = X && a.ctl_ratio > 0 && stage == 0 && pending_cb && !redoing && (a.ctl_phase + step + 1) % a.ctl_ratio == 0;   // wave-uniform
         // which evaluation of the reference's schedule this is (wave-uniform): the one at the new state of an RK update that has just
         // been made — `step` counts the callbacks that have run, so one update more is complete — a re-evaluation at the accepted state, or
@@ -822,10 +826,13 @@ restart:
                 if constexpr (X) {
                     if (ctl_now && !aux.crash) {
                         CtlIn v;
-                        v.lat = tap.lat; v.lon = tap.lon;
-                        v.EAS = tap.EAS; v.theta = tap.theta; v.phi = tap.phi; v.clm = -tap.vd; v.chi = tap.chi;
-                        v.w_wb_b = {tap.wx, tap.wy, tap.wz};
-                        v.alpha = tap.alpha; v.beta = tap.beta;
+                        {
+                            const CtlSink tv = tap_values(tap);
+                            v.lat = tv.lat; v.lon = tv.lon;
+                            v.EAS = tv.EAS; v.theta = tv.theta; v.phi = tv.phi; v.clm = -tv.vd; v.chi = tv.chi;
+                            v.w_wb_b = {tv.wx, tv.wy, tv.wz};
+                            v.alpha = tv.alpha; v.beta = tv.beta;
+                        }
                         auto XS = [&](int k) { return xs_l[SV::row(k) * B + t]; };   // x_{n+1}, before f_step! touches it
                         v.h_e = XS(h_e_row<KIN>());
                         v.w_eb_b = {XS(FB_X_OMEGA_EB_B), XS(FB_X_OMEGA_EB_B + 1), XS(FB_X_OMEGA_EB_B + 2)};

@@ -182,6 +182,31 @@ struct CtlSinkOpt : CtlSink {
     bool on;
 };
 
+// ... and with its twelve values in an LDS panel [12][B] instead of twelve doubles that are live — and, at 512 registers, spilled — across every evaluation of
+// a launch (the ground-capable Cessna172Xv2 kernels: at 256 lanes their LDS has 27 KB to spare; k_step_air)
+template <int B>
+struct CtlSinkLds {
+    static constexpr bool enabled = true, full = false;
+    typedef void dynamic_tag;
+    bool on;
+    __attribute__((address_space(3))) double* base;   // &panel[lane]
+    FBD void put(int k, double v) const {
+        int r = -1;
+        if (k == FB_Y_KIN + 1) r = 0; else if (k == FB_Y_KIN + 2) r = 1; else if (k == FB_Y_KIN + 15) r = 2; else if (k == FB_Y_KIN + 16) r = 3;
+        else if (k == FB_Y_KIN + 25) r = 4; else if (k == FB_Y_KIN + 26) r = 5; else if (k == FB_Y_KIN + 27) r = 6; else if (k == FB_Y_KIN + 36) r = 7;
+        else if (k == FB_Y_KIN + 38) r = 8; else if (k == FB_Y_AIR + 20) r = 9; else if (k == FB_Y_AERO) r = 10; else if (k == FB_Y_AERO + 1) r = 11;
+        if (r >= 0) base[r * B] = v;
+    }
+    FBD CtlSink values() const {
+        CtlSink t;
+        t.theta = base[0 * B]; t.phi = base[1 * B]; t.lat = base[2 * B]; t.lon = base[3 * B]; t.wx = base[4 * B]; t.wy = base[5 * B]; t.wz = base[6 * B];
+        t.vd = base[7 * B]; t.chi = base[8 * B]; t.EAS = base[9 * B]; t.alpha = base[10 * B]; t.beta = base[11 * B];
+        return t;
+    }
+};
+FBD CtlSink tap_values(const CtlSinkOpt& t) { return t; }
+template <int B> FBD CtlSink tap_values(const CtlSinkLds<B>& t) { return t.values(); }
+
 FBD double sgnd(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
 FBD double wrap_to_pi(double x) { return x + 2 * PI * floor((PI - x) / (2 * PI)); }   // FP/attitude.jl:478
 constexpr double CTL_INF = __builtin_huge_val();
