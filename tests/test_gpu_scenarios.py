@@ -238,3 +238,40 @@ def test_crosswind_landing_scenario_against_the_oracles_phase_machine(fb, oracle
     d = np.abs(gpu["touchdown"] - st["rec"])
     print("touchdown against the oracle's phase machine: time %.3f s, along track %.3f m, cross track %.4f m" % (d[0].max(), d[1].max(), d[2].max()))
     assert d[0].max() <= 2 * dt + 1e-9 and d[1].max() < 1.5 and d[2].max() < 0.05
+
+
+def test_elevator_doublet_device_table_equals_host_callback_and_the_oracle(fb, oracle):
+    """c172_demos.jl:286-316: `elevator_offset` = +a for 5 <= t < 7, -a for 7 <= t < 9, else 0, from a user callback — as a host callback, as a table on the
+    device (bitwise the same run), and on the oracle stepped one step at a time with the closure applied to ITS inputs (1e-6 after 20 s: the doublet excites
+    the short-period and phugoid modes of 64 aircraft at different speeds and altitudes)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import elevator_doublet as demo
+    from oracle_binding import OracleX
+    from test_gpu_c172x import ref_to_dev_rows, x_scale
+    K = fb.K
+    a = demo.run(n=64, seed=4)
+    b = demo.run(n=64, seed=4, mode="device")
+    assert (b["phase"] == 3).all() and _same(a["x"], b["x"]) and _same(a["cs"], b["cs"]) and _same(a["cu"], b["cu"]) and (a["status"] == 0).all()
+    # the oracle: same trims (the GPU's initial condition is reproduced by running the example's set-up again), the closure on its inputs
+    n, dt = 64, 0.02
+    rng = np.random.default_rng(4)
+    w = fb.Cessna172Xv2World(n)
+    sim = fb.Simulation(w, dt=dt, Δt=dt, save_on=False, steps_per_launch=50)
+    fb.init(sim, fb.TrimParameters(EAS=rng.uniform(40.0, 52.0, n), h_e=rng.uniform(500.0, 2500.0, n)))
+    amp = rng.uniform(0.05, 0.1, n)
+    assert np.array_equal(amp, a["amp"])
+    perm = ref_to_dev_rows(K)
+    X = OracleX(oracle, fb.ctl_gains.ctl_gains_blob())
+    env = oracle.default_env()
+    o = dict(x=np.zeros((34, n)), u=w.u, ui=w.ui, s=w.s, cu=w.cu, cs=w.cs, status=np.zeros(n, np.int32), nstep=0)
+    o["x"][perm] = w.x
+    w.close()
+    for k in range(1, 1001):
+        X.step(o, env, dt, 1, 1, threads=16)
+        t = k * dt
+        o["cu"][K["FB_CU_ELEVATOR_OFFSET"]] = amp if 5 <= t < 7 else (-amp if 7 <= t < 9 else 0.0)
+    err = np.abs(b["x"] - o["x"][perm]) / x_scale(o["x"])[perm]
+    print("elevator doublet, 64 aircraft x 1000 steps, device table against the oracle with the closure: max scaled error %.2e" % err.max())
+    assert err.max() < 1e-6 and (o["status"] == 0).all()
+    dq = np.abs(b["x"][K["FB_X2_KIN"] + 8] - a["x"][K["FB_X2_KIN"] + 8]).max()
+    assert dq == 0.0
