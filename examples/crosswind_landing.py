@@ -153,13 +153,14 @@ def run(n=64, t_end=150.0, dt=0.02, seed=0, verbose=False, hold_decrab=False, ki
 if __name__ == "__main__":
     n_ = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     mode_ = "device" if "device" in sys.argv[2:] else "callback"
+    every_ = next((int(a_.split("=")[1]) for a_ in sys.argv[2:] if a_.startswith("every=")), 1)   # scenario period in steps (device mode)
     if len(sys.argv) > 2 and sys.argv[2] == "disperse":   # touchdown dispersion over a crosswind distribution: 0 ... 9 m/s from the east
         import time
         cw_ = np.random.default_rng(1).uniform(0.0, 9.0, n_)
         t0_ = time.perf_counter()
-        o_ = run(n_, verbose=True, crosswind=cw_, hold_decrab=True, mode=mode_)
+        o_ = run(n_, verbose=True, crosswind=cw_, hold_decrab=True, mode=mode_, every=every_)
         el_ = time.perf_counter() - t0_
-        print(f"{mode_}: {n_} aircraft x 7500 steps in {el_:.1f} s (trim and set-up included): {n_ * 7500 / el_:.3e} aircraft-steps/s")
+        print(f"{mode_} (scenario evaluated every {every_} step(s)): {n_} aircraft x 7500 steps in {el_:.1f} s (trim and set-up included): {n_ * 7500 / el_:.3e} aircraft-steps/s")
         td_ = o_["touchdown"]
         for lo_ in range(0, 9, 3):
             m_ = (cw_ >= lo_) & (cw_ < lo_ + 3) & np.isfinite(td_[0])
@@ -167,4 +168,4 @@ if __name__ == "__main__":
                 print(f"crosswind {lo_}-{lo_ + 3} m/s: {int(m_.sum())} aircraft, touchdown {td_[1][m_].mean():.0f} ± {td_[1][m_].std():.0f} m past the threshold, "
                       f"cross-track {td_[2][m_].mean():+.2f} ± {td_[2][m_].std():.2f} m")
     else:
-        run(n_, verbose=True, hold_decrab="hold" in sys.argv[2:], mode=mode_)
+        run(n_, verbose=True, hold_decrab="hold" in sys.argv[2:], mode=mode_, every=every_)
