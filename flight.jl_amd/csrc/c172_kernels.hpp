@@ -297,18 +297,41 @@ FBD void load_inputs(const KArgs& a, int64_t i, Inputs& in) {
 }
 // Cessna172X: the seven actuator commands in force — the four control-law outputs (assign!, c172x_ctl.jl:449-458, 986-995)
 // and the flaps / brake commands of u — saturated to the actuators' Ranged input types (c172x.jl:113-119)
-FBD double x2_command(const KArgs& a, int64_t i, int k) {
+// An actuator's position at an RK4 stage, from its closed form between control updates (x_n, the command c, z = dt / tau): the stage's argument is
+// c + (x_n - c) ms with ms = 1, 1 - z/2, 1 - z/2 + z^2/4, 1 - z + z^2/2 - z^3/4. Written from the other end — x_n + (c - x_n) (1 - ms) — the step's
+// FIRST stage is the state itself, bit for bit (1 - ms = 0), as in the reference, whose RK4 evaluates k1 at x_n; c + (x_n - c) rounds differently for
+// another c, and then the derivative at x_{n+1} that one launch carries over to the next (k_step_air<X>'s k1, evaluated ahead of the control update with
+// the OLD commands) and the one a launch evaluates for itself (behind it, with the NEW ones) are not the same numbers: a run cut into launches
+// differently — a host callback after every step against a scenario table on the device — differed in the last place
+// (tests/test_gpu_scenarios.py compares the two bit for bit). FB_ACT_STAGE_FORM: 2 this form; 1 the old one with the first stage selected
+// (+0.9 % on the Cessna172Xv2 launch, profiles/r06_ab_stage0.txt); 0 the old one (rounds 3-5).
+#ifndef FB_ACT_STAGE_FORM
+#define FB_ACT_STAGE_FORM 2
+#endif
+FBD double act_stage_mc(int stage, double z) {   // 1 - ms (form 2), ms (forms 0, 1)
+    if constexpr (FB_ACT_STAGE_FORM == 2) return stage == 0 ? 0.0 : (stage == 1 ? z / 2 : (stage == 2 ? z / 2 - z * z / 4 : z - z * z / 2 + z * z * z / 4));
+    else return stage == 0 ? 1.0 : (stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+}
+FBD double act_stage_pos(double x_n, double c, double mc, [[maybe_unused]] bool first_stage) {
+    if constexpr (FB_ACT_STAGE_FORM == 2) return __builtin_fma(c - x_n, mc, x_n);
+    else if constexpr (FB_ACT_STAGE_FORM == 1) return first_stage ? x_n : c + (x_n - c) * mc;
+    else return c + (x_n - c) * mc;
+}
+// (in two parts — the row as it stands in memory, and its saturation — for callers that want all seven loads in flight before the first clamp)
+FBD double x2_command_row(const KArgs& a, int64_t i, int k) {
     const int64_t n = a.n;
     switch (k) {
-        case FB_ACT_THROTTLE: return clampd(a.cs[(int64_t)FB_CS_THROTTLE_CMD * n + i], 0, 1);
-        case FB_ACT_AILERON: return clampd(a.cs[(int64_t)FB_CS_AILERON_CMD * n + i], -1, 1);
-        case FB_ACT_ELEVATOR: return clampd(a.cs[(int64_t)FB_CS_ELEVATOR_CMD * n + i], -1, 1);
-        case FB_ACT_RUDDER: return clampd(a.cs[(int64_t)FB_CS_RUDDER_CMD * n + i], -1, 1);
-        case FB_ACT_FLAPS: return clampd(a.u[(int64_t)FB_U_FLAPS * n + i], 0, 1);
-        case FB_ACT_BRAKE_LEFT: return clampd(a.u[(int64_t)FB_U_BRAKE_LEFT * n + i], 0, 1);
-        default: return clampd(a.u[(int64_t)FB_U_BRAKE_RIGHT * n + i], 0, 1);
+        case FB_ACT_THROTTLE: return a.cs[(int64_t)FB_CS_THROTTLE_CMD * n + i];
+        case FB_ACT_AILERON: return a.cs[(int64_t)FB_CS_AILERON_CMD * n + i];
+        case FB_ACT_ELEVATOR: return a.cs[(int64_t)FB_CS_ELEVATOR_CMD * n + i];
+        case FB_ACT_RUDDER: return a.cs[(int64_t)FB_CS_RUDDER_CMD * n + i];
+        case FB_ACT_FLAPS: return a.u[(int64_t)FB_U_FLAPS * n + i];
+        case FB_ACT_BRAKE_LEFT: return a.u[(int64_t)FB_U_BRAKE_LEFT * n + i];
+        default: return a.u[(int64_t)FB_U_BRAKE_RIGHT * n + i];
     }
 }
+FBD double x2_command_sat(int k, double v) { return clampd(v, (k == FB_ACT_AILERON || k == FB_ACT_ELEVATOR || k == FB_ACT_RUDDER) ? -1.0 : 0.0, 1.0); }
+FBD double x2_command(const KArgs& a, int64_t i, int k) { return x2_command_sat(k, x2_command_row(a, i, k)); }
 // dst[k n + i] = src[k n + i], k < ROWS, G rows at a time: G loads in flight, then G stores. (Row by row — a load, a wait, a store, the next
 // load behind the store it may alias — the launch-start copy of the control-law record was 94 dependent memory round trips per workgroup.)
 template <int ROWS, int G>
@@ -595,6 +618,13 @@ template <bool X, bool GROUND> constexpr bool step_acc_in_regs() { return GROUND
 #ifndef FB_STEP_ATTR
 #define FB_STEP_ATTR
 #endif
+// diagnostic builds (-DFB_STAMP, tools/stamp_ground_launch.py): where a launch of the ground-capable Cessna172Xv2 pass spends its cycles outside the
+// evaluations — slots 13 entry, 14 tables staged, 15 x_n in LDS, 30 loop entered (inputs, commands, the carried k1), 31 state written back
+#ifdef FB_STAMP
+#define FB_LAUNCH_STAMP(k) do { if constexpr (X && GROUND) fb_stamp(k); } while (0)
+#else
+#define FB_LAUNCH_STAMP(k) do { } while (0)
+#endif
 template <int KIN, bool X = false, bool GROUND = false, bool PERENV = false>
 __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step_air(KArgs a, int nsteps) {
     constexpr int B = step_block<X, GROUND>(), NR = GROUND ? (int)FB_NX : FB_NX - 6;
@@ -610,7 +640,9 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
     if constexpr (GROUND) {   // second pass: only the lanes the airborne pass handed over
         const int mine = (i < a.n) && a.redo[i] != 0;
         if (!__syncthreads_or(mine)) return;
+        FB_LAUNCH_STAMP(13);
         stage_tables<PR_NC_STEP>(lds, rk, a.tables);
+        FB_LAUNCH_STAMP(14);
         if (!mine) return;
         a.redo[i] = 0;
     } else {
@@ -649,16 +681,33 @@ __global__ __launch_bounds__((step_block<X, GROUND>())) FB_STEP_ATTR void k_step
 #define FB_REPLAY_MINE mine
 #endif
 restart:
+    // The lane's index, opaque to the optimiser from here to the loop: the ~100 row addresses of this block (state, carried k1, record copies, commands)
+    // are invariant in the replay loop that `restart` heads, and hoisted in front of it they were all live across it — 83 of them spilled in the
+    // ground-capable Cessna172Xv2 instance and reloaded one by one, each row's load waiting for its address: load, wait, store, 27 + 27 times
+    // (tools/stamp_ground_launch.py: 36 k + 27 k cycles of a one-step launch's 286 k).
+    int64_t il = i;
+    asm volatile("" : "+v"(il));
     if (mine) {
         bool to_ground = false;
+        // nine rows in flight at a time (left to itself the scheduler pairs them: load, load, wait, store — thirteen round trips to memory in a row)
+        static_assert(FB_NX % 9 == 0, "row batches");
 #pragma unroll
-        for (int k = 0; k < FB_NX; k++) {
-            const double v = a.x[(int64_t)k * a.n + i];
-            if (SV::skip(k)) to_ground = to_ground || (v != 0.0);
-            else { xs_l[SV::row(k) * B + t] = v; acc.set(SV::row(k), 0.0); }
+        for (int k0 = 0; k0 < FB_NX; k0 += 9) {
+            double v[9];
+#pragma unroll
+            for (int g = 0; g < 9; g++) v[g] = a.x[(int64_t)(k0 + g) * a.n + il];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 9; g++) {
+                const int k = k0 + g;
+                if (SV::skip(k)) to_ground = to_ground || (v[g] != 0.0);
+                else { xs_l[SV::row(k) * B + t] = v[g]; acc.set(SV::row(k), 0.0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (to_ground) { a.redo[i] = 1; return; }   // (airborne instance only: the ground-capable one skips no row)
+        if (to_ground) { a.redo[il] = 1; return; }   // (airborne instance only: the ground-capable one skips no row)
     }
+    FB_LAUNCH_STAMP(15);
     if constexpr (X) {
         // the control laws run inside this launch and rewrite cs / cu; a lane that is later handed to the ground-capable pass, or stepped
         // a second time up to the evaluation that threw, must find them as they were at launch start
@@ -668,11 +717,11 @@ restart:
         // 1.5 KB per aircraft and launch, as much again as the state and the record the step itself moves.)
         if (a.ctl_ratio > 0 && nsteps > 1 && mine) {
             if (!replaying) {
-                copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
-                copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
+                copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, il);
+                copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, il);
             } else {
-                copy_rows_batched<FB_NCS, 11>(a.cs, a.ctl_bak, a.n, i);
-                copy_rows_batched<FB_NCU, 14>(const_cast<double*>(a.cu), a.ctl_bak + (int64_t)FB_NCS * a.n, a.n, i);
+                copy_rows_batched<FB_NCS, 11>(a.cs, a.ctl_bak, a.n, il);
+                copy_rows_batched<FB_NCU, 14>(const_cast<double*>(a.cu), a.ctl_bak + (int64_t)FB_NCS * a.n, a.n, il);
             }
         }
     }
@@ -682,19 +731,23 @@ restart:
     if (FB_REPLAY_MINE) steps_alive = 0;
     if constexpr (X) {
         if (FB_REPLAY_MINE) {
+            double cr[NAL];
 #pragma unroll
-            for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
+            for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + il]; cr[k] = x2_command_row(a, il, k); }
+            __builtin_amdgcn_sched_barrier(0);   // (all fourteen rows requested before the first saturation waits for its own)
+#pragma unroll
+            for (int k = 0; k < NAL; k++) ca[k] = x2_command_sat(k, cr[k]);
         }
-        in.xa = nullptr; in.u_glob = a.u + i; in.n = a.n; in.ui = a.ui[i];
+        in.xa = nullptr; in.u_glob = a.u + il; in.n = a.n; in.ui = a.ui[il];
         sum_payload_of(in);
     } else {
-        load_inputs(a, i, in);
+        load_inputs(a, il, in);
         if constexpr (GROUND) in.load_ground_inputs();
         in.u_glob = nullptr;   // (ground-only inputs are never read in the air, and the ground-capable pass has just fetched them)
         in.sum_payload();
         in.sum_aero((lds_cptr)lds + LDS_AERO, (lds_cptr)rk + LDS_AERO);
     }
-    if (FB_REPLAY_MINE) { stall = a.s[i]; eng = a.s[a.n + i]; }
+    if (FB_REPLAY_MINE) { stall = a.s[il]; eng = a.s[a.n + il]; }
     const double dt = a.dt, hdt = a.dt / 2, dt6 = a.dt / 6;
     const double z = dt / ACT_TAU;
     // The loop below is a WAVE-uniform state machine: stage and step live in SGPRs, so the three-way choice inside emit() is a
@@ -707,20 +760,29 @@ restart:
     if constexpr (X) {
         // FSAL across launches: the previous launch's last evaluation sat at this very state. A wave whose lanes all
         // hold a valid k1 starts at stage 1; otherwise the lanes without one evaluate it first while the others sit out.
-        const bool have_k1 = mine && a.k1 && a.k1_valid[i];
+        const bool have_k1 = mine && a.k1 && a.k1_valid[il];
         if (have_k1) {
 #pragma unroll
-            for (int j = 0; j < FB_NX; j++) {
-                if (SV::skip(j)) continue;
-                const int idx = SV::row(j) * B + t;
-                const double kj = a.k1[(int64_t)j * a.n + i];
-                acc.set(SV::row(j), kj);
-                xc_l[idx] = xs_l[idx] + hdt * kj;
+            for (int j0 = 0; j0 < FB_NX; j0 += 9) {   // (nine rows in flight at a time, like x_n above)
+                double kv[9];
+#pragma unroll
+                for (int g = 0; g < 9; g++) kv[g] = SV::skip(j0 + g) ? 0.0 : a.k1[(int64_t)(j0 + g) * a.n + il];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 9; g++) {
+                    const int j = j0 + g;
+                    if (SV::skip(j)) continue;
+                    const int idx = SV::row(j) * B + t;
+                    acc.set(SV::row(j), kv[g]);
+                    xc_l[idx] = xs_l[idx] + hdt * kv[g];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (__builtin_amdgcn_ballot_w64(mine && !have_k1) == 0) stage = 1;
         else { run = mine && !have_k1; redoing = true; }
     }
+    FB_LAUNCH_STAMP(30);
 #pragma unroll 1
     while (true) {
         StepAux aux;
@@ -755,9 +817,9 @@ restart:
 #pragma unroll
                     for (int r = 0; r < NR; r++) xs_l[r * B + t] = xc_l[r * B + t];
                     if constexpr (X) {
-                        const double ms = stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4);
+                        const double ms = act_stage_mc(stage, z);
 #pragma unroll
-                        for (int k = 0; k < NAL; k++) xa[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                        for (int k = 0; k < NAL; k++) xa[k] = act_stage_pos(xa[k], ca[k], ms, false);   // (the argument the evaluation was given: the same expression)
                     }
                 }
                 if constexpr (X) { if (a.k1) a.k1_valid[i] = 0; }
@@ -768,9 +830,9 @@ restart:
             InT inl = in;                   // and keeps products of the per-lane inputs from being hoisted out of it
             double xa_s[X ? FB_NACT : 1];
             if constexpr (X) {
-                const double ms = stage == 0 ? 1.0 : (stage == 1 ? 1 - z / 2 : (stage == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+                const double ms = act_stage_mc(stage, z);
 #pragma unroll
-                for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+                for (int k = 0; k < NAL; k++) xa_s[k] = act_stage_pos(xa[k], ca[k], ms, stage == 0);
                 if constexpr (!GROUND) { xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0; }   // (never read in the air)
                 inl.xa = xa_s;
                 inl.u_glob = in.u_glob + lds_off;
@@ -902,12 +964,14 @@ restart:
                 if constexpr (X) {
                     if (a.k1 && (dead || step == nsteps)) {   // this evaluation's derivatives (acc = k at stage 0) are the next launch's k1 unless something changed
                         const bool keep = !dead && !mod;
+                        int64_t ik = i;
+                        asm volatile("" : "+v"(ik));   // (the 27 row addresses formed here, not carried — spilled — through the whole loop: see `il`)
                         if (keep) {
 #pragma unroll
                             for (int j = 0; j < FB_NX; j++)
-                                a.k1[(int64_t)j * a.n + i] = SV::skip(j) ? 0.0 : acc.get(SV::row(j));
+                                a.k1[(int64_t)j * a.n + ik] = SV::skip(j) ? 0.0 : acc.get(SV::row(j));
                         }
-                        a.k1_valid[i] = keep ? 1 : 0;
+                        a.k1_valid[ik] = keep ? 1 : 0;
                     }
                 }
                 if (dead) { alive = false; run = false; mod = false; }
@@ -948,30 +1012,33 @@ restart:
         return;
     }
     bool bad = false;
+    int64_t ie = i;
+    asm volatile("" : "+v"(ie));   // (the write-back's row addresses formed here: see `il`)
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
         if (SV::skip(k)) continue;
         const double v = xs_l[SV::row(k) * B + t];
         bad = bad || !isfinite(v);
-        a.x[(int64_t)k * a.n + i] = v;
+        a.x[(int64_t)k * a.n + ie] = v;
     }
     if constexpr (X) {
 #pragma unroll
-        for (int k = 0; k < NAL; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + i] = xa[k]; }
+        for (int k = 0; k < NAL; k++) { bad = bad || !isfinite(xa[k]); a.x[(int64_t)(X2_ACT + k) * a.n + ie] = xa[k]; }
         const double P = 1 - z + z * z / 2 - z * z * z / 6 + z * z * z * z / 24;
 #pragma unroll
         for (int k = NAL; k < FB_NACT; k++) {
-            const double c = x2_command(a, i, k), x0 = a.x[(int64_t)(X2_ACT + k) * a.n + i];
+            const double c = x2_command(a, ie, k), x0 = a.x[(int64_t)(X2_ACT + k) * a.n + ie];
             double v = x0;
             for (int m = 0; m < steps_alive; m++) v = c + (v - c) * P;   // step by step: bit-identical to the per-step update
             bad = bad || !isfinite(v);
-            a.x[(int64_t)(X2_ACT + k) * a.n + i] = v;
+            a.x[(int64_t)(X2_ACT + k) * a.n + ie] = v;
         }
 
     }
-    if (bad) a.status[i] |= FB_ST_NAN;
-    a.s[i] = stall;
-    a.s[a.n + i] = eng;
+    if (bad) a.status[ie] |= FB_ST_NAN;
+    a.s[ie] = stall;
+    a.s[a.n + ie] = eng;
+    FB_LAUNCH_STAMP(31);
 }
 
 // ---- the same update in two halves, for the wave-specialised stepper (k_step_duo<KIN, true>) ---------------------------------------
@@ -1400,7 +1467,7 @@ enum { DUO_C_EXIT = 4, DUO_C_TAP = 8, DUO_C_CMD = 16 };            // per-pair c
 //     D waits for before the next evaluation's T (so the record's rows are at rest whenever an evaluation runs, and when a lane's record is
 //     put back from ctl_bak at the end). Callback order as in the reference: cb_step, then cb_periodic (FC/sim.jl:204-218).
 //   * no derivative is carried across launches (k_step_air<X> saves one evaluation in 201 that way): a.k1_valid is cleared for the lanes
-//     stepped here, the ground-capable pass evaluates its own.
+//     whose steps are committed here; a lane handed over keeps the one the ground-capable pass left it (see the epilogue).
 constexpr int DUO_PT_U = DUO_NPT, DUO_PT_F = DUO_NPT;   // (behind the evaluation's points) role D: flags of the update written; role P: its half of the update done
 constexpr int DUO_PT_Z = DUO_NPT + 1;                   // role D (inside its half of an update): the pitch-axis outer loops' elevator reference put (x2_periodic_half)
 // Diagnostic builds (-DFB_STAMP -DFB_DUO_PHASES, tools/duo_phases.py): the shader clock when role D's first wave of workgroup 0 passes the
@@ -1574,10 +1641,10 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         [[maybe_unused]] auto form_sums = [&](int stg_for, int lds_off) {
             double z = z0;
             asm volatile("" : "+v"(z));
-            const double ms = stg_for == 0 ? 1.0 : (stg_for == 1 ? 1 - z / 2 : (stg_for == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
+            const double ms = act_stage_mc(stg_for, z);
             double xa_s[FB_NACT];
 #pragma unroll
-            for (int k = 0; k < NAL; k++) xa_s[k] = ca[k] + (xa[k] - ca[k]) * ms;
+            for (int k = 0; k < NAL; k++) xa_s[k] = act_stage_pos(xa[k], ca[k], ms, stg_for == 0);
             xa_s[FB_ACT_BRAKE_LEFT] = 0; xa_s[FB_ACT_BRAKE_RIGHT] = 0;   // (never read in the air)
             const InputsX ix = {xa_s, nullptr, a.n, in.ui};
             // InputsAgg::sum_aero's expressions, term by term; the flap-dependent ones (two table locations, three lookups, five of the ten
@@ -1649,8 +1716,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                         // iteration was right (the usual case: the next stage, the same commands)
                         double z = z0;
                         asm volatile("" : "+v"(z));   // (opaque: the stage multipliers are formed here, not hoisted out of the loop into registers that then spill)
-                        const double ms = stg == 0 ? 1.0 : (stg == 1 ? 1 - z / 2 : (stg == 2 ? 1 - z / 2 + z * z / 4 : 1 - z + z * z / 2 - z * z * z / 4));
-                        inl.throttle = clampd(ca[FB_ACT_THROTTLE] + (xa[FB_ACT_THROTTLE] - ca[FB_ACT_THROTTLE]) * ms, 0.0, 1.0);   // InputsX::get_throttle
+                        const double ms = act_stage_mc(stg, z);
+                        inl.throttle = clampd(act_stage_pos(xa[FB_ACT_THROTTLE], ca[FB_ACT_THROTTLE], ms, stg == 0), 0.0, 1.0);   // InputsX::get_throttle
                     }
                     DUO_MARK(1, 12);   // (Cessna172Xv2: stage positions and aerodynamic sums formed and stored)
                     asm volatile("" : "+v"(inl.throttle), "+v"(inl.mixture));
@@ -1774,7 +1841,6 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     for (int k = 0; k < 10; k++) a.duo_pld[(int64_t)k * a.n + i] = pv[k];
                 }
                 in.ui = in0.ui;
-                if (a.k1) a.k1_valid[i] = 0;   // (nothing is carried across launches here; the ground-capable pass evaluates its own k1)
                 if (a.ctl_ratio > 0 && nsteps > 1 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
                     copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
                 }
@@ -1978,6 +2044,12 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
         a.redo[i] = 1;
         return;
     }
+    // Nothing is carried across launches HERE, so the derivative the ground-capable pass may have left for this lane (k_step_air<X>'s k1) is stale once
+    // this launch's steps are committed — and only then: a lane that is handed over (at entry, because its contact states are set; or at its first
+    // evaluation within reach of the ground) has not moved, and the pass that takes it over starts from the k1 it stored itself at the end of the
+    // launch before. (Up to round 6 the flag was cleared at entry for every lane: the ground-capable pass then evaluated k1 again in EVERY launch —
+    // five evaluations where four do in a one-step launch, the shape of every scenario table evaluated after each step; tools/stamp_ground_launch.py.)
+    if constexpr (X) { if (a.k1) a.k1_valid[i] = 0; }
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < FB_NX; k++) {
