@@ -334,6 +334,17 @@ FBD double x2_command_sat(int k, double v) { return clampd(v, (k == FB_ACT_AILER
 FBD double x2_command(const KArgs& a, int64_t i, int k) { return x2_command_sat(k, x2_command_row(a, i, k)); }
 // dst[k n + i] = src[k n + i], k < ROWS, G rows at a time: G loads in flight, then G stores. (Row by row — a load, a wait, a store, the next
 // load behind the store it may alias — the launch-start copy of the control-law record was 94 dependent memory round trips per workgroup.)
+// (k_step_duo's two copies: rows per batch, and a diagnostic switch — FB_X2_BAK = 0 leaves the copies out, which is WRONG for a lane that is handed
+// over behind a control update and only measures what they cost)
+#ifndef FB_X2_BAK
+#define FB_X2_BAK 1
+#endif
+#ifndef FB_X2_BAK_G_CS
+#define FB_X2_BAK_G_CS 11
+#endif
+#ifndef FB_X2_BAK_G_CU
+#define FB_X2_BAK_G_CU 14
+#endif
 template <int ROWS, int G>
 __device__ __forceinline__ void copy_rows_batched(double* dst, const double* src, int64_t n, int64_t i) {
     static_assert(ROWS % G == 0, "");
@@ -1610,9 +1621,9 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                 for (int k = 0; k < NAL; k++) { xa[k] = a.x[(int64_t)(X2_ACT + k) * a.n + i]; ca[k] = x2_command(a, i, k); }
                 in.mixture = clampd(a.u[(int64_t)FB_U_MIXTURE * a.n + i], 0, 1);
                 in.ui = a.ui[i];
-                if (a.ctl_ratio > 0 && nsteps > 1) {   // its half of the launch-start copy of the control-law record (role D copies cu); not for a launch of one step: see k_step_air
-                    static_assert(FB_NCS % 11 == 0 && FB_NCU % 14 == 0, "batch sizes of the record copies");
-                    copy_rows_batched<FB_NCS, 11>(a.ctl_bak, a.cs, a.n, i);
+                if (FB_X2_BAK && a.ctl_ratio > 0 && nsteps > 1) {   // its half of the launch-start copy of the control-law record (role D copies cu); not for a launch of one step: see k_step_air
+                    static_assert(FB_NCS % 11 == 0 && FB_NCU % 14 == 0 && FB_NCS % FB_X2_BAK_G_CS == 0 && FB_NCU % FB_X2_BAK_G_CU == 0, "batch sizes of the record copies");
+                    copy_rows_batched<FB_NCS, FB_X2_BAK_G_CS>(a.ctl_bak, a.cs, a.n, i);
                 }
             }
             // once per launch: the backup rows have left this wave before its first publication, whichever kind that is — role D restores a
@@ -1841,8 +1852,8 @@ __global__ __launch_bounds__(2 * DUO_B) void k_step_duo(KArgs a, int nsteps) {
                     for (int k = 0; k < 10; k++) a.duo_pld[(int64_t)k * a.n + i] = pv[k];
                 }
                 in.ui = in0.ui;
-                if (a.ctl_ratio > 0 && nsteps > 1 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
-                    copy_rows_batched<FB_NCU, 14>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
+                if (FB_X2_BAK && a.ctl_ratio > 0 && nsteps > 1 && !to_ground) {   // its half of the launch-start copy of the control-law record (role P copies cs)
+                    copy_rows_batched<FB_NCU, FB_X2_BAK_G_CU>(a.ctl_bak + (int64_t)FB_NCS * a.n, a.cu, a.n, i);
                 }
             } else {
                 InputsAgg in0;
