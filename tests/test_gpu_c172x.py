@@ -1,5 +1,8 @@
 """Cessna172Xv2 (fly-by-wire actuators + gain-scheduled control laws) on the GPU, through the C ABI, against the CPU oracle
 and against the reference's closed-loop tolerances (lib/FlightApps/test/c172/test_c172x1.jl)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -9,6 +12,7 @@ from oracle_binding import OracleX
 from test_gpu_parity import lattice_trim_params, state_scale
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def ref_to_dev_rows(K):
@@ -485,3 +489,48 @@ def test_x2_mechanisations_device_log(fb, gains, kin):
                 assert np.array_equal(ts.y[k], w.y[rows]), k
         assert (w.status == 0).all()
         w.close()
+
+
+@pytest.mark.parametrize("where", ["air", "ground"])
+def test_x2_launch_partition_is_invisible(fb, gains, where):
+    """A run cut into launches of 1, 7 or 50 steps is the same run, bit for bit — state, control-law record, discrete states — as long as
+    every aircraft stays with one pass (the airborne and the ground-capable pass are different code and agree to rounding only). What it
+    pins: the control-law schedule across launches (ctl_phase), the actuators' closed form (the first RK4 stage IS the state: act_stage_pos,
+    csrc/c172_kernels.hpp), and on the ground the derivative carried from launch to launch (k1 / k1_valid) against the one a launch
+    evaluates for itself — round 6 found the carried one had never been used in the two-pass flow, and was not the same numbers."""
+    K = fb.K
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    n = 512
+    rng = np.random.default_rng(12)
+    out = []
+    for spl in (1, 7, 50):
+        if where == "air":
+            w = fb.Cessna172Xv2World(n, gains=gains)
+            w.set_params(wind_ned=(2.0, -1.0, 0.0))
+            sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=spl)
+            r = np.random.default_rng(5)
+            fb.init(sim, fb.TrimParameters(EAS=r.uniform(38, 55, n), h_e=r.uniform(300, 2500, n), ψ_nb=r.uniform(-3, 3, n)))
+            assert w.trim_success.all()
+            cu = w.cu
+            cu[K["FB_CU_LON_MODE_REQ"]] = r.integers(0, 9, n); cu[K["FB_CU_LAT_MODE_REQ"]] = r.integers(0, 5, n)
+            cu[K["FB_CU_EAS_REF"]] += 2.0; cu[K["FB_CU_CLM_REF"]] += 1.0; cu[K["FB_CU_PHI_REF"]] += 0.2
+            w.cu = cu
+        else:
+            import ground_launch_anatomy as gla
+            w = gla.parked(n)                      # parked, brakes set, engine off ...
+            x = w.x; s = w.s
+            roll = np.arange(n) % 2 == 0           # ... and every other one rolling at 3-12 m/s when the brakes bite
+            x[K["FB_X2_DYN"] + 3] = np.where(roll, np.random.default_rng(6).uniform(3, 12, n), 0.0)
+            w.set_state(x, s)
+            fb.f_init(w, None)
+            sim = fb.Simulation(w, dt=0.01, Δt=0.02, save_on=False, steps_per_launch=spl)
+        fb.step(sim, 1.4); w.sync()               # (140 steps: 1, 7 and 50 all end launches at other instants on the way)
+        out.append(dict(x=w.x, cs=w.cs, s=w.s, status=w.status))
+        w.close()
+    a = out[0]
+    assert (a["status"] == 0).all()
+    if where == "ground":
+        v = a["x"][K["FB_X2_DYN"] + 3]
+        assert v[::2].min() > 0.5 and np.abs(v[1::2]).max() < 0.1, "the rolling half is still rolling (friction regulators active), the parked half stands (settling on its struts)"
+    for b in out[1:]:
+        assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["cs"], b["cs"]) and np.array_equal(a["s"], b["s"]) and np.array_equal(a["status"], b["status"])

@@ -12,10 +12,9 @@ sys.path.insert(0, os.path.join(R, "flight.jl_amd")); sys.path.insert(0, os.path
 import flightbatch as fb
 import traffic_pattern as tpat
 K = fb.K
-ratio = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 
 
-def parked(n):
+def parked(n, ratio=1):
     w = fb.Cessna172Xv2World(n)
     w.set_params(h_terrain=tpat.H_ORTH)
     sim = fb.Simulation(w, dt=0.02, Δt=0.02 * ratio, save_on=False, steps_per_launch=1)
@@ -38,9 +37,10 @@ def parked(n):
 
 
 def main():
+    ratio = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     print(f"# control laws every {ratio} step(s); per-launch HIP events (fb_timing_begin_per_launch), median of the launches of 1.6 s of flight; both passes of a launch")
     for n in (256, 16384, 65536, 262144, 1048576):
-        w = parked(n)
+        w = parked(n, ratio)
         row = []
         for k in (1, 2, 4, 8):
             sim = fb.Simulation(w, dt=0.02, Δt=0.02 * ratio, save_on=False, steps_per_launch=k)

@@ -9,8 +9,8 @@ import sys
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "tools"))
-sys.argv, argv = sys.argv[:1] + ["1"], sys.argv[1:]
-import ground_launch_anatomy as gla   # (parked(); its own sweep runs on import only as __main__)
+argv = sys.argv[1:]
+import ground_launch_anatomy as gla   # (parked(); its own sweep runs only as __main__)
 fb = gla.fb
 n = int(argv[0]) if argv else 65536
 k = int(argv[1]) if len(argv) > 1 else 1
