@@ -2385,12 +2385,16 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
     const int64_t n = a.n;
     const int lane = threadIdx.x;
     const int64_t W = (int64_t)gridDim.x * 64, slot = (int64_t)blockIdx.x * 64 + lane;
-    double* const wsl = ws + slot;
-    auto Jrow = [&](int m, int i, int j) -> double& { return wsl[(int64_t)(TRIM_WS_J + (m * N + i) * N + j) * W]; };
-    auto Zrow = [&](int v, int k) -> double& { return wsl[(int64_t)(TRIM_WS_Z + v * N + k) * W]; };   // v: 0 the given state, 1 the first descent's result, 2 the last good continuation point
+    // The lane's workspace rows are ws[row W + slot]. Their ~170 addresses are invariant in the loop below; formed ahead of it and common to every use
+    // they had nowhere to live: ~140 of them were the kernel's 1 168 B of scratch, each use a scratch_load in front of the row's own load. The lane's
+    // slot is therefore opaque at every access (the INDEX, not the pointer: a laundered pointer loses its address space and the accesses turn
+    // into flat_load / flat_store): an address is one 64-bit multiply-add where the row is used.
+    auto wsb = [&]() -> double* { int64_t sl = slot; asm volatile("" : "+v"(sl)); return ws + sl; };
+    auto Jrow = [&](int m, int i, int j) -> double& { return wsb()[(int64_t)(TRIM_WS_J + (m * N + i) * N + j) * W]; };
+    auto Zrow = [&](int v, int k) -> double& { return wsb()[(int64_t)(TRIM_WS_Z + v * N + k) * W]; };   // v: 0 the given state, 1 the first descent's result, 2 the last good continuation point
     auto env_now = [&]() -> Env {
         if constexpr (PERENV) {
-            auto E = [&](int k) { return wsl[(int64_t)(TRIM_WS_ENV + k) * W]; };
+            auto E = [&](int k) { return wsb()[(int64_t)(TRIM_WS_ENV + k) * W]; };
             return {E(FB_ENV_T_SL), E(FB_ENV_P_SL), E(FB_ENV_WIND_N), E(FB_ENV_WIND_E), E(FB_ENV_WIND_D), E(FB_ENV_H_TERRAIN), a.env.surface, E(ENV_DEV_LN_P), E(ENV_DEV_K_RT)};
         } else return a.env;
     };
@@ -2426,8 +2430,8 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                     const int64_t mine = (int64_t)base + __builtin_popcountll(idle & ((1ull << lane) - 1));
                     if (mine < n) {
                         i = mine;
-                        for (int k = 0; k < FB_NTP; k++) wsl[(int64_t)k * W] = tp[(int64_t)k * n + i];
-                        if constexpr (PERENV) for (int k = 0; k < ENV_DEV_ROWS; k++) wsl[(int64_t)(TRIM_WS_ENV + k) * W] = a.env_rows[(int64_t)k * n + i];
+                        for (int k = 0; k < FB_NTP; k++) wsb()[(int64_t)k * W] = tp[(int64_t)k * n + i];
+                        if constexpr (PERENV) for (int k = 0; k < ENV_DEV_ROWS; k++) wsb()[(int64_t)(TRIM_WS_ENV + k) * W] = a.env_rows[(int64_t)k * n + i];
 #pragma unroll
                         for (int k = 0; k < N; k++) { S.z[k] = ts[(int64_t)k * n + i]; Zrow(0, k) = S.z[k]; }
                         active = true; fresh = true; mode = 0; maxit = TRIM_MAX_ITER;
@@ -2549,7 +2553,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
             if (__builtin_amdgcn_ballot_w64(need) != 0) {
                 if (need) {
                     TrimP p;
-                    trim_load_params(p, ws, W, slot);
+                    trim_load_params(p, wsb(), W, 0);   // (the lane's parked parameters: through the opaque base, like every workspace row)
                     trim_resid_body<true>(p, zq, env_now(), T, rq);
                 }
             }
@@ -2676,7 +2680,7 @@ __global__ __launch_bounds__(64) void k_trim(KArgs a, const double* tp, double* 
                     constexpr int row[14] = {FB_TP_H_E, FB_TP_EAS, FB_TP_GAMMA_WB_N, FB_TP_PSI_WB_DOT, FB_TP_THETA_WB_DOT, FB_TP_BETA_A, FB_TP_FUEL_LOAD, FB_TP_MIXTURE,
                                              FB_TP_FLAPS, FB_TP_PAYLOAD, FB_TP_PAYLOAD + 1, FB_TP_PAYLOAD + 2, FB_TP_PAYLOAD + 3, FB_TP_PAYLOAD + 4};
 #pragma unroll
-                    for (int k = 0; k < 14; k++) wsl[(int64_t)row[k] * W] = d0[k] + tn * (tp[(int64_t)row[k] * n + i] - d0[k]);
+                    for (int k = 0; k < 14; k++) wsb()[(int64_t)row[k] * W] = d0[k] + tn * (tp[(int64_t)row[k] * n + i] - d0[k]);
                     fresh = true;
                 } else active = false;
             }
